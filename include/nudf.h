@@ -1,0 +1,190 @@
+/* libnudf -- C ABI of the MI355X-native NeuralUDF volume-rendering hot path.
+ *
+ * Plain pointers and sizes only (no torch types).  All pointers are DEVICE pointers to
+ * contiguous fp32 unless noted; the caller owns every buffer (kernels never allocate);
+ * every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant,
+ * and returns 0 or a hipError_t value (text via nudf_last_error()).  No host syncs.
+ *
+ * Each entry point names the chain of PyTorch ops of the reference (xxlong0/NeuralUDF,
+ * paths relative to the reference root) that it replaces -- the reference itself has no
+ * native kernels and no FFI; INTEGRATION.md shows the ctypes binding a maintainer adds.
+ */
+#ifndef NUDF_H
+#define NUDF_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int nudf_version(void);
+const char* nudf_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense layer GEMMs (fp32 MFMA).  Replace F.linear + weight_norm + Softplus/ReLU and their
+ * autograd (double-)backward:  models/fields.py:192-231 (UDFNetwork.forward/.gradient),
+ * :452-495 (ResidualRenderingNetwork.forward), :599-628 (NeRF.forward).
+ * ---------------------------------------------------------------------------------- */
+enum {
+  NUDF_EPI_NONE = 0,      /* C1 = (acc + bias) * scale                                   */
+  NUDF_EPI_SOFTPLUS = 1,  /* C1 = softplus100(acc+bias)*scale ; C2 = softplus100'(..)     */
+  NUDF_EPI_RELU = 2,      /* C1 = relu(acc+bias)*scale                                   */
+  NUDF_EPI_MUL = 3,       /* C1 = acc * X1 * scale                                       */
+  NUDF_EPI_MULMASK = 4,   /* C1 = (X1 > 0) ? acc*scale : 0      (ReLU backward)          */
+  NUDF_EPI_TANGENT = 5,   /* C1 = acc*X1*scale ; C2 = acc*X2*100*(1-X1)                   */
+  NUDF_EPI_BWD = 6,       /* C1 = acc*scale*X1 + X2                                      */
+  NUDF_EPI_SIGMOID = 7,   /* cols < iparam: sigmoid -> C1 (and C2) ; others raw -> C3[row, col-iparam] (or C1) */
+  NUDF_EPI_UDFHEAD = 8,   /* col 0: |v|*scale -> C2[row], sign -> C3[row]; col c>0 -> C1[row,c-1] */
+  NUDF_EPI_SKIPSPLIT = 9, /* col < iparam: C1 = acc*X1*scale ; else C2[col-iparam] = acc*scale */
+  NUDF_EPI_RELU_DUAL = 10,/* C1 = C2 = relu(acc+bias)                                    */
+  NUDF_EPI_ADDMASK = 11   /* C1 = (X1 > 0) ? (acc + X2)*scale : 0   (ReLU backward at a join) */
+};
+
+typedef struct NudfGemmNN {
+  const float* A; int32_t lda;      /* [M, K] row-major, K % 32 == 0, lda % 4 == 0        */
+  const float* B; int32_t ldb;      /* [K, ldb] row-major (packed W^T or W), ldb % 4 == 0 */
+  const float* bias;                /* [N] or NULL                                        */
+  float* C1; int32_t ldc1;          /* [M, N]                                             */
+  float* C2; int32_t ldc2;          /* second output or NULL                              */
+  float* C3; int32_t ldc3;          /* third output (UDFHEAD: sign per row; SIGMOID: raw tail) or NULL */
+  const float* X1; int32_t ldx1;    /* epilogue operand 1 [M, N] or NULL                  */
+  const float* X2; int32_t ldx2;    /* epilogue operand 2 [M, N] or NULL                  */
+  int32_t M, N, K;
+  int32_t epi;                      /* NUDF_EPI_*                                         */
+  int32_t iparam;
+  float scale;
+} NudfGemmNN;
+
+/* C[M,N] = epilogue(A[M,K] B[K,N]) */
+int nudf_gemm_nn(const NudfGemmNN* args, void* stream);
+
+typedef struct NudfGemmTN {
+  const float* A1; int32_t lda1; int32_t na1;   /* [M, na1]                               */
+  const float* B1; int32_t ldb1;                /* [M, ldb1]                              */
+  const float* A2; int32_t lda2; int32_t na2;   /* optional second pair (NULL to skip)    */
+  const float* B2; int32_t ldb2;
+  float* C; int32_t ldc;                        /* [NA, NB], accumulated with atomics     */
+  float* dbias;                                 /* [NA] += column sums of A1, or NULL     */
+  int32_t M, NA, NB;
+  int32_t rows_per_block;                       /* 0 = choose                             */
+} NudfGemmTN;
+
+/* C[NA,NB] += A1^T B1 (+ A2^T B2): weight gradients, reduction over the M points */
+int nudf_gemm_tn(const NudfGemmTN* args, void* stream);
+
+
+/* ------------------------------------------------------------------------------------
+ * Fused UDF -> density -> alpha -> composite (forward / backward), one wavefront per ray.
+ * Replaces models/udf_renderer_blending.py:352-362, 370-423, 484-553 (+ :151-159, :292-320).
+ * ---------------------------------------------------------------------------------- */
+typedef struct NudfComposite {
+  const float* rays_o; const float* rays_d;   /* [N,3]                                     */
+  const float* z;                              /* [N,S] sorted sample positions             */
+  const float* udf;                            /* [N,S] unsigned distance at the mid points */
+  const float* grad;                           /* [N,S,3] d udf / d x                       */
+  const float* color;                          /* [N,S,3] view-dependent colour (sigmoid'd) */
+  const float* color_base;                     /* [N,S,3]                                   */
+  const float* bg_z;                           /* [N,n_out] outside sample positions / NULL */
+  const float* bg_sigma;                       /* [N,n_out] raw NeRF density                */
+  const float* bg_color;                       /* [N,n_out,3]                               */
+  const float* scal;                           /* [3] device: inv_s, beta, gamma (clipped)  */
+  const float* sample_dist;                    /* [1] device                                */
+  const float* background_rgb;                 /* [3] device or NULL                        */
+  int32_t N, S, n_out, s_nominal;              /* s_nominal: #weights summed into weight_sum */
+  int32_t has_anneal; float cos_anneal;        /* cos_anneal_ratio (None -> has_anneal = 0) */
+  float flip_saturation;
+  int32_t use_norm_grad;
+  float sparse_scale;
+  /* outputs */
+  float* weights;                              /* [N,S+n_out]                               */
+  float* out_color; float* out_color_base;     /* [N,3]                                     */
+  float* out_depth;                            /* [N]                                       */
+  float* out_normals;                          /* [N,3]                                     */
+  float* out_wsum; float* out_wsum_all;        /* [N]                                       */
+  float* sums;                                 /* [5] += {eik_num, eik_den, eikns_num, eikns_den, sparse_sum} (caller zeroes) */
+  /* optional diagnostics, [N,S] each or NULL */
+  float* o_alpha; float* o_alpha_plus; float* o_alpha_minus; float* o_vis_prob;
+  float* o_alpha_occ; float* o_raw_occ; float* o_true_cos; float* o_grad_mag;
+  float* o_mid_z; float* o_dists; float* o_inside; float* o_flip;
+} NudfComposite;
+
+typedef struct NudfCompositeGrad {
+  /* upstream (any may be NULL = zero) */
+  const float* d_color; const float* d_color_base;   /* [N,3]                              */
+  const float* d_weights;                             /* [N,S+n_out]                        */
+  const float* d_depth;                               /* [N]                                */
+  const float* d_normals;                             /* [N,3]                              */
+  const float* d_wsum; const float* d_wsum_all;       /* [N]                                */
+  const float* d_sums;                                /* [5] device                         */
+  /* results */
+  float* o_d_udf;                                     /* [N,S]                              */
+  float* o_d_grad;                                    /* [N,S,3]                            */
+  float* o_d_color; float* o_d_color_base;            /* [N,S,3] or NULL                    */
+  float* o_d_bg_sigma;                                /* [N,n_out] or NULL                  */
+  float* o_d_bg_color;                                /* [N,n_out,3] or NULL                */
+  float* o_d_scal;                                    /* [3] += d inv_s, d beta, d gamma (caller zeroes) */
+} NudfCompositeGrad;
+
+int nudf_composite_fwd(const NudfComposite* args, void* stream);
+int nudf_composite_bwd(const NudfComposite* args, const NudfCompositeGrad* grads, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Hierarchical importance re-sampling (no autograd), one wavefront per ray.
+ *   nudf_upsample: up_sample_unbias (mode 0, models/udf_renderer_blending.py:197-272) or
+ *                  up_sample_no_occ_aware (mode 1, :834-866) fused with sample_pdf(det=True) (:66-104)
+ *   nudf_merge   : sorted merge of cat_z_vals (:278-288), carrying udf along (udf* may be NULL)
+ * ---------------------------------------------------------------------------------- */
+typedef struct NudfUpsample {
+  const float* rays_o; const float* rays_d;   /* [N,3]                                     */
+  const float* z; const float* udf;           /* [N,M] current samples and their udf       */
+  const float* u;                              /* [K] quantiles linspace(.5/K, 1-.5/K, K)   */
+  const float* sample_dist;                    /* [1] device                                */
+  const float* gamma_dev;                      /* [1] device gamma (mix schedule) or NULL   */
+  int32_t N, M, K, mode;
+  float inv_s, beta, gamma;
+  float* z_new;                                /* [N,K] ascending                           */
+  float* pts_new;                              /* [N*K,3] o + d*z_new, or NULL              */
+} NudfUpsample;
+int nudf_upsample(const NudfUpsample* args, void* stream);
+int nudf_merge(const float* z, const float* udf, const float* z_new, const float* udf_new, int N, int M,
+               int K, float* z_out, float* udf_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ray sampling helpers (models/udf_renderer_blending.py:605-630, 352-357, 164-173, 205)
+ * ---------------------------------------------------------------------------------- */
+int nudf_coarse_z(const float* near, const float* far, int nf_stride, const float* t_rand, int N, int S,
+                  float* z, float* sample_dist, void* stream);
+int nudf_outside_z(const float* far, int f_stride, const float* lin, int N, int n_out, int n_samples,
+                   float* z_out, void* stream);
+int nudf_ray_points(const float* rays_o, const float* rays_d, const float* z, const float* sample_dist, int N,
+                    int S, int mode, float* pts, void* stream);
+
+/* positional encoding value / JVP (tangent != NULL) / VJP  (models/embedder.py:15-36) */
+int nudf_posenc(const float* x, int xld, int xdiv, const float* tangent, int D, int L, float in_scale, int P,
+                float* dst1, int ld1, float scale1, float* dst2, int ld2, float scale2, void* stream);
+int nudf_posenc_vjp(const float* x, int xld, int D, int L, float in_scale, int P, const float* src1, int ld1,
+                    float scale1, const float* src2, int ld2, float scale2, float* g, void* stream);
+int nudf_copy_cols(const float* src, int lds, int sdiv, float* dst, int ldd, int ncols, int P, float scale,
+                   void* stream);
+int nudf_add_cols(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int P, int C, void* stream);
+
+/* heads of the MLP chains */
+int nudf_udf_grad_seed(const float* sign, const float* w_row0, const float* sig, int lds, int P, int C,
+                       float inv_scale, float* out, int ldo, void* stream);
+int nudf_udf_head_bwd(const float* sign, const float* dudf, const float* dfeat, int ldf, int P, int F,
+                      float scale, float* out, int ldo, void* stream);
+int nudf_signed_colsum(const float* sign, const float* R, int ldr, int P, int C, float scale, float* out,
+                       void* stream);
+int nudf_sigmoid_head_bwd(const float* y, const float* dy, const float* dy_extra, int ldx, int nsig,
+                          const float* draw, int ldr, int nraw, int P, float* out, int ldo, void* stream);
+
+/* weight_norm packing (torch.nn.utils.weight_norm at fields.py:175-176, 433-446) and its backward */
+int nudf_weightnorm_pack(const float* v, const float* g, int out, int in, const int* perm, float* W, int ldw,
+                         float* Wt, int ldwt, float* inv_norm, void* stream);
+int nudf_weightnorm_unpack_grad(const float* dW, int ldw, const float* v, const float* g, const float* inv_norm,
+                                int out, int in, const int* perm, float* dv, float* dg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUDF_H */

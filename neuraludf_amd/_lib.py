@@ -1,0 +1,156 @@
+"""ctypes binding of libnudf.so (declared in include/nudf.h).
+
+The product path has NO fallback: if the library is missing or a call fails this raises.
+torch is imported first so that the library's HIP runtime dependency (libamdhip64.so.7)
+resolves to the copy already loaded by PyTorch-ROCm (one HIP runtime per process)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before libnudf, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnudf.so")
+
+c_fp = C.c_void_p
+i32 = C.c_int32
+f32 = C.c_float
+
+
+class NudfError(RuntimeError):
+    pass
+
+
+class GemmNN(C.Structure):
+    _fields_ = [("A", c_fp), ("lda", i32), ("B", c_fp), ("ldb", i32), ("bias", c_fp),
+                ("C1", c_fp), ("ldc1", i32), ("C2", c_fp), ("ldc2", i32), ("C3", c_fp), ("ldc3", i32),
+                ("X1", c_fp), ("ldx1", i32), ("X2", c_fp), ("ldx2", i32),
+                ("M", i32), ("N", i32), ("K", i32), ("epi", i32), ("iparam", i32), ("scale", f32)]
+
+
+class GemmTN(C.Structure):
+    _fields_ = [("A1", c_fp), ("lda1", i32), ("na1", i32), ("B1", c_fp), ("ldb1", i32),
+                ("A2", c_fp), ("lda2", i32), ("na2", i32), ("B2", c_fp), ("ldb2", i32),
+                ("C", c_fp), ("ldc", i32), ("dbias", c_fp), ("M", i32), ("NA", i32), ("NB", i32),
+                ("rows_per_block", i32)]
+
+
+class Composite(C.Structure):
+    _fields_ = [("rays_o", c_fp), ("rays_d", c_fp), ("z", c_fp), ("udf", c_fp), ("grad", c_fp),
+                ("color", c_fp), ("color_base", c_fp), ("bg_z", c_fp), ("bg_sigma", c_fp), ("bg_color", c_fp),
+                ("scal", c_fp), ("sample_dist", c_fp), ("background_rgb", c_fp),
+                ("N", i32), ("S", i32), ("n_out", i32), ("s_nominal", i32),
+                ("has_anneal", i32), ("cos_anneal", f32), ("flip_saturation", f32),
+                ("use_norm_grad", i32), ("sparse_scale", f32),
+                ("weights", c_fp), ("out_color", c_fp), ("out_color_base", c_fp), ("out_depth", c_fp),
+                ("out_normals", c_fp), ("out_wsum", c_fp), ("out_wsum_all", c_fp), ("sums", c_fp),
+                ("o_alpha", c_fp), ("o_alpha_plus", c_fp), ("o_alpha_minus", c_fp), ("o_vis_prob", c_fp),
+                ("o_alpha_occ", c_fp), ("o_raw_occ", c_fp), ("o_true_cos", c_fp), ("o_grad_mag", c_fp),
+                ("o_mid_z", c_fp), ("o_dists", c_fp), ("o_inside", c_fp), ("o_flip", c_fp)]
+
+
+class CompositeGrad(C.Structure):
+    _fields_ = [("d_color", c_fp), ("d_color_base", c_fp), ("d_weights", c_fp), ("d_depth", c_fp),
+                ("d_normals", c_fp), ("d_wsum", c_fp), ("d_wsum_all", c_fp), ("d_sums", c_fp),
+                ("o_d_udf", c_fp), ("o_d_grad", c_fp), ("o_d_color", c_fp), ("o_d_color_base", c_fp),
+                ("o_d_bg_sigma", c_fp), ("o_d_bg_color", c_fp), ("o_d_scal", c_fp)]
+
+
+class Upsample(C.Structure):
+    _fields_ = [("rays_o", c_fp), ("rays_d", c_fp), ("z", c_fp), ("udf", c_fp), ("u", c_fp),
+                ("sample_dist", c_fp), ("gamma_dev", c_fp),
+                ("N", i32), ("M", i32), ("K", i32), ("mode", i32),
+                ("inv_s", f32), ("beta", f32), ("gamma", f32),
+                ("z_new", c_fp), ("pts_new", c_fp)]
+
+
+EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
+           SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11)
+
+# every symbol include/nudf.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_gemm_tn", "nudf_composite_fwd",
+    "nudf_composite_bwd", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
+    "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
+    "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
+    "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
+]
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_ARGTYPES = {
+    "nudf_gemm_nn": [C.POINTER(GemmNN), _P],
+    "nudf_gemm_tn": [C.POINTER(GemmTN), _P],
+    "nudf_composite_fwd": [C.POINTER(Composite), _P],
+    "nudf_composite_bwd": [C.POINTER(Composite), C.POINTER(CompositeGrad), _P],
+    "nudf_upsample": [C.POINTER(Upsample), _P],
+    "nudf_merge": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "nudf_coarse_z": [_P, _P, _I, _P, _I, _I, _P, _P, _P],
+    "nudf_outside_z": [_P, _I, _P, _I, _I, _I, _P, _P],
+    "nudf_ray_points": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "nudf_posenc": [_P, _I, _I, _P, _I, _I, _F, _I, _P, _I, _F, _P, _I, _F, _P],
+    "nudf_posenc_vjp": [_P, _I, _I, _I, _F, _I, _P, _I, _F, _P, _I, _F, _P, _P],
+    "nudf_copy_cols": [_P, _I, _I, _P, _I, _I, _I, _F, _P],
+    "nudf_add_cols": [_P, _I, _P, _I, _P, _I, _I, _I, _P],
+    "nudf_udf_grad_seed": [_P, _P, _P, _I, _I, _I, _F, _P, _I, _P],
+    "nudf_udf_head_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _I, _P],
+    "nudf_signed_colsum": [_P, _P, _I, _I, _I, _F, _P, _P],
+    "nudf_sigmoid_head_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P],
+    "nudf_weightnorm_pack": [_P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P],
+    "nudf_weightnorm_unpack_grad": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+}
+
+_lib = None
+
+
+def _bind(l):
+    for name, at in _ARGTYPES.items():
+        fn = getattr(l, name)
+        fn.argtypes = at
+        fn.restype = C.c_int
+
+
+def lib():
+    """The loaded library; raises NudfError when it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NudfError(
+                f"{LIB_PATH} not found: build it with `python -m neuraludf_amd.build` "
+                "(the NeuralUDF hot path has no CPU/PyTorch fallback)")
+        try:
+            _lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NudfError(f"cannot load {LIB_PATH}: {e}") from e
+        _lib.nudf_last_error.restype = C.c_char_p
+        _lib.nudf_version.restype = C.c_int
+        _bind(_lib)
+    return _lib
+
+
+def ptr(t):
+    """raw device pointer of a contiguous fp32/int32 CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NudfError("libnudf kernels need device tensors (got a CPU tensor): run on an MI355X")
+    if not t.is_contiguous():
+        raise NudfError("libnudf kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().nudf_last_error()
+        raise NudfError(f"{what} failed (hipError {rc}): {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    """call an entry point on torch's current stream; struct arguments are passed by reference."""
+    fn = getattr(lib(), name)
+    conv = [C.byref(a) if isinstance(a, C.Structure) else a for a in args]
+    check(fn(*conv, stream()), name)

@@ -1,0 +1,385 @@
+// Ray points, positional encodings (forward / JVP / VJP) and the small per-point head
+// kernels around the MLP GEMM chains.  All HBM-bound elementwise work, one thread per
+// output element so that stores are coalesced.
+#include "nudf_common.h"
+#include "../../include/nudf.h"
+
+static inline int nblocks(long long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+// ---------------------------------------------------------------------------------------
+// coarse samples: z = near + (far-near)*linspace(0,1,S) + t_rand*2/S
+// (models/udf_renderer_blending.py:606-608, 617-619); sample_dist = mean((far-near)/S) (:605)
+// ---------------------------------------------------------------------------------------
+__global__ void coarse_z_kernel(const float* near, const float* far, int nf_stride, const float* t_rand,
+                                int N, int S, float* z) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * S) return;
+  int r = idx / S, s = idx - r * S;
+  float nr = near[r * nf_stride], fr = far[r * nf_stride];
+  // torch.linspace(0,1,S): i*step for the first half, 1-(S-1-i)*step for the second
+  float step = 1.0f / (float)(S - 1);
+  float t = (s < S / 2) ? s * step : 1.0f - (S - 1 - s) * step;
+  float v = nr + (fr - nr) * t;
+  if (t_rand) v = v + t_rand[r] * 2.0f / (float)S;
+  z[idx] = v;
+}
+
+__global__ void sample_dist_kernel(const float* near, const float* far, int n, int S, float* out) {
+  // single block: mean over n of (far-near)/S
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (far[i] - near[i]) / (float)S;
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+
+extern "C" int nudf_coarse_z(const float* near, const float* far, int nf_stride, const float* t_rand, int N, int S,
+                             float* z, float* sample_dist, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(coarse_z_kernel, dim3(nblocks((long long)N * S, 256)), dim3(256), 0, st, near, far, nf_stride,
+                     t_rand, N, S, z);
+  if (sample_dist)
+    hipLaunchKernelGGL(sample_dist_kernel, dim3(1), dim3(256), 0, st, near, far, nf_stride ? N : 1, S, sample_dist);
+  NUDF_CHECK_LAUNCH("nudf_coarse_z");
+  return 0;
+}
+
+// outside samples (models/udf_renderer_blending.py:611, 621-630):
+//   lin = linspace(1e-3, 1-1/(n_out+1), n_out) [optionally stratified-jittered, done by caller]
+//   z_out = far / flip(lin) + 1/n_samples
+__global__ void outside_z_kernel(const float* far, int f_stride, const float* lin, int N, int n_out, float inv_ns,
+                                 float* z_out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * n_out) return;
+  int r = idx / n_out, j = idx - r * n_out;
+  z_out[idx] = far[r * f_stride] / lin[n_out - 1 - j] + inv_ns;
+}
+extern "C" int nudf_outside_z(const float* far, int f_stride, const float* lin, int N, int n_out, int n_samples,
+                              float* z_out, void* stream) {
+  hipLaunchKernelGGL(outside_z_kernel, dim3(nblocks((long long)N * n_out, 256)), dim3(256), 0, (hipStream_t)stream,
+                     far, f_stride, lin, N, n_out, 1.0f / (float)n_samples, z_out);
+  NUDF_CHECK_LAUNCH("nudf_outside_z");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// points along rays.  mode 0: end points o + d*z (up-sampling code, :205, 277, 729)
+//                     mode 1: interval mid points o + d*(z + dist/2) (:352-357, 164-169),
+//                             dist = z[i+1]-z[i], last = sample_dist
+//                     mode 2: mode 1 + NeRF++ inverted sphere (x/r, 1/r), r = clip(|x|,1,1e10) (:171-173)
+// ---------------------------------------------------------------------------------------
+__global__ void ray_points_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
+                                  const float* sample_dist, int N, int S, int mode, float* __restrict__ pts) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * S) return;
+  int r = idx / S, s = idx - r * S;
+  float t = z[idx];
+  if (mode >= 1) {
+    float dist = (s < S - 1) ? (z[idx + 1] - t) : sample_dist[0];
+    t = t + dist * 0.5f;
+  }
+  float px = o[r * 3 + 0] + d[r * 3 + 0] * t;
+  float py = o[r * 3 + 1] + d[r * 3 + 1] * t;
+  float pz = o[r * 3 + 2] + d[r * 3 + 2] * t;
+  if (mode == 2) {
+    float rr = sqrtf(px * px + py * py + pz * pz);
+    rr = fminf(fmaxf(rr, 1.0f), 1e10f);
+    pts[(size_t)idx * 4 + 0] = px / rr;
+    pts[(size_t)idx * 4 + 1] = py / rr;
+    pts[(size_t)idx * 4 + 2] = pz / rr;
+    pts[(size_t)idx * 4 + 3] = 1.0f / rr;
+  } else {
+    pts[(size_t)idx * 3 + 0] = px;
+    pts[(size_t)idx * 3 + 1] = py;
+    pts[(size_t)idx * 3 + 2] = pz;
+  }
+}
+extern "C" int nudf_ray_points(const float* rays_o, const float* rays_d, const float* z, const float* sample_dist, int N,
+                               int S, int mode, float* pts, void* stream) {
+  if (N * S == 0) return 0;
+  hipLaunchKernelGGL(ray_points_kernel, dim3(nblocks((long long)N * S, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                     rays_d, z, sample_dist, N, S, mode, pts);
+  NUDF_CHECK_LAUNCH("nudf_ray_points");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// positional encoding [x, sin(2^k x), cos(2^k x)]_k  (models/embedder.py:15-36), written into
+// up to two destinations (column offset + scale each): e.g. the UDF net's layer-0 input and the
+// skip-concat tail of its layer-4 input (/sqrt(2), fields.py:202-203).
+// mode 0: value ; mode 1: JVP with tangent v (d/dx applied to v).
+// x row for point p is x[(p / xdiv) * xld .. +D]  (xdiv = S broadcasts per-ray directions)
+// ---------------------------------------------------------------------------------------
+__global__ void posenc_kernel(const float* __restrict__ x, int xld, int xdiv, const float* __restrict__ v, int D, int L,
+                              float in_scale, int P, float* d1, int ld1, float s1, float* d2, int ld2, float s2,
+                              int mode) {
+  const int E = D * (2 * L + 1);
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)P * E) return;
+  int p = (int)(idx / E), e = (int)(idx - (long long)p * E);
+  int blk = e / D, j = e - blk * D;
+  float xv = x[(size_t)(p / xdiv) * xld + j] * in_scale;
+  float val;
+  if (blk == 0) {
+    val = (mode == 0) ? xv : v[(size_t)p * D + j] * in_scale;
+  } else {
+    int k = (blk - 1) >> 1;
+    float f = (float)(1 << k);
+    float a = xv * f;
+    bool is_sin = ((blk - 1) & 1) == 0;
+    if (mode == 0) val = is_sin ? sinf(a) : cosf(a);
+    else val = (is_sin ? cosf(a) : -sinf(a)) * f * v[(size_t)p * D + j] * in_scale;
+  }
+  if (d1) d1[(size_t)p * ld1 + e] = val * s1;
+  if (d2) d2[(size_t)p * ld2 + e] = val * s2;
+}
+extern "C" int nudf_posenc(const float* x, int xld, int xdiv, const float* tangent, int D, int L, float in_scale, int P,
+                           float* dst1, int ld1, float scale1, float* dst2, int ld2, float scale2, void* stream) {
+  if (P == 0) return 0;
+  const int E = D * (2 * L + 1);
+  hipLaunchKernelGGL(posenc_kernel, dim3(nblocks((long long)P * E, 256)), dim3(256), 0, (hipStream_t)stream, x, xld,
+                     xdiv, tangent, D, L, in_scale, P, dst1, ld1, scale1, dst2, ld2, scale2, tangent ? 1 : 0);
+  NUDF_CHECK_LAUNCH("nudf_posenc");
+  return 0;
+}
+
+// VJP of the encoding: g[p, j] = in_scale * sum_e dE[p,e] * dE_e/dx_j, dE gathered from up to two
+// sources (scaled).  One thread per point (D*(2L+1) reads, D writes).
+__global__ void posenc_vjp_kernel(const float* __restrict__ x, int xld, int D, int L, float in_scale, int P,
+                                  const float* __restrict__ s1, int ld1, float c1, const float* __restrict__ s2,
+                                  int ld2, float c2, float* __restrict__ g) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  for (int j = 0; j < D; ++j) {
+    float xv = x[(size_t)p * xld + j] * in_scale;
+    auto de = [&](int e) {
+      float t = 0.f;
+      if (s1) t += s1[(size_t)p * ld1 + e] * c1;
+      if (s2) t += s2[(size_t)p * ld2 + e] * c2;
+      return t;
+    };
+    float acc = de(j);
+    for (int k = 0; k < L; ++k) {
+      float f = (float)(1 << k);
+      float a = xv * f;
+      float sn, cs;
+      sincosf(a, &sn, &cs);
+      acc += f * (de(D * (1 + 2 * k) + j) * cs - de(D * (2 + 2 * k) + j) * sn);
+    }
+    g[(size_t)p * D + j] = acc * in_scale;
+  }
+}
+extern "C" int nudf_posenc_vjp(const float* x, int xld, int D, int L, float in_scale, int P, const float* src1, int ld1,
+                               float scale1, const float* src2, int ld2, float scale2, float* g, void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(posenc_vjp_kernel, dim3(nblocks(P, 256)), dim3(256), 0, (hipStream_t)stream, x, xld, D, L,
+                     in_scale, P, src1, ld1, scale1, src2, ld2, scale2, g);
+  NUDF_CHECK_LAUNCH("nudf_posenc_vjp");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// column block copy: dst[p, 0:ncols] = src[(p/sdiv), 0:ncols] * scale   (pts -> colour-net input etc.)
+// ---------------------------------------------------------------------------------------
+__global__ void copy_cols_kernel(const float* __restrict__ src, int lds, int sdiv, float* __restrict__ dst, int ldd,
+                                 int ncols, int P, float scale) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)P * ncols) return;
+  int p = (int)(idx / ncols), c = (int)(idx - (long long)p * ncols);
+  dst[(size_t)p * ldd + c] = src[(size_t)(p / sdiv) * lds + c] * scale;
+}
+extern "C" int nudf_copy_cols(const float* src, int lds, int sdiv, float* dst, int ldd, int ncols, int P, float scale,
+                              void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(nblocks((long long)P * ncols, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     lds, sdiv, dst, ldd, ncols, P, scale);
+  NUDF_CHECK_LAUNCH("nudf_copy_cols");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// seed of the reverse sweep for d udf / d x (fields.py:219-231 via autograd):
+//   da_last_hidden[p, c] = sign[p] * W_last[0, c] * inv_scale * softplus'(a)[p, c]
+// ---------------------------------------------------------------------------------------
+__global__ void udf_grad_seed_kernel(const float* __restrict__ sign, const float* __restrict__ wrow,
+                                     const float* __restrict__ sig, int lds, int P, int C, float inv_scale,
+                                     float* __restrict__ out, int ldo) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)P * C) return;
+  int p = (int)(idx / C), c = (int)(idx - (long long)p * C);
+  out[(size_t)p * ldo + c] = sign[p] * wrow[c] * inv_scale * sig[(size_t)p * lds + c];
+}
+extern "C" int nudf_udf_grad_seed(const float* sign, const float* w_row0, const float* sig, int lds, int P, int C,
+                                  float inv_scale, float* out, int ldo, void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(udf_grad_seed_kernel, dim3(nblocks((long long)P * C, 256)), dim3(256), 0, (hipStream_t)stream, sign,
+                     w_row0, sig, lds, P, C, inv_scale, out, ldo);
+  NUDF_CHECK_LAUNCH("nudf_udf_grad_seed");
+  return 0;
+}
+
+// adjoint of the UDF output layer: abar[p,0] = sign[p]*scale*dudf[p] ; abar[p,1+c] = dfeat[p,c]
+__global__ void udf_head_bwd_kernel(const float* __restrict__ sign, const float* __restrict__ dudf,
+                                    const float* __restrict__ dfeat, int ldf, int P, int F, float scale,
+                                    float* __restrict__ out, int ldo) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = F + 1;
+  if (idx >= (long long)P * C) return;
+  int p = (int)(idx / C), c = (int)(idx - (long long)p * C);
+  float v;
+  if (c == 0) v = dudf ? sign[p] * scale * dudf[p] : 0.f;
+  else v = dfeat ? dfeat[(size_t)p * ldf + (c - 1)] : 0.f;
+  out[(size_t)p * ldo + c] = v;
+}
+extern "C" int nudf_udf_head_bwd(const float* sign, const float* dudf, const float* dfeat, int ldf, int P, int F,
+                                 float scale, float* out, int ldo, void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(udf_head_bwd_kernel, dim3(nblocks((long long)P * (F + 1), 256)), dim3(256), 0, (hipStream_t)stream,
+                     sign, dudf, dfeat, ldf, P, F, scale, out, ldo);
+  NUDF_CHECK_LAUNCH("nudf_udf_head_bwd");
+  return 0;
+}
+
+// sign-weighted column sums: out[c] += sum_p sign[p] * R[p, c]  (gradient of row 0 of the last
+// UDF layer through the d udf/dx path).  Block = 256 rows x C columns.
+__global__ void signed_colsum_kernel(const float* __restrict__ sign, const float* __restrict__ R, int ldr, int P, int C,
+                                     float scale, float* __restrict__ out) {
+  int c = threadIdx.x;
+  int p0 = blockIdx.x * 256;
+  int p1 = min(p0 + 256, P);
+  for (; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int p = p0; p < p1; ++p) acc += sign[p] * R[(size_t)p * ldr + c];
+    atomicAdd(out + c, acc * scale);
+  }
+}
+extern "C" int nudf_signed_colsum(const float* sign, const float* R, int ldr, int P, int C, float scale, float* out,
+                                  void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(signed_colsum_kernel, dim3(nblocks(P, 256)), dim3(256), 0, (hipStream_t)stream, sign, R, ldr, P, C,
+                     scale, out);
+  NUDF_CHECK_LAUNCH("nudf_signed_colsum");
+  return 0;
+}
+
+// backward of a sigmoid head: out[p,c] = (c < nsig) ? dy*y*(1-y) (+ extra) : draw   -> padded [P, ldo]
+__global__ void sigmoid_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                        const float* __restrict__ dy_extra, int ldx, int nsig,
+                                        const float* __restrict__ draw, int ldr, int nraw, int P,
+                                        float* __restrict__ out, int ldo) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = nsig + nraw;
+  if (idx >= (long long)P * C) return;
+  int p = (int)(idx / C), c = (int)(idx - (long long)p * C);
+  float v;
+  if (c < nsig) {
+    float s = y[(size_t)p * nsig + c];
+    float d = dy ? dy[(size_t)p * nsig + c] : 0.f;
+    if (dy_extra) d += dy_extra[(size_t)p * ldx + c];
+    v = d * s * (1.0f - s);
+  } else {
+    v = draw ? draw[(size_t)p * ldr + (c - nsig)] : 0.f;
+  }
+  out[(size_t)p * ldo + c] = v;
+}
+extern "C" int nudf_sigmoid_head_bwd(const float* y, const float* dy, const float* dy_extra, int ldx, int nsig,
+                                     const float* draw, int ldr, int nraw, int P, float* out, int ldo, void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(sigmoid_head_bwd_kernel, dim3(nblocks((long long)P * (nsig + nraw), 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, dy, dy_extra, ldx, nsig, draw, ldr, nraw, P, out, ldo);
+  NUDF_CHECK_LAUNCH("nudf_sigmoid_head_bwd");
+  return 0;
+}
+
+// out[p,c] = a[p,c] + b[p,c]  (adjoint joins, e.g. the hidden tap of the colour net)
+__global__ void add_cols_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                float* __restrict__ out, int ldo, int P, int C) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)P * C) return;
+  int p = (int)(idx / C), c = (int)(idx - (long long)p * C);
+  out[(size_t)p * ldo + c] = a[(size_t)p * lda + c] + b[(size_t)p * ldb + c];
+}
+extern "C" int nudf_add_cols(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int P, int C,
+                             void* stream) {
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(add_cols_kernel, dim3(nblocks((long long)P * C, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                     ldb, out, ldo, P, C);
+  NUDF_CHECK_LAUNCH("nudf_add_cols");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight_norm packing: W = g * v / ||v||_row  (torch.nn.utils.weight_norm, applied at
+// fields.py:175-176, 433-446), written zero-padded into the two layouts the GEMMs read:
+//   W  [out_pad, in_pad]  (backward-data GEMMs)   and   Wt [in_pad, out_pad]  (forward GEMMs),
+// with an optional input-column permutation (activation buffers use their own column order).
+// One wave per output row.  g == NULL: plain nn.Linear (NeRF, fields.py:577-594).
+// ---------------------------------------------------------------------------------------
+__global__ void wn_pack_kernel(const float* __restrict__ v, const float* __restrict__ g, int out, int in,
+                               const int* __restrict__ perm, float* __restrict__ W, int ldw, float* __restrict__ Wt,
+                               int ldwt, float* __restrict__ inv_norm) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= out) return;
+  const int l = threadIdx.x & 63;
+  float sc = 1.0f;
+  if (g) {
+    float ss = 0.f;
+    for (int i = l; i < in; i += 64) {
+      float t = v[(size_t)row * in + i];
+      ss += t * t;
+    }
+    ss = wave_sum(ss);
+    float inv = 1.0f / sqrtf(ss);
+    if (l == 0 && inv_norm) inv_norm[row] = inv;
+    sc = g[row] * inv;
+  }
+  for (int i = l; i < in; i += 64) {
+    int c = perm ? perm[i] : i;
+    float w = v[(size_t)row * in + i] * sc;
+    if (W) W[(size_t)row * ldw + c] = w;
+    if (Wt) Wt[(size_t)c * ldwt + row] = w;
+  }
+}
+extern "C" int nudf_weightnorm_pack(const float* v, const float* g, int out, int in, const int* perm, float* W, int ldw,
+                                    float* Wt, int ldwt, float* inv_norm, void* stream) {
+  hipLaunchKernelGGL(wn_pack_kernel, dim3((out + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, g, out, in, perm, W, ldw,
+                     Wt, ldwt, inv_norm);
+  NUDF_CHECK_LAUNCH("nudf_weightnorm_pack");
+  return 0;
+}
+
+// backward of the packing: dW [out, ldw] (packed column order) -> dv [out,in], dg [out]
+//   dg = <dW, v> * inv ;  dv = g*inv * (dW - v*inv * dg*inv ... ) = g*inv*dW - v * (g*inv^3 * <dW,v>)
+__global__ void wn_unpack_grad_kernel(const float* __restrict__ dW, int ldw, const float* __restrict__ v,
+                                      const float* __restrict__ g, const float* __restrict__ inv_norm, int out, int in,
+                                      const int* __restrict__ perm, float* __restrict__ dv, float* __restrict__ dg) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= out) return;
+  const int l = threadIdx.x & 63;
+  if (!g) {
+    for (int i = l; i < in; i += 64) dv[(size_t)row * in + i] = dW[(size_t)row * ldw + (perm ? perm[i] : i)];
+    return;
+  }
+  float dot = 0.f;
+  for (int i = l; i < in; i += 64) dot += dW[(size_t)row * ldw + (perm ? perm[i] : i)] * v[(size_t)row * in + i];
+  dot = wave_sum(dot);
+  const float inv = inv_norm[row];
+  const float gg = g[row];
+  if (l == 0) dg[row] = dot * inv;
+  const float c1 = gg * inv, c2 = gg * inv * inv * inv * dot;
+  for (int i = l; i < in; i += 64)
+    dv[(size_t)row * in + i] = c1 * dW[(size_t)row * ldw + (perm ? perm[i] : i)] - c2 * v[(size_t)row * in + i];
+}
+extern "C" int nudf_weightnorm_unpack_grad(const float* dW, int ldw, const float* v, const float* g,
+                                           const float* inv_norm, int out, int in, const int* perm, float* dv, float* dg,
+                                           void* stream) {
+  hipLaunchKernelGGL(wn_unpack_grad_kernel, dim3((out + 3) / 4), dim3(256), 0, (hipStream_t)stream, dW, ldw, v, g,
+                     inv_norm, out, in, perm, dv, dg);
+  NUDF_CHECK_LAUNCH("nudf_weightnorm_unpack_grad");
+  return 0;
+}

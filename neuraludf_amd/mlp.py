@@ -1,0 +1,493 @@
+"""Host-side sequencing of the MLP GEMM chains on libnudf (no torch arithmetic on activations).
+
+Three engines, each a pair of (forward, hand-derived backward) over `nudf_gemm_nn/_tn`:
+  * UDFEngine    -- UDFNetwork.forward + .gradient (models/fields.py:192-231) and their
+                    backward, including the second-order part (the reference differentiates
+                    through autograd.grad(create_graph=True));
+  * ColorEngine  -- ResidualRenderingNetwork.forward (fields.py:452-495);
+  * NerfEngine   -- NeRF.forward with view directions (fields.py:599-628).
+torch is used for buffer allocation (caching allocator), streams and autograd plumbing.
+
+Activation buffers are [P, ld] with ld = roundup(width, 32); pad columns are zero.  Weights are
+re-normalised (weight_norm) and packed by `nudf_weightnorm_pack` into W [out_pad, in_pad] and
+W^T [in_pad, out_pad]; packing is cached on the parameters' version counters.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import EPI, GemmNN, GemmTN, call, ptr
+
+
+def pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def _buf(P, width, dev, zero=None):
+    """[P, pad32(width)] fp32; zero-filled when there are pad columns (or when asked)."""
+    ld = pad32(width)
+    if zero is None:
+        zero = ld != width
+    return (torch.zeros if zero else torch.empty)((P, ld), device=dev, dtype=torch.float32)
+
+
+def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=0, X1=None, ldx1=0, X2=None, ldx2=0,
+            bias=None, lda=None, ldb=None, iparam=0, scale=1.0, c1_off=0, c2_off=0, x1_off=0, x2_off=0):
+    """thin wrapper filling NudfGemmNN; *_off are column offsets (in floats) into the buffers."""
+    a = GemmNN()
+    a.A, a.lda = ptr(A), (lda if lda is not None else A.shape[1])
+    a.B, a.ldb = ptr(B), (ldb if ldb is not None else B.shape[1])
+    a.bias = ptr(bias)
+    a.C1 = (ptr(C1) + 4 * c1_off) if C1 is not None else None
+    a.ldc1 = ldc1 or (C1.shape[1] if (C1 is not None and C1.dim() == 2) else 0)
+    a.C2 = (ptr(C2) + 4 * c2_off) if C2 is not None else None
+    a.ldc2 = ldc2 or (C2.shape[1] if (C2 is not None and C2.dim() == 2) else 0)
+    a.C3 = ptr(C3)
+    a.ldc3 = ldc3 or (C3.shape[1] if (C3 is not None and C3.dim() == 2) else 0)
+    a.X1 = (ptr(X1) + 4 * x1_off) if X1 is not None else None
+    a.ldx1 = ldx1 or (X1.shape[1] if (X1 is not None and X1.dim() == 2) else 0)
+    a.X2 = (ptr(X2) + 4 * x2_off) if X2 is not None else None
+    a.ldx2 = ldx2 or (X2.shape[1] if (X2 is not None and X2.dim() == 2) else 0)
+    a.M, a.N, a.K, a.epi, a.iparam, a.scale = M, N, K, EPI[epi], iparam, scale
+    call("nudf_gemm_nn", a)
+
+
+def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
+    a = GemmTN()
+    a.A1, a.lda1, a.na1 = ptr(A1), A1.shape[1], na1
+    a.B1, a.ldb1 = ptr(B1), B1.shape[1]
+    if A2 is not None:
+        a.A2, a.lda2, a.na2 = ptr(A2), A2.shape[1], na2
+        a.B2, a.ldb2 = ptr(B2), B2.shape[1]
+    a.C, a.ldc = ptr(C), C.shape[1]
+    a.dbias = ptr(dbias)
+    a.M, a.NA, a.NB, a.rows_per_block = M, NA, NB, 0
+    call("nudf_gemm_tn", a)
+
+
+class PackedLinear:
+    """one (weight-normed or plain) nn.Linear packed for the GEMM kernels."""
+
+    def __init__(self, lin: torch.nn.Module, perm: Optional[List[int]] = None):
+        self.lin = lin
+        self.weight_norm = hasattr(lin, "weight_v")
+        v = lin.weight_v if self.weight_norm else lin.weight
+        self.out, self.inp = v.shape
+        self.out_pad, self.in_pad = pad32(self.out), pad32(self.inp)
+        self._perm_list = perm
+        self.perm = None
+        self.W = self.Wt = self.inv_norm = None
+        self._ver = None
+
+    def params(self):
+        if self.weight_norm:
+            return [self.lin.weight_v, self.lin.weight_g, self.lin.bias]
+        return [self.lin.weight, self.lin.bias]
+
+    def pack(self):
+        """(re)pack if the parameters changed; returns self."""
+        ps = self.params()
+        v = ps[0]
+        ver = tuple((p.data_ptr(), p._version) for p in ps[:-1])
+        if ver == self._ver and self.W is not None and self.W.device == v.device:
+            return self
+        dev = v.device
+        if self.W is None or self.W.device != dev:
+            self.W = torch.zeros(self.out_pad, self.in_pad, device=dev)
+            self.Wt = torch.zeros(self.in_pad, self.out_pad, device=dev)
+            self.inv_norm = torch.empty(self.out, device=dev)
+            if self._perm_list is not None:
+                self.perm = torch.tensor(self._perm_list, dtype=torch.int32, device=dev)
+        g = ps[1] if self.weight_norm else None
+        call("nudf_weightnorm_pack", ptr(v.detach().contiguous()), ptr(g.detach().contiguous()) if g is not None else None,
+             self.out, self.inp, ptr(self.perm), ptr(self.W), self.in_pad, ptr(self.Wt), self.out_pad,
+             ptr(self.inv_norm))
+        self._ver = ver
+        return self
+
+    @property
+    def bias(self):
+        return self.lin.bias.detach()
+
+    def new_grad_buffers(self):
+        dev = self.W.device
+        return torch.zeros(self.out_pad, self.in_pad, device=dev), torch.zeros(self.out, device=dev)
+
+    def unpack_grads(self, dW, db):
+        """packed dW/db -> gradients in params() order."""
+        ps = self.params()
+        v = ps[0].detach().contiguous()
+        dv = torch.empty_like(v)
+        if self.weight_norm:
+            g = ps[1].detach().contiguous()
+            dg = torch.empty_like(g)
+            call("nudf_weightnorm_unpack_grad", ptr(dW), self.in_pad, ptr(v), ptr(g), ptr(self.inv_norm), self.out,
+                 self.inp, ptr(self.perm), ptr(dv), ptr(dg))
+            return [dv, dg, db]
+        call("nudf_weightnorm_unpack_grad", ptr(dW), self.in_pad, ptr(v), None, None, self.out, self.inp,
+             ptr(self.perm), ptr(dv), None)
+        return [dv, db]
+
+
+# =========================================================================================
+# UDF network
+# =========================================================================================
+class UDFEngine:
+    def __init__(self, net):
+        self.net = net
+        self.L = net.num_layers - 2                     # index of the last linear layer
+        self.E = net.embed_dim
+        self.layers = [PackedLinear(getattr(net, f"lin{l}")) for l in range(self.L + 1)]
+        self.skip = set(net.skip_in)
+        self.inv_sqrt2 = 1.0 / math.sqrt(2.0)
+
+    def params(self):
+        out = []
+        for pl in self.layers:
+            out += pl.params()
+        return out
+
+    def _embed(self, x, P, X, tangent=None):
+        net = self.net
+        # layer-0 input, plus the tail of every skip layer's input (cat([x, inputs])/sqrt(2), fields.py:202-203)
+        skip_dst = [X[s] for s in sorted(self.skip)]
+        d2 = skip_dst[0] if skip_dst else None
+        off2 = (self.layers[sorted(self.skip)[0]].inp - self.E) if skip_dst else 0
+        call("nudf_posenc", ptr(x), 3, 1, ptr(tangent), net.d_in, net.multires, float(net.scale), P,
+             ptr(X[0]), X[0].shape[1], 1.0,
+             (ptr(d2) + 4 * off2) if d2 is not None else None, d2.shape[1] if d2 is not None else 0, self.inv_sqrt2)
+        for s, dst in zip(sorted(self.skip)[1:], skip_dst[1:]):
+            off = self.layers[s].inp - self.E
+            call("nudf_posenc", ptr(x), 3, 1, ptr(tangent), net.d_in, net.multires, float(net.scale), P,
+                 ptr(dst) + 4 * off, dst.shape[1], self.inv_sqrt2, None, 0, 0.0)
+
+    def forward(self, x, need_grad_state, feat_dst=None, feat_ld=0, want_feat=True, udf_only=False):
+        """x [P,3] -> dict(udf [P], sign [P], feat (dst or new [P,F]), state...)."""
+        P = x.shape[0]
+        dev = x.device
+        L = self.L
+        for pl in self.layers:
+            pl.pack()
+        X = [_buf(P, pl.inp, dev) for pl in self.layers]
+        SIG = [_buf(P, self.layers[l].out, dev) for l in range(L)] if need_grad_state else [None] * L
+        self._embed(x, P, X)
+        for l in range(L):
+            pl = self.layers[l]
+            sc = self.inv_sqrt2 if (l + 1) in self.skip else 1.0
+            gemm_nn(X[l], pl.Wt, P, pl.out, pl.in_pad, "SOFTPLUS", C1=X[l + 1], C2=SIG[l], bias=pl.bias, scale=sc)
+        pl = self.layers[L]
+        udf = torch.empty(P, device=dev)
+        sign = torch.empty(P, device=dev) if need_grad_state else None
+        F = pl.out - 1
+        feat = None
+        n_out = 1 if udf_only else pl.out
+        if not udf_only and want_feat:
+            if feat_dst is None:
+                feat = torch.empty(P, F, device=dev)
+                feat_dst, feat_ld = feat, F
+            else:
+                feat = feat_dst
+        gemm_nn(X[L], pl.Wt, P, n_out, pl.in_pad, "UDFHEAD", C1=feat_dst if not udf_only and want_feat else None,
+                ldc1=feat_ld, C2=udf, ldc2=1, C3=sign, bias=pl.bias, scale=1.0 / float(self.net.scale))
+        return dict(udf=udf, sign=sign, feat=feat, X=X, SIG=SIG, P=P)
+
+    def gradient(self, x, st):
+        """reverse sweep for d udf / d x given forward state -> (g [P,3], DA list)."""
+        P, L, dev = st["P"], self.L, x.device
+        SIG = st["SIG"]
+        DA = [_buf(P, self.layers[l].out, dev) for l in range(L)]
+        plL = self.layers[L]
+        call("nudf_udf_grad_seed", ptr(st["sign"]), ptr(plL.W), ptr(SIG[L - 1]), SIG[L - 1].shape[1], P,
+             self.layers[L - 1].out, 1.0 / float(self.net.scale), ptr(DA[L - 1]), DA[L - 1].shape[1])
+        Epad = pad32(self.E)
+        demb_skip = None
+        for l in range(L - 1, 0, -1):
+            pl = self.layers[l]
+            if l in self.skip:
+                if demb_skip is not None:
+                    raise NotImplementedError("more than one skip layer")
+                demb_skip = torch.zeros(P, Epad, device=dev)
+                gemm_nn(DA[l], pl.W, P, pl.inp, pl.out_pad, "SKIPSPLIT", C1=DA[l - 1], C2=demb_skip, X1=SIG[l - 1],
+                        iparam=self.layers[l - 1].out, scale=self.inv_sqrt2)
+            else:
+                gemm_nn(DA[l], pl.W, P, pl.inp, pl.out_pad, "MUL", C1=DA[l - 1], X1=SIG[l - 1])
+        demb0 = torch.zeros(P, Epad, device=dev)
+        pl0 = self.layers[0]
+        gemm_nn(DA[0], pl0.W, P, pl0.inp, pl0.out_pad, "NONE", C1=demb0)
+        g = torch.empty(P, 3, device=dev)
+        call("nudf_posenc_vjp", ptr(x), 3, self.net.d_in, self.net.multires, float(self.net.scale), P,
+             ptr(demb0), Epad, 1.0, ptr(demb_skip), Epad, 1.0, ptr(g))
+        return g, DA
+
+    def backward(self, x, st, DA, d_udf, d_feat, d_feat_ld, d_g):
+        """-> list of parameter gradients in params() order.
+        d_udf [P] / d_feat [P, F] (row stride d_feat_ld) / d_g [P,3]; any may be None."""
+        P, L, dev = st["P"], self.L, x.device
+        X, SIG, sign = st["X"], st["SIG"], st["sign"]
+        layers = self.layers
+        grads = [pl.new_grad_buffers() for pl in layers]
+        second = d_g is not None and DA is not None
+        R = EX = None
+        if second:
+            # tangent sweep with direction d_g (forward-over-reverse; see DESIGN.md "second order")
+            R = [_buf(P, pl.inp, dev) for pl in layers]
+            EX = [_buf(P, layers[l].out, dev) for l in range(L)]
+            self._embed(x, P, R, tangent=d_g.contiguous())
+            for l in range(L):
+                pl = layers[l]
+                sc = self.inv_sqrt2 if (l + 1) in self.skip else 1.0
+                gemm_nn(R[l], pl.Wt, P, pl.out, pl.in_pad, "TANGENT", C1=R[l + 1], C2=EX[l], X1=SIG[l], X2=DA[l],
+                        scale=sc)
+            # d W_L[0,:] += sum_p sign_p * R_L[p,:] / scale
+            call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp,
+                 1.0 / float(self.net.scale), ptr(grads[L][0]))
+        # adjoint of the output layer
+        plL = layers[L]
+        ABAR = [None] * (L + 1)
+        ABAR[L] = _buf(P, plL.out, dev)
+        call("nudf_udf_head_bwd", ptr(sign), ptr(d_udf), ptr(d_feat), d_feat_ld, P, plL.out - 1,
+             1.0 / float(self.net.scale), ptr(ABAR[L]), ABAR[L].shape[1])
+        for l in range(L, 0, -1):
+            pl = layers[l]
+            ABAR[l - 1] = _buf(P, layers[l - 1].out, dev)
+            sc = self.inv_sqrt2 if l in self.skip else 1.0
+            if second:
+                gemm_nn(ABAR[l], pl.W, P, layers[l - 1].out, pl.out_pad, "BWD", C1=ABAR[l - 1], X1=SIG[l - 1],
+                        X2=EX[l - 1], scale=sc)
+            else:
+                gemm_nn(ABAR[l], pl.W, P, layers[l - 1].out, pl.out_pad, "MUL", C1=ABAR[l - 1], X1=SIG[l - 1], scale=sc)
+        out = []
+        for l, pl in enumerate(layers):
+            dW, db = grads[l]
+            if second and l < L:
+                gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db, A2=DA[l], na2=pl.out, B2=R[l])
+            else:
+                gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db)
+            out += pl.unpack_grads(dW, db)
+        return out
+
+
+# =========================================================================================
+# ReLU chains (colour network, NeRF)
+# =========================================================================================
+def relu_chain_bwd(layers, inputs, outs, D_last, P, first_needs_input_grad, add_at=None):
+    """Backward through `layers[i]: inputs[i] -> relu -> outs[i]` (the last layer's pre-activation
+    gradient is D_last [P, out_pad]).  Returns (grads per layer, d_input of layer 0 or None).
+    add_at = {layer_index: tensor} adds an extra adjoint to that layer's *output* before the mask."""
+    n = len(layers)
+    grads = [pl.new_grad_buffers() for pl in layers]
+    D = D_last
+    d_in0 = None
+    for i in range(n - 1, -1, -1):
+        pl = layers[i]
+        gemm_tn(D, pl.out, inputs[i], grads[i][0], pl.out, pl.in_pad, P, dbias=grads[i][1])
+        if i > 0:
+            prev = layers[i - 1]
+            Dn = _buf(P, prev.out, D.device)
+            extra = add_at.get(i - 1) if add_at else None
+            if extra is not None:
+                gemm_nn(D, pl.W, P, prev.out, pl.out_pad, "ADDMASK", C1=Dn, X1=outs[i - 1], ldx1=outs[i - 1].shape[1],
+                        X2=extra[0], ldx2=extra[1], x2_off=extra[2])
+            else:
+                gemm_nn(D, pl.W, P, prev.out, pl.out_pad, "MULMASK", C1=Dn, X1=outs[i - 1], ldx1=outs[i - 1].shape[1])
+            D = Dn
+        elif first_needs_input_grad:
+            d_in0 = _buf(P, pl.inp, D.device)
+            gemm_nn(D, pl.W, P, pl.inp, pl.out_pad, "NONE", C1=d_in0)
+    return grads, d_in0
+
+
+class ColorEngine:
+    """ResidualRenderingNetwork, mode 'no_normal' (the only mode the shipped confs use)."""
+
+    def __init__(self, net):
+        self.net = net
+        if net.mode != "no_normal":
+            raise NotImplementedError("ResidualRenderingNetwork mode %r (confs use 'no_normal')" % net.mode)
+        n = net.num_layers - 1
+        self.n = n
+        F, H, dout = net.d_feature, net.d_hidden, net.d_out
+        self.F, self.H, self.dout = F, H, dout
+        self.npe = net.view_dim                        # width of PE(view_dirs)
+        # base input buffer [feat F | pts 3]; reference order is [pts 3, feat F]
+        perm_b0 = [F + i for i in range(3)] + list(range(F))
+        # view input buffer [hidden H | PE(dir) | color_base dout]; reference order [PE(dir), color_base, hidden]
+        perm_v0 = [H + i for i in range(self.npe)] + [H + self.npe + j for j in range(dout)] + list(range(H))
+        self.base = [PackedLinear(getattr(net, f"lin_base{l}"), perm_b0 if l == 0 else None) for l in range(n)]
+        self.view = [PackedLinear(getattr(net, f"lin{l}"), perm_v0 if l == 0 else None) for l in range(n)]
+
+    def params(self):
+        out = []
+        for pl in self.view + self.base:               # registration order: lin*, then lin_base*
+            out += pl.params()
+        return out
+
+    def alloc_base_input(self, P, dev):
+        return torch.zeros(P, pad32(self.F + 3), device=dev)
+
+    def forward(self, CIN, pts, rays_d, S, P, keep_state=True):
+        """CIN [P, pad(F+3)] already holds the feature in cols 0..F-1 (written by the UDF head)."""
+        dev = CIN.device
+        n = self.n
+        for pl in self.base + self.view:
+            pl.pack()
+        call("nudf_copy_cols", ptr(pts), 3, 1, ptr(CIN) + 4 * self.F, CIN.shape[1], 3, P, 1.0)
+        VIN = torch.zeros(P, pad32(self.H + self.npe + self.dout), device=dev)
+        # PE(view_dirs) (fields.py:453-454); directions are per ray -> xdiv = S
+        call("nudf_posenc", ptr(rays_d), 3, S, None, 3, self.net.multires_view, 1.0, P,
+             ptr(VIN) + 4 * self.H, VIN.shape[1], 1.0, None, 0, 0.0)
+        HB = [CIN]
+        for l in range(n - 1):
+            pl = self.base[l]
+            h = _buf(P, pl.out, dev)
+            if l == n - 2:   # hidden tap (post-ReLU) also feeds the view branch
+                gemm_nn(HB[l], pl.Wt, P, pl.out, pl.in_pad, "RELU_DUAL", C1=h, C2=VIN, bias=pl.bias)
+            else:
+                gemm_nn(HB[l], pl.Wt, P, pl.out, pl.in_pad, "RELU", C1=h, bias=pl.bias)
+            HB.append(h)
+        color_base = torch.empty(P, self.dout, device=dev)
+        pl = self.base[n - 1]
+        gemm_nn(HB[n - 1], pl.Wt, P, pl.out, pl.in_pad, "SIGMOID", C1=color_base, C2=VIN, c2_off=self.H + self.npe,
+                bias=pl.bias, iparam=self.dout)
+        HV = [VIN]
+        for l in range(n - 1):
+            pl = self.view[l]
+            h = _buf(P, pl.out, dev)
+            gemm_nn(HV[l], pl.Wt, P, pl.out, pl.in_pad, "RELU", C1=h, bias=pl.bias)
+            HV.append(h)
+        pl = self.view[n - 1]
+        color = torch.empty(P, self.dout, device=dev)
+        nb = pl.out - self.dout
+        logits = torch.empty(P, max(nb, 1), device=dev)
+        gemm_nn(HV[n - 1], pl.Wt, P, pl.out, pl.in_pad, "SIGMOID", C1=color, C3=logits, bias=pl.bias,
+                iparam=self.dout)
+        st = dict(HB=HB, HV=HV, P=P) if keep_state else None
+        return color_base, color, (logits if nb > 0 else None), st
+
+    def backward(self, st, color_base, color, d_cb, d_color, d_logits):
+        """-> (param grads in params() order, d_feat buffer [P, pad(F+3)] whose cols 0..F-1 are d feature)."""
+        P, n = st["P"], self.n
+        HB, HV = st["HB"], st["HV"]
+        dev = color.device
+        plv = self.view[n - 1]
+        nb = plv.out - self.dout
+        D = _buf(P, plv.out, dev, zero=True)
+        call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, self.dout, ptr(d_logits), max(nb, 1), nb, P,
+             ptr(D), D.shape[1])
+        gv, dVIN = relu_chain_bwd(self.view, HV, HV[1:], D, P, True)
+        # base head: d color_base = direct + through the view branch's input columns
+        Db = _buf(P, self.dout, dev, zero=True)
+        call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (self.H + self.npe), dVIN.shape[1],
+             self.dout, None, 0, 0, P, ptr(Db), Db.shape[1])
+        gb, dCIN = relu_chain_bwd(self.base, HB, HB[1:], Db, P, True, add_at={n - 2: (dVIN, dVIN.shape[1], 0)})
+        out = []
+        for pl, (dW, db) in zip(self.view + self.base, gv + gb):
+            out += pl.unpack_grads(dW, db)
+        return out, dCIN
+
+
+class NerfEngine:
+    """Background NeRF with view directions (fields.py:541-628)."""
+
+    def __init__(self, net):
+        self.net = net
+        if not net.use_viewdirs:
+            raise NotImplementedError("NeRF without view directions")
+        self.D, self.W = net.D, net.W
+        self.e = net.input_ch
+        self.ev = net.input_ch_view
+        self.skips = set(net.skips)
+        self.pts = []
+        for i in range(self.D):
+            lin = net.pts_linears[i]
+            perm = None
+            if (i - 1) in self.skips:   # input was cat([input_pts e, h W]); buffer is [h W | e]
+                perm = [self.W + j for j in range(self.e)] + list(range(self.W))
+            self.pts.append(PackedLinear(lin, perm))
+        self.alpha = PackedLinear(net.alpha_linear)
+        self.feature = PackedLinear(net.feature_linear)
+        self.views = PackedLinear(net.views_linears[0])
+        self.rgb = PackedLinear(net.rgb_linear)
+        if len(net.views_linears) != 1:
+            raise NotImplementedError("NeRF with more than one views layer")
+
+    def _all(self):
+        # registration order of nn.Module: pts_linears, views_linears, feature_linear, alpha_linear, rgb_linear
+        return self.pts + [self.views, self.feature, self.alpha, self.rgb]
+
+    def params(self):
+        out = []
+        for pl in self._all():
+            out += pl.params()
+        return out
+
+    def forward(self, pts4, rays_d, S, P, keep_state=True):
+        dev = pts4.device
+        for pl in self._all():
+            pl.pack()
+        Hin = [_buf(P, pl.inp, dev) for pl in self.pts]
+        skip_layers = [i + 1 for i in sorted(self.skips) if i + 1 < self.D]
+        d2 = Hin[skip_layers[0]] if skip_layers else None
+        call("nudf_posenc", ptr(pts4), self.net.d_in, 1, None, self.net.d_in, self.net.multires, 1.0, P,
+             ptr(Hin[0]), Hin[0].shape[1], 1.0,
+             (ptr(d2) + 4 * self.W) if d2 is not None else None, d2.shape[1] if d2 is not None else 0, 1.0)
+        if len(skip_layers) > 1:
+            raise NotImplementedError("more than one NeRF skip")
+        outs = []
+        for i in range(self.D):
+            pl = self.pts[i]
+            dst = Hin[i + 1] if i + 1 < self.D else _buf(P, pl.out, dev)
+            gemm_nn(Hin[i], pl.Wt, P, pl.out, pl.in_pad, "RELU", C1=dst, bias=pl.bias)
+            outs.append(dst)
+        h = outs[-1]
+        if (self.D - 1) in self.skips:
+            raise NotImplementedError("skip after the last NeRF layer")
+        sigma = torch.empty(P, 1, device=dev)
+        gemm_nn(h, self.alpha.Wt, P, 1, self.alpha.in_pad, "NONE", C1=sigma, bias=self.alpha.bias)
+        VIN = torch.zeros(P, pad32(self.W + self.ev), device=dev)
+        gemm_nn(h, self.feature.Wt, P, self.feature.out, self.feature.in_pad, "NONE", C1=VIN, bias=self.feature.bias)
+        call("nudf_posenc", ptr(rays_d), 3, S, None, self.net.d_in_view, self.net.multires_view, 1.0, P,
+             ptr(VIN) + 4 * self.W, VIN.shape[1], 1.0, None, 0, 0.0)
+        hv = _buf(P, self.views.out, dev)
+        gemm_nn(VIN, self.views.Wt, P, self.views.out, self.views.in_pad, "RELU", C1=hv, bias=self.views.bias)
+        rgb = torch.empty(P, 3, device=dev)
+        gemm_nn(hv, self.rgb.Wt, P, 3, self.rgb.in_pad, "NONE", C1=rgb, bias=self.rgb.bias)
+        st = dict(Hin=Hin, outs=outs, VIN=VIN, hv=hv, P=P) if keep_state else None
+        return sigma, rgb, st
+
+    def backward(self, st, d_sigma, d_rgb):
+        P = st["P"]
+        Hin, outs, VIN, hv = st["Hin"], st["outs"], st["VIN"], st["hv"]
+        dev = VIN.device
+        # rgb head
+        Drgb = torch.zeros(P, 32, device=dev)
+        call("nudf_copy_cols", ptr(d_rgb), 3, 1, ptr(Drgb), 32, 3, P, 1.0)
+        g_rgb = self.rgb.new_grad_buffers()
+        gemm_tn(Drgb, 3, hv, g_rgb[0], 3, self.rgb.in_pad, P, dbias=g_rgb[1])
+        Dv = _buf(P, self.views.out, dev)
+        gemm_nn(Drgb, self.rgb.W, P, self.views.out, self.rgb.out_pad, "MULMASK", C1=Dv, X1=hv)
+        g_views = self.views.new_grad_buffers()
+        gemm_tn(Dv, self.views.out, VIN, g_views[0], self.views.out, self.views.in_pad, P, dbias=g_views[1])
+        dVIN = _buf(P, self.views.inp, dev)
+        gemm_nn(Dv, self.views.W, P, self.views.inp, self.views.out_pad, "NONE", C1=dVIN)
+        # feature / alpha heads share h = outs[-1]
+        g_feat = self.feature.new_grad_buffers()
+        gemm_tn(dVIN, self.feature.out, outs[-1], g_feat[0], self.feature.out, self.feature.in_pad, P, dbias=g_feat[1])
+        Dsig = torch.zeros(P, 32, device=dev)
+        call("nudf_copy_cols", ptr(d_sigma), 1, 1, ptr(Dsig), 32, 1, P, 1.0)
+        g_alpha = self.alpha.new_grad_buffers()
+        gemm_tn(Dsig, 1, outs[-1], g_alpha[0], 1, self.alpha.in_pad, P, dbias=g_alpha[1])
+        T1 = _buf(P, self.W, dev)
+        gemm_nn(Dsig, self.alpha.W, P, self.W, self.alpha.out_pad, "NONE", C1=T1)
+        Dh = _buf(P, self.W, dev)
+        gemm_nn(dVIN, self.feature.W, P, self.W, self.feature.out_pad, "ADDMASK", C1=Dh, X1=outs[-1],
+                ldx1=outs[-1].shape[1], X2=T1)
+        gp, _ = relu_chain_bwd(self.pts, Hin, outs, Dh, P, False)
+        out = []
+        for pl, (dW, db) in zip(self._all(), gp + [g_views, g_feat, g_alpha, g_rgb]):
+            out += pl.unpack_grads(dW, db)
+        return out

@@ -1,0 +1,74 @@
+"""Shared helpers for the tests / golden generator / bench: shipped-conf kwargs, seeded
+'trained-like' weights, oracle glue."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# kwargs of the shipped DTU conf (confs/udf_dtu_blending.conf:56-118)
+CONF = dict(
+    udf=dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+             geometric_init=True, weight_norm=True, udf_type="abs"),
+    color=dict(d_feature=256, mode="no_normal", d_in=6, d_out=3, d_hidden=128, n_layers=4, weight_norm=True,
+               multires_view=4, squeeze_out=True, blending_cand_views=10),
+    var=dict(init_val=0.3),
+    beta=dict(init_var_beta=0.5, init_var_gamma=0.3, init_var_zeta=0.3, beta_min=0.00005,
+              requires_grad_beta=True, requires_grad_gamma=False, requires_grad_zeta=False),
+    nerf=dict(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4],
+              use_viewdirs=True),
+)
+
+
+def build_modules(fields_mod, seed=0):
+    """Instantiate the five networks in the runner's order (exp_runner_blending.py:125-129)."""
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        nerf = fields_mod.NeRF(**CONF["nerf"])
+        udf = fields_mod.UDFNetwork(**CONF["udf"])
+        var = fields_mod.SingleVarianceNetwork(**CONF["var"])
+        color = fields_mod.ResidualRenderingNetwork(**CONF["color"])
+        beta = fields_mod.BetaNetwork(**CONF["beta"])
+    return dict(nerf=nerf, udf=udf, var=var, color=color, beta=beta)
+
+
+@torch.no_grad()
+def perturb_(mods, seed=1, scale=0.02):
+    """Make the geometric-init weights 'trained-like': the init zeroes the positional-encoding
+    columns of lin0/lin4, which would hide channel-order bugs.  Deterministic."""
+    g = torch.Generator().manual_seed(seed)
+    for name in ["nerf", "udf", "color"]:
+        for p in mods[name].parameters():
+            p.add_(torch.randn(p.shape, generator=g) * scale * (p.abs().mean() + 0.05))
+    return mods
+
+
+def state_dicts(mods):
+    return {k: {n: t.detach().clone() for n, t in m.state_dict().items()} for k, m in mods.items()}
+
+
+def oracle_nets(sds, requires_grad=False):
+    from oracle import udf_oracle as O
+    def prep(sd):
+        out = {}
+        for k, v in sd.items():
+            t = v.detach().clone().float()
+            if requires_grad:
+                t.requires_grad_(True)
+            out[k] = t
+        return out
+    return O.Nets(udf=prep(sds["udf"]), color=prep(sds["color"]), var=prep(sds["var"]),
+                  beta=prep(sds["beta"]), nerf=prep(sds["nerf"]) if "nerf" in sds else None)
+
+
+def checksum(sd):
+    """order-stable float64 checksum of a state dict."""
+    s = 0.0
+    for i, (k, v) in enumerate(sorted(sd.items())):
+        s += float((v.double() * ((i % 7) + 1)).sum())
+    return s
