@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""Headline benchmark: ray-samples/s of one full train step of the NeuralUDF volume-rendering hot
+path (render + colour/eikonal loss + backward + Adam) on synthetic DTU-scan24-shaped rays.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 512 rays x 128 samples per GPU (64 coarse + 64 hierarchical in
+4 rounds, no outside samples), fp32.  With N GPUs the global batch is 512*N rays, ray-sharded, one
+packed loss all-reduce + one gradient all-reduce per step (weak scaling).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel of the step (the fp32 MFMA layer GEMM `gemm_nn_kernel`):
+                  algorithmic FLOPs of its launches / their summed duration, measured with HIP
+                  events on the launch stream during one extra instrumented step; peak = 157.3 TFLOP/s
+                  (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md).
+  roofline_composite -- the fused sample+composite kernels against the 8 TB/s HBM roof
+                  (48 B/sample + 68 B/ray forward, 84 B/sample + 68 B/ray backward).
+  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path) timed on this host's
+                  cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (rays per GPU, renderer conf, scene)
+    "dtu_scan24_512x128": (512, dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0),
+                           "dtu"),
+    "dtu_shipped_512x114+32": (512, dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5,
+                                         perturb=1.0), "dtu"),
+}
+
+
+def cpu_baseline(workload, seconds_budget=25.0):
+    """the oracle's full train step (fwd + loss + bwd + Adam) on the host cores, bounded sample."""
+    from neuraludf_amd import synth
+    from neuraludf_amd.train import DTU_MODEL_CONF  # noqa: F401
+    from oracle import udf_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    _, rconf, scene_kind = WORKLOADS[workload]
+    n_rays = 64
+    torch.set_num_threads(os.cpu_count() or 1)
+    # seeded reference-identical init through the drop-in modules (CPU construction only, no kernels)
+    from neuraludf_amd.models import fields
+    from common import build_modules, state_dicts
+    mods = build_modules(fields, seed=0)
+    sds = state_dicts(mods)
+    nets = O.Nets(**{k: {n: t.clone().requires_grad_(t.is_floating_point()) for n, t in sds[k].items()}
+                     for k in ("udf", "color", "var", "beta", "nerf")})
+    nets.beta["gamma"].requires_grad_(False)
+    nets.beta["zeta"].requires_grad_(False)
+    params = [t for d in (nets.udf, nets.color, nets.var, nets.beta, nets.nerf) for t in d.values() if t.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    cfg = O.RenderCfg(n_samples=rconf["n_samples"], n_importance=rconf["n_importance"], n_outside=rconf["n_outside"],
+                      up_sample_steps=rconf["up_sample_steps"])
+    scene = synth.make_scene(scene_kind)
+    rays = synth.make_rays(scene, 0, n_rays, seed=1234)
+    s_core = rconf["n_samples"] + rconf["n_importance"]
+
+    def step():
+        t_rand = torch.rand(n_rays, 1) - 0.5
+        out = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
+                       flip_saturation=1.0, t_rand=t_rand,
+                       t_rand_out=torch.rand(cfg.n_outside) if cfg.n_outside else None)
+        cl = O.color_loss(0.01, 1.0, 0.0, 0.0, 3, out["color_base"], out["color"], rays["true_rgb"], None, None,
+                          None, None, None)
+        loss = cl["loss"] + 0.1 * out["gradient_error"]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 5 and (time.time() - t_start) < seconds_budget:
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n_rays * s_core / med, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps "
+                                      f"(oracle/udf_oracle.py, fp32, median {med:.3f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="dtu_scan24_512x128", choices=list(WORKLOADS))
+    ap.add_argument("--rays-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fused-adam", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible: bench.py measures the HIP path only"}))
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from neuraludf_amd import mlp, synth
+    from neuraludf_amd import dist as nd
+    from neuraludf_amd.train import Trainer
+
+    rays_per_gpu, rconf, scene_kind = WORKLOADS[args.workload]
+    if args.rays_per_gpu:
+        rays_per_gpu = args.rays_per_gpu
+    fused = bool(args.fused_adam)
+    try:
+        import neuraludf_amd.optim  # noqa: F401
+    except Exception:
+        fused = False
+    tr = Trainer(dev, rconf, seed=0, data_parallel=(world > 1), fused_adam=fused)
+    tr.renderer.diagnostics = False
+    scene = synth.make_scene(scene_kind)
+    rays = synth.make_rays(scene, 0, rays_per_gpu * world, seed=1234)
+    batch = {k: nd.shard(v, rank, world).contiguous().to(dev) for k, v in rays.items()}
+    s_core = rconf["n_samples"] + rconf["n_importance"]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * rays_per_gpu * s_core / (dt / args.steps)
+
+    result = {
+        "metric": "ray-samples/sec (train step)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
+                   "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
+                   "step": "render + L1/eikonal loss + backward + Adam", "parallelism": f"ray-sharded dp{world}",
+                   "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # ---- one instrumented step: HIP events around every GEMM launch on the launch stream ----
+        mlp.PROFILE = []
+        tr.step(batch)
+        torch.cuda.synchronize()
+        prof, mlp.PROFILE = mlp.PROFILE, None
+        agg = {}
+        for name, flops, s, e in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += s.elapsed_time(e) * 1e-3
+        dom = max(agg, key=lambda k: agg[k][2])
+        n, fl, sec = agg[dom]
+        result["roofline"] = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": fl / sec / 1e12,
+                              "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                              "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
+                              "algorithmic_gflop_per_step": fl / 1e9}
+        result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
+                                 "tflops": v[1] / v[2] / 1e12} for k, v in agg.items()}
+        # ---- fused composite kernel alone (HBM roof) ----
+        try:
+            result["roofline_composite"] = composite_roofline(dev, rays_per_gpu, s_core)
+        except Exception as ex:  # pragma: no cover
+            result["roofline_composite"] = {"error": repr(ex)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.workload)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def composite_roofline(dev, N, S, reps=50):
+    """time nudf_composite_fwd / _bwd alone on resident inputs (L2/MALL-resident at this size; the
+    larger 8192x256 shape is reported next to it)."""
+    from neuraludf_amd.models.udf_renderer_blending import _CompositeFn
+    out = {}
+    for (n, s) in [(N, S), (8192, 256)]:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        z = torch.sort(torch.rand(n, s, generator=g) * 2 + 1.5, -1)[0].to(dev)
+        ro = torch.randn(n, 3, generator=g).to(dev)
+        rd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        udf = (torch.rand(n, s, generator=g) * 0.3).to(dev).requires_grad_(True)
+        grad = torch.randn(n, s, 3, generator=g).to(dev).requires_grad_(True)
+        col = torch.rand(n, s, 3, generator=g).to(dev).requires_grad_(True)
+        cb = torch.rand(n, s, 3, generator=g).to(dev).requires_grad_(True)
+        scal = torch.tensor([64.0, 128.0, 20.0], device=dev)
+        sd = torch.tensor([2.0 / 64], device=dev)
+        c = dict(s_nominal=s, cos_anneal=1.0, flip_saturation=1.0, use_norm_grad=False, sparse_scale=25000.0,
+                 diagnostics=False)
+        with torch.no_grad():
+            for _ in range(3):
+                _CompositeFn.apply(c, ro, rd, z, sd, None, udf, grad, col, cb, None, None, None, scal)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # isolate the kernel from the allocator: time the ctypes launches only
+            from neuraludf_amd._lib import Composite, call, ptr
+            from neuraludf_amd.models.udf_renderer_blending import _fill_composite
+            a = Composite()
+            a.rays_o, a.rays_d, a.z, a.udf, a.grad = ptr(ro), ptr(rd), ptr(z), ptr(udf.detach()), ptr(grad.detach())
+            a.color, a.color_base = ptr(col.detach()), ptr(cb.detach())
+            a.scal, a.sample_dist = ptr(scal), ptr(sd)
+            _fill_composite(a, c, n, s, 0)
+            bufs = [torch.empty(n, s, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev),
+                    torch.empty(n, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev),
+                    torch.empty(n, device=dev), torch.zeros(5, device=dev)]
+            (a.weights, a.out_color, a.out_color_base, a.out_depth, a.out_normals, a.out_wsum, a.out_wsum_all,
+             a.sums) = [ptr(b) for b in bufs]
+            e0.record()
+            for _ in range(reps):
+                call("nudf_composite_fwd", a)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / reps * 1e3
+        bytes_fwd = 48.0 * n * s + 68.0 * n
+        out[f"fwd_{n}x{s}"] = {"bound": "hbm", "achieved": bytes_fwd / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": bytes_fwd / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "avg_launch_us": us, "algorithmic_bytes": bytes_fwd}
+    return out
+
+
+if __name__ == "__main__":
+    main()

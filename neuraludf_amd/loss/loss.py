@@ -1,0 +1,113 @@
+"""Drop-in for the reference's loss/loss.py: `ColorLoss(**conf.color_loss)` with the same call surface
+and result dict (loss/loss.py:87-133).
+
+The per-ray reductions are tiny ([N,3] tensors); the SSIM patch error runs in the `nudf_ssim_patch`
+kernel.  With `data_parallel=True` the L1 numerators / mask counts are all-reduced over the process
+group so every rank forms the same global loss (see neuraludf_amd/dist.py)."""
+import torch
+import torch.nn as nn
+
+from .. import dist as nudf_dist
+from .patch_metric import ssim_patch_error
+
+
+class ColorPixelLoss(nn.Module):
+    """loss/loss.py:21-44 -- the mask only enters the denominator, never the error."""
+
+    def __init__(self, type='mse'):
+        super().__init__()
+        self.data_parallel = False
+
+    def forward(self, pred, gt, mask):
+        num = (pred - gt).abs().sum()
+        if mask is not None:
+            den = mask.sum().float()
+            if self.data_parallel:
+                packed = nudf_dist.all_reduce_sum(torch.stack([num, den]))
+                num, den = packed[0], packed[1]
+            return num / (den + 1e-4)
+        cnt = torch.tensor(float(pred.numel()), device=pred.device)
+        if self.data_parallel:
+            packed = nudf_dist.all_reduce_sum(torch.stack([num, cnt]))
+            num, cnt = packed[0], packed[1]
+        return num / cnt
+
+
+class ColorPatchLoss(nn.Module):
+    """loss/loss.py:47-84 ('ssim'): per-ray SSIM error, masked, top-30 % errors trimmed."""
+
+    def __init__(self, type='ssim', h_patch_size=3):
+        super().__init__()
+        if type != 'ssim':
+            raise NotImplementedError("patch_loss_type %r: the shipped confs use 'ssim'" % type)
+        self.type = type
+        self.h_patch_size = h_patch_size
+        self.data_parallel = False
+
+    def forward(self, pred, gt, mask, penalize_ratio=0.3):
+        error = ssim_patch_error(pred, gt, self.h_patch_size)            # [N]
+        m = mask.reshape(-1).bool()
+        error = error * m.float()
+        if self.data_parallel and nudf_dist.world_size() > 1:
+            # order statistics over the whole ray batch: gather errors + masks, trim identically everywhere
+            return _global_trimmed_mean(error, m, penalize_ratio)
+        err_s, idx = torch.sort(error, descending=True)
+        ms = m[idx].clone()
+        ms[:int(penalize_ratio * ms.sum())] = False
+        return err_s[ms].mean()
+
+
+def _global_trimmed_mean(error, m, ratio):
+    import torch.distributed as dist
+    w = nudf_dist.world_size()
+    errs = [torch.zeros_like(error) for _ in range(w)]
+    ms = [torch.zeros_like(m, dtype=torch.float32) for _ in range(w)]
+    dist.all_gather(errs, error.detach())
+    dist.all_gather(ms, m.float())
+    errs[nudf_dist.rank()] = error                                       # keep the local autograd edge
+    e = torch.cat(errs)
+    mm = torch.cat(ms).bool()
+    es, idx = torch.sort(e, descending=True)
+    mk = mm[idx].clone()
+    mk[:int(ratio * mk.sum())] = False
+    return es[mk].mean()
+
+
+class ColorLoss(nn.Module):
+    def __init__(self, color_base_weight, color_weight, color_pixel_weight, color_patch_weight,
+                 pixel_loss_type='l1', patch_loss_type='ssim', h_patch_size=3):
+        super().__init__()
+        self.color_base_weight = color_base_weight
+        self.color_weight = color_weight
+        self.color_pixel_weight = color_pixel_weight
+        self.color_patch_weight = color_patch_weight
+        self.pixel_func = ColorPixelLoss(pixel_loss_type)
+        self.patch_func = ColorPatchLoss(patch_loss_type, h_patch_size)
+        self.h_patch_size = h_patch_size
+
+    def set_data_parallel(self, flag=True):
+        self.pixel_func.data_parallel = flag
+        self.patch_func.data_parallel = flag
+
+    def set_color_weights(self, color_base_weight, color_weight, color_pixel_weight, color_patch_weight):
+        self.color_base_weight = color_base_weight
+        self.color_weight = color_weight
+        self.color_pixel_weight = color_pixel_weight
+        self.color_patch_weight = color_patch_weight
+
+    def forward(self, color_base, color, gt_color, color_pixel, pixel_mask, patch_colors, gt_patch_colors, patch_mask):
+        color_base_loss = color_loss = color_pixel_loss = color_patch_loss = 0.0
+        if color_base is not None:
+            color_base_loss = self.pixel_func(color_base, gt_color, pixel_mask)
+        if color is not None:
+            color_loss = self.pixel_func(color, gt_color, pixel_mask)
+        if color_pixel is not None:
+            color_pixel_loss = self.pixel_func(color_pixel, gt_color, patch_mask)
+        if patch_colors is not None:
+            color_patch_loss = self.patch_func(patch_colors, gt_patch_colors, patch_mask)
+        total_loss = (color_base_loss * self.color_base_weight + color_loss * self.color_weight
+                      + color_pixel_loss * self.color_pixel_weight) / (
+                self.color_base_weight + self.color_weight + self.color_pixel_weight) \
+            + color_patch_loss * self.color_patch_weight
+        return {'loss': total_loss, 'color_base_loss': color_base_loss, 'color_loss': color_loss,
+                'color_pixel_loss': color_pixel_loss, 'color_patch_loss': color_patch_loss}

@@ -53,7 +53,24 @@ def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=
     a.X2 = (ptr(X2) + 4 * x2_off) if X2 is not None else None
     a.ldx2 = ldx2 or (X2.shape[1] if (X2 is not None and X2.dim() == 2) else 0)
     a.M, a.N, a.K, a.epi, a.iparam, a.scale = M, N, K, EPI[epi], iparam, scale
+    if PROFILE is not None:
+        _timed("gemm_nn", 2.0 * M * N * getattr(B, "k_true", K), lambda: call("nudf_gemm_nn", a))
+        return
     call("nudf_gemm_nn", a)
+
+
+# bench.py sets PROFILE = [] for one instrumented step: every GEMM launch is bracketed by HIP events on
+# the launch stream and recorded as (kernel, algorithmic flops, start, end)
+PROFILE = None
+
+
+def _timed(name, flops, fn):
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    PROFILE.append((name, flops, s, e))
 
 
 def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
@@ -66,6 +83,9 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
     a.C, a.ldc = ptr(C), C.shape[1]
     a.dbias = ptr(dbias)
     a.M, a.NA, a.NB, a.rows_per_block = M, NA, NB, 0
+    if PROFILE is not None:
+        _timed("gemm_tn", 2.0 * M * NA * NB * (2 if A2 is not None else 1), lambda: call("nudf_gemm_tn", a))
+        return
     call("nudf_gemm_tn", a)
 
 
@@ -100,6 +120,7 @@ class PackedLinear:
             self.W = torch.zeros(self.out_pad, self.in_pad, device=dev)
             self.Wt = torch.zeros(self.in_pad, self.out_pad, device=dev)
             self.inv_norm = torch.empty(self.out, device=dev)
+            self.Wt.k_true, self.W.k_true = self.inp, self.out      # unpadded reduction lengths (flop accounting)
             if self._perm_list is not None:
                 self.perm = torch.tensor(self._perm_list, dtype=torch.int32, device=dev)
         g = ps[1] if self.weight_norm else None
@@ -165,8 +186,9 @@ class UDFEngine:
             call("nudf_posenc", ptr(x), 3, 1, ptr(tangent), net.d_in, net.multires, float(net.scale), P,
                  ptr(dst) + 4 * off, dst.shape[1], self.inv_sqrt2, None, 0, 0.0)
 
-    def forward(self, x, need_grad_state, feat_dst=None, feat_ld=0, want_feat=True, udf_only=False):
-        """x [P,3] -> dict(udf [P], sign [P], feat (dst or new [P,F]), state...)."""
+    def forward(self, x, need_grad_state, feat_ld=0, udf_only=False):
+        """x [P,3] -> dict(udf [P], sign [P], feat [P, max(feat_ld, F)], state...).
+        feat_ld > F additionally writes x into cols F..F+2 (the colour net's base-input layout)."""
         P = x.shape[0]
         dev = x.device
         L = self.L
@@ -184,15 +206,13 @@ class UDFEngine:
         sign = torch.empty(P, device=dev) if need_grad_state else None
         F = pl.out - 1
         feat = None
-        n_out = 1 if udf_only else pl.out
-        if not udf_only and want_feat:
-            if feat_dst is None:
-                feat = torch.empty(P, F, device=dev)
-                feat_dst, feat_ld = feat, F
-            else:
-                feat = feat_dst
-        gemm_nn(X[L], pl.Wt, P, n_out, pl.in_pad, "UDFHEAD", C1=feat_dst if not udf_only and want_feat else None,
-                ldc1=feat_ld, C2=udf, ldc2=1, C3=sign, bias=pl.bias, scale=1.0 / float(self.net.scale))
+        if not udf_only:
+            ld = max(feat_ld, F)
+            feat = (torch.zeros if ld > F else torch.empty)((P, ld), device=dev)
+            if ld >= F + 3:
+                call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
+        gemm_nn(X[L], pl.Wt, P, 1 if udf_only else pl.out, pl.in_pad, "UDFHEAD", C1=feat, C2=udf, ldc2=1, C3=sign,
+                ldc3=1, bias=pl.bias, scale=1.0 / float(self.net.scale))
         return dict(udf=udf, sign=sign, feat=feat, X=X, SIG=SIG, P=P)
 
     def gradient(self, x, st):
@@ -326,16 +346,16 @@ class ColorEngine:
             out += pl.params()
         return out
 
-    def alloc_base_input(self, P, dev):
-        return torch.zeros(P, pad32(self.F + 3), device=dev)
+    @property
+    def cin_ld(self):
+        return pad32(self.F + 3)
 
-    def forward(self, CIN, pts, rays_d, S, P, keep_state=True):
-        """CIN [P, pad(F+3)] already holds the feature in cols 0..F-1 (written by the UDF head)."""
+    def forward(self, CIN, rays_d, S, P, keep_state=True):
+        """CIN [P, pad(F+3)] = [feature F | pts 3 | 0] (written by the UDF head + nudf_copy_cols)."""
         dev = CIN.device
         n = self.n
         for pl in self.base + self.view:
             pl.pack()
-        call("nudf_copy_cols", ptr(pts), 3, 1, ptr(CIN) + 4 * self.F, CIN.shape[1], 3, P, 1.0)
         VIN = torch.zeros(P, pad32(self.H + self.npe + self.dout), device=dev)
         # PE(view_dirs) (fields.py:453-454); directions are per ray -> xdiv = S
         call("nudf_posenc", ptr(rays_d), 3, S, None, 3, self.net.multires_view, 1.0, P,

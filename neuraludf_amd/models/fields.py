@@ -1,0 +1,339 @@
+"""Drop-in field networks for the reference's `models.fields` (same class names, constructor
+signatures, parameter names/shapes/registration order and initialisation, so checkpoints and
+Adam state interchange), evaluated by hand-written HIP kernels through libnudf.
+
+  UDFNetwork                 models/fields.py:115-231
+  ResidualRenderingNetwork   models/fields.py:400-495   (`RenderingNetwork` is an alias)
+  NeRF                       models/fields.py:541-642
+  SingleVarianceNetwork      models/fields.py:645-655
+  BetaNetwork                models/fields.py:658-700
+  color_blend                models/fields.py:498-537   (see models/blend.py kernels)
+
+There is NO PyTorch fallback for the arithmetic: calling these modules without libnudf.so or
+on CPU tensors raises `NudfError`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .embedder import get_embedder
+from .. import mlp
+from .._lib import NudfError  # noqa: F401
+
+
+def _wn(lin, enable):
+    return nn.utils.weight_norm(lin) if enable else lin
+
+
+# ------------------------------------------------------------------------------------------
+# autograd plumbing: one Function per engine; forward/backward are libnudf kernel chains
+# ------------------------------------------------------------------------------------------
+class _UDFEvalFn(torch.autograd.Function):
+    """(x, *params) -> (udf [P], featbuf [P, ld], grad [P,3]).
+    featbuf holds the F appearance features in cols 0..F-1; when `feat_ld` > F it is laid out as the
+    colour network's base input ([feat F | pts 3 | zero pad], see mlp.ColorEngine)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, want_grad, feat_ld, *params):
+        x = x.detach().contiguous()
+        need_state = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        st = engine.forward(x, need_grad_state=(need_state or want_grad), feat_ld=feat_ld)
+        g = DA = None
+        if want_grad:
+            g, DA = engine.gradient(x, st)
+        ctx.engine, ctx.x = engine, x
+        ctx.st, ctx.DA = (st if need_state else None), (DA if need_state else None)
+        return st["udf"], st["feat"], (g if g is not None else x.new_zeros(0))
+
+    @staticmethod
+    def backward(ctx, d_udf, d_feat, d_g):
+        engine, st = ctx.engine, ctx.st
+        if st is None:
+            raise RuntimeError("UDF evaluation was run without gradient state")
+        if d_g is not None and d_g.numel() == 0:
+            d_g = None
+        ldf = 0
+        if d_feat is not None:
+            d_feat = d_feat.contiguous()
+            ldf = d_feat.shape[1]
+        grads = engine.backward(ctx.x, st, ctx.DA, d_udf.contiguous() if d_udf is not None else None,
+                                d_feat, ldf, d_g.contiguous() if d_g is not None else None)
+        ctx.st = ctx.DA = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class UDFNetwork(nn.Module):
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, scale=1, bias=0.5,
+                 geometric_init=True, weight_norm=True, udf_type='abs',
+                 udf_shift=None, predict_grad=None):   # the garment confs pass these two; the reference ignores/chokes
+        super().__init__()
+        if udf_type != 'abs':
+            raise NotImplementedError("udf_type %r: the shipped confs (and the HIP head) use 'abs'" % udf_type)
+        dims = [d_in] + [d_hidden for _ in range(n_layers)] + [d_out]
+        self.embed_fn_fine = None
+        self.multires = multires
+        self.d_in = d_in
+        if multires > 0:
+            embed_fn, input_ch = get_embedder(multires, input_dims=d_in)
+            self.embed_fn_fine = embed_fn
+            dims[0] = input_ch
+        self.embed_dim = dims[0]
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        self.geometric_init = geometric_init
+        self.udf_type = udf_type
+        # identical construction + init order to fields.py:148-178 so torch.manual_seed gives identical weights
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)
+            if geometric_init:
+                if l == self.num_layers - 2:
+                    torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    torch.nn.init.constant_(lin.bias, -bias)
+                elif multires > 0 and l == 0:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    torch.nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif multires > 0 and l in self.skip_in:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    torch.nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                else:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            setattr(self, "lin" + str(l), _wn(lin, weight_norm))
+        self._engine = None
+
+    # -- HIP evaluation ------------------------------------------------------------------
+    def engine(self):
+        if self._engine is None:
+            self._engine = mlp.UDFEngine(self)
+        return self._engine
+
+    def evaluate(self, x, want_grad=True, feat_ld=0):
+        """fused value + spatial gradient: -> (udf [P], featbuf [P, max(feat_ld, F)], grad [P,3] or empty)."""
+        eng = self.engine()
+        return _UDFEvalFn.apply(eng, x, want_grad, feat_ld, *eng.params())
+
+    @property
+    def n_feature(self):
+        return getattr(self, "lin" + str(self.num_layers - 2)).bias.shape[0] - 1
+
+    def udf_only(self, x):
+        """no-grad udf [P] (importance sampling, fields.py:731): skips the 256 feature channels."""
+        eng = self.engine()
+        with torch.no_grad():
+            return eng.forward(x.detach().contiguous(), need_grad_state=False, udf_only=True)["udf"]
+
+    def forward(self, inputs):
+        udf, feat, _ = self.evaluate(inputs, want_grad=False)
+        return torch.cat([udf[:, None], feat[:, :self.n_feature]], dim=-1)
+
+    def udf(self, x):
+        udf, _, _ = self.evaluate(x, want_grad=False)
+        return udf[:, None]
+
+    def udf_hidden_appearance(self, x):
+        return self.forward(x)
+
+    def gradient(self, x):
+        _, _, g = self.evaluate(x, want_grad=True)
+        return g.unsqueeze(1)
+
+
+class SDFNetwork(nn.Module):
+    """Only the name is needed: exp_runner_blending.py:16 imports it and never instantiates it."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("SDFNetwork is dead code in the reference (never constructed by the runner)")
+
+
+# ------------------------------------------------------------------------------------------
+class _ColorFn(torch.autograd.Function):
+    """(CIN = [feat F | pts 3 | pad] buffer, rays_d, *params) -> (color_base, color, logits)."""
+
+    @staticmethod
+    def forward(ctx, engine, CIN, rays_d, S, *params):
+        P = CIN.shape[0]
+        need = torch.is_grad_enabled() and (CIN.requires_grad or any(p.requires_grad for p in params))
+        cb, col, logits, st = engine.forward(CIN.detach(), rays_d.detach().contiguous(), S, P, keep_state=need)
+        ctx.engine, ctx.st = engine, st
+        ctx.save_for_backward(cb, col)
+        if logits is None:
+            logits = cb.new_zeros(0)
+        return cb, col, logits
+
+    @staticmethod
+    def backward(ctx, d_cb, d_col, d_logits):
+        cb, col = ctx.saved_tensors
+        if d_logits is not None and d_logits.numel() == 0:
+            d_logits = None
+        grads, dCIN = ctx.engine.backward(ctx.st, cb, col,
+                                          d_cb.contiguous() if d_cb is not None else None,
+                                          d_col.contiguous() if d_col is not None else None,
+                                          d_logits.contiguous() if d_logits is not None else None)
+        ctx.st = None
+        return (None, dCIN, None, None) + tuple(grads)
+
+
+class ResidualRenderingNetwork(nn.Module):
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=0,
+                 squeeze_out=True, blending_cand_views=10):
+        super().__init__()
+        self.mode = mode
+        self.squeeze_out = squeeze_out
+        self.d_out, self.d_feature, self.d_hidden = d_out, d_feature, d_hidden
+        self.multires_view = multires_view
+        dims_base = [d_in - 3 + d_feature] + [d_hidden for _ in range(n_layers)] + [d_out]
+        dims = [d_hidden + d_out + 3] + [d_hidden for _ in range(n_layers)] + [d_out + blending_cand_views]
+        self.embedview_fn = None
+        self.view_dim = 3
+        if multires_view > 0 and self.mode != 'no_view_dir':
+            embedview_fn, input_ch = get_embedder(multires_view)
+            self.embedview_fn = embedview_fn
+            dims[0] += (input_ch - 3)
+            self.view_dim = input_ch
+        self.num_layers = len(dims)
+        # same creation order as fields.py:429-446: all lin*, then all lin_base*
+        for l in range(self.num_layers - 1):
+            setattr(self, "lin" + str(l), _wn(nn.Linear(dims[l], dims[l + 1]), weight_norm))
+        for l in range(self.num_layers - 1):
+            setattr(self, "lin_base" + str(l), _wn(nn.Linear(dims_base[l], dims_base[l + 1]), weight_norm))
+        self.if_blending = blending_cand_views > 0
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = mlp.ColorEngine(self)
+        return self._engine
+
+    def evaluate(self, CIN, rays_d, S):
+        """CIN: [P, pad(F+3)] = [feat | pts | 0] as produced by UDFNetwork.evaluate(feat_ld=engine.cin_ld)."""
+        eng = self.engine()
+        return _ColorFn.apply(eng, CIN, rays_d, S, *eng.params())
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        """reference call surface (fields.py:452-495); view_dirs is per point here."""
+        eng = self.engine()
+        P = points.shape[0]
+        pad = eng.cin_ld - eng.F - 3
+        CIN = torch.cat([feature_vectors, points.detach(), points.new_zeros(P, pad)], dim=1)   # layout plumbing
+        cb, col, logits = _ColorFn.apply(eng, CIN, view_dirs.contiguous(), 1, *eng.params())
+        if self.if_blending:
+            return cb, col, logits
+        return cb, col
+
+
+RenderingNetwork = ResidualRenderingNetwork   # north-star name; the runner instantiates the residual variant
+
+
+# ------------------------------------------------------------------------------------------
+class _NerfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, pts4, rays_d, S, *params):
+        P = pts4.shape[0]
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        sigma, rgb, st = engine.forward(pts4.detach().contiguous(), rays_d.detach().contiguous(), S, P, keep_state=need)
+        ctx.engine, ctx.st = engine, st
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, d_sigma, d_rgb):
+        P = ctx.st["P"]
+        dev = ctx.st["VIN"].device
+        if d_sigma is None:
+            d_sigma = torch.zeros(P, 1, device=dev)
+        if d_rgb is None:
+            d_rgb = torch.zeros(P, 3, device=dev)
+        grads = ctx.engine.backward(ctx.st, d_sigma.contiguous(), d_rgb.contiguous())
+        ctx.st = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class NeRF(nn.Module):
+    def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=0, output_ch=4, skips=[4],
+                 use_viewdirs=False, occupancy=True):
+        super().__init__()
+        self.D, self.W, self.d_in, self.d_in_view = D, W, d_in, d_in_view
+        self.input_ch, self.input_ch_view = 3, 3
+        self.multires, self.multires_view = multires, multires_view
+        self.embed_fn = self.embed_fn_view = None
+        self.occupancy = occupancy
+        if multires > 0:
+            self.embed_fn, self.input_ch = get_embedder(multires, input_dims=d_in)
+        if multires_view > 0:
+            self.embed_fn_view, self.input_ch_view = get_embedder(multires_view, input_dims=d_in_view)
+        self.skips = list(skips)
+        self.use_viewdirs = use_viewdirs
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)] +
+            [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_view + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = mlp.NerfEngine(self)
+        return self._engine
+
+    def evaluate(self, pts4, rays_d, S):
+        eng = self.engine()
+        return _NerfFn.apply(eng, pts4, rays_d, S, *eng.params())
+
+    def forward(self, input_pts, input_views):
+        if input_views is None:
+            raise NotImplementedError("NeRF.forward without view directions is unused on the hot path")
+        return self.evaluate(input_pts, input_views.contiguous(), 1)
+
+
+# ------------------------------------------------------------------------------------------
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val, requires_grad=True):
+        super().__init__()
+        self.variance = nn.Parameter(torch.Tensor([init_val]), requires_grad=requires_grad)
+
+    def set_trainable(self):
+        self.variance.requires_grad = True
+
+    def forward(self, x):
+        # 1-element parameter transform (fields.py:654-655): host-side plumbing, not per-sample work
+        return torch.ones([len(x), 1], device=x.device) * torch.exp(self.variance * 10.0)
+
+
+class BetaNetwork(nn.Module):
+    def __init__(self, init_var_beta=0.1, init_var_gamma=0.1, init_var_zeta=0.05, beta_min=0.00005,
+                 requires_grad_beta=True, requires_grad_gamma=True, requires_grad_zeta=True):
+        super().__init__()
+        self.beta = nn.Parameter(torch.Tensor([init_var_beta]), requires_grad=requires_grad_beta)
+        self.gamma = nn.Parameter(torch.Tensor([init_var_gamma]), requires_grad=requires_grad_gamma)
+        self.zeta = nn.Parameter(torch.Tensor([init_var_zeta]), requires_grad=requires_grad_zeta)
+        self.beta_min = beta_min
+
+    def get_beta(self):
+        return torch.exp(self.beta * 10).clip(0, 1. / self.beta_min)
+
+    def get_gamma(self):
+        return torch.exp(self.gamma * 10)
+
+    def get_zeta(self):
+        return self.zeta.abs()
+
+    def set_beta_trainable(self):
+        self.beta.requires_grad = True
+
+    @torch.no_grad()
+    def set_gamma(self, x):
+        self.gamma = nn.Parameter(torch.Tensor([x]), requires_grad=self.gamma.requires_grad).to(self.gamma.device)
+
+    def forward(self):
+        return self.get_beta(), self.get_gamma(), self.get_zeta()

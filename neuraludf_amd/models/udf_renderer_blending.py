@@ -1,0 +1,397 @@
+"""Drop-in for the reference's `models/udf_renderer_blending.py`: `UDFRendererBlending` with the
+same constructor / `render` signature and the same 32-key result dict
+(models/udf_renderer_blending.py:107-148, 586-721), driving hand-written HIP kernels:
+
+  coarse samples            nudf_coarse_z / nudf_outside_z          (:605-630)
+  importance re-sampling    nudf_upsample + nudf_merge + UDF MLP     (:723-755, 762-866, 66-104, 274-290)
+  background                NeRF MLP on the outside samples          (:161-195, see note below)
+  render_core               UDF MLP (+ d udf/dx), colour MLP, fused composite kernel (:327-584)
+
+Host code here only allocates buffers, draws the random numbers (so seeding matches the
+reference, Appendix B-18 of SURVEY.md) and sequences kernels; there is no PyTorch fallback.
+
+Notes on value-preserving deviations (all verified against the oracle):
+  * render_core evaluates the UDF MLP once (the reference runs the identical forward twice, :364/:368);
+  * the NeRF is evaluated on the `n_outside` samples only when `color_maps is None` (the
+    reference evaluates all S+n_outside points and discards the inside ones, :493-501);
+  * NaN guards that block on the host (:97, :265, :543, :860) are dropped;
+  * `sparse_random_error` (:681-686, never consumed by the runner) is 0.0 unless
+    `renderer.compute_sparse_random = True`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .._lib import Composite, CompositeGrad, Upsample, call, ptr
+from .. import dist as nudf_dist
+
+_DIAG = ["alpha", "alpha_plus", "alpha_minus", "vis_prob", "alpha_occ", "raw_occ", "true_cos", "grad_mag", "mid_z",
+         "dists", "inside", "flip"]
+
+
+def _fill_composite(a, c, N, S, n_out):
+    a.N, a.S, a.n_out, a.s_nominal = N, S, n_out, c["s_nominal"]
+    a.has_anneal = 0 if c["cos_anneal"] is None else 1
+    a.cos_anneal = 0.0 if c["cos_anneal"] is None else float(c["cos_anneal"])
+    a.flip_saturation = float(c["flip_saturation"])
+    a.use_norm_grad = 1 if c["use_norm_grad"] else 0
+    a.sparse_scale = float(c["sparse_scale"])
+
+
+class _CompositeFn(torch.autograd.Function):
+    """fused alpha/transmittance/composite; differentiable w.r.t. udf, grad, colours, background and scalars."""
+
+    @staticmethod
+    def forward(ctx, c, rays_o, rays_d, z, sample_dist, background_rgb, udf, grad, color, color_base, bg_z, bg_sigma,
+                bg_color, scal):
+        N, S = z.shape
+        n_out = 0 if bg_z is None else bg_z.shape[1]
+        dev = z.device
+        t = lambda x: None if x is None else x.detach().contiguous()
+        rays_o, rays_d, z, udf, grad, color, color_base = map(t, (rays_o, rays_d, z, udf, grad, color, color_base))
+        bg_z, bg_sigma, bg_color, scal = map(t, (bg_z, bg_sigma, bg_color, scal))
+        a = Composite()
+        a.rays_o, a.rays_d, a.z, a.udf, a.grad = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf), ptr(grad)
+        a.color, a.color_base = ptr(color), ptr(color_base)
+        a.bg_z, a.bg_sigma, a.bg_color = ptr(bg_z), ptr(bg_sigma), ptr(bg_color)
+        a.scal, a.sample_dist, a.background_rgb = ptr(scal), ptr(sample_dist), ptr(t(background_rgb))
+        _fill_composite(a, c, N, S, n_out)
+        weights = torch.empty(N, S + n_out, device=dev)
+        out_color = torch.empty(N, 3, device=dev)
+        out_cb = torch.empty(N, 3, device=dev)
+        depth = torch.empty(N, 1, device=dev)
+        normals = torch.empty(N, 3, device=dev)
+        wsum = torch.empty(N, 1, device=dev)
+        wsum_all = torch.empty(N, 1, device=dev)
+        sums = torch.zeros(5, device=dev)
+        a.weights, a.out_color, a.out_color_base = ptr(weights), ptr(out_color), ptr(out_cb)
+        a.out_depth, a.out_normals, a.out_wsum, a.out_wsum_all, a.sums = (ptr(depth), ptr(normals), ptr(wsum),
+                                                                          ptr(wsum_all), ptr(sums))
+        diag = []
+        if c["diagnostics"]:
+            for k in _DIAG:
+                d = torch.empty(N, S, device=dev)
+                setattr(a, "o_" + k, ptr(d))
+                diag.append(d)
+        call("nudf_composite_fwd", a)
+        ctx.c = c
+        ctx.save_for_backward(rays_o, rays_d, z, sample_dist, t(background_rgb), udf, grad, color, color_base, bg_z,
+                              bg_sigma, bg_color, scal)
+        ctx.mark_non_differentiable(*diag)
+        return (out_color, out_cb, weights, depth, normals, wsum, wsum_all, sums) + tuple(diag)
+
+    @staticmethod
+    def backward(ctx, d_color, d_cb, d_weights, d_depth, d_normals, d_wsum, d_wsum_all, d_sums, *_):
+        (rays_o, rays_d, z, sample_dist, background_rgb, udf, grad, color, color_base, bg_z, bg_sigma, bg_color,
+         scal) = ctx.saved_tensors
+        c = ctx.c
+        N, S = z.shape
+        n_out = 0 if bg_z is None else bg_z.shape[1]
+        dev = z.device
+        a = Composite()
+        a.rays_o, a.rays_d, a.z, a.udf, a.grad = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf), ptr(grad)
+        a.color, a.color_base = ptr(color), ptr(color_base)
+        a.bg_z, a.bg_sigma, a.bg_color = ptr(bg_z), ptr(bg_sigma), ptr(bg_color)
+        a.scal, a.sample_dist, a.background_rgb = ptr(scal), ptr(sample_dist), ptr(background_rgb)
+        _fill_composite(a, c, N, S, n_out)
+        g = CompositeGrad()
+        cg = lambda x: None if x is None else x.contiguous()
+        keep = [cg(x) for x in (d_color, d_cb, d_weights, d_depth, d_normals, d_wsum, d_wsum_all, d_sums)]
+        (g.d_color, g.d_color_base, g.d_weights, g.d_depth, g.d_normals, g.d_wsum, g.d_wsum_all,
+         g.d_sums) = [ptr(x) for x in keep]
+        o_udf = torch.empty(N, S, device=dev)
+        o_grad = torch.empty(N, S, 3, device=dev)
+        o_col = torch.empty(N, S, 3, device=dev)
+        o_cb = torch.empty(N, S, 3, device=dev)
+        o_sig = torch.empty(N, n_out, device=dev) if n_out else None
+        o_bgc = torch.empty(N, n_out, 3, device=dev) if n_out else None
+        o_scal = torch.zeros(3, device=dev)
+        g.o_d_udf, g.o_d_grad, g.o_d_color, g.o_d_color_base = ptr(o_udf), ptr(o_grad), ptr(o_col), ptr(o_cb)
+        g.o_d_bg_sigma, g.o_d_bg_color, g.o_d_scal = ptr(o_sig), ptr(o_bgc), ptr(o_scal)
+        call("nudf_composite_bwd", a, g)
+        return (None, None, None, None, None, None, o_udf, o_grad, o_col, o_cb, None, o_sig, o_bgc, o_scal)
+
+
+def extract_fields(bound_min, bound_max, resolution, query_func, device='cuda'):
+    """Dense-grid field query (models/udf_renderer_blending.py:16-31): chunks of 64^3 points."""
+    n = 64
+    X = torch.linspace(bound_min[0], bound_max[0], resolution).split(n)
+    Y = torch.linspace(bound_min[1], bound_max[1], resolution).split(n)
+    Z = torch.linspace(bound_min[2], bound_max[2], resolution).split(n)
+    u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+    with torch.no_grad():
+        for xi, xs in enumerate(X):
+            for yi, ys in enumerate(Y):
+                for zi, zs in enumerate(Z):
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(device)
+                    val = query_func(pts).reshape(len(xs), len(ys), len(zs)).detach().cpu().numpy()
+                    u[xi * n: xi * n + len(xs), yi * n: yi * n + len(ys), zi * n: zi * n + len(zs)] = val
+    return u
+
+
+def extract_gradient_fields(bound_min, bound_max, resolution, query_func, device='cuda'):
+    """(:33-49) same chunking, [R,R,R,3] output."""
+    n = 64
+    X = torch.linspace(bound_min[0], bound_max[0], resolution).split(n)
+    Y = torch.linspace(bound_min[1], bound_max[1], resolution).split(n)
+    Z = torch.linspace(bound_min[2], bound_max[2], resolution).split(n)
+    u = np.zeros([resolution, resolution, resolution, 3], dtype=np.float32)
+    for xi, xs in enumerate(X):
+        for yi, ys in enumerate(Y):
+            for zi, zs in enumerate(Z):
+                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(device)
+                val = query_func(pts).reshape(len(xs), len(ys), len(zs), 3).detach().cpu().numpy()
+                u[xi * n: xi * n + len(xs), yi * n: yi * n + len(ys), zi * n: zi * n + len(zs)] = val
+    return u
+
+
+class UDFRendererBlending:
+    def __init__(self, nerf, udf_network, deviation_network, color_network, beta_network, n_samples, n_importance,
+                 n_outside, up_sample_steps, perturb, sdf2alpha_type='numerical', upsampling_type='classical',
+                 sparse_scale_factor=25000, h_patch_size=3, use_norm_grad_for_cosine=False):
+        self.nerf = nerf
+        self.udf_network = udf_network
+        self.deviation_network = deviation_network
+        self.color_network = color_network
+        self.beta_network = beta_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.perturb = perturb
+        self.up_sample_steps = up_sample_steps
+        if sdf2alpha_type != 'numerical':
+            raise NotImplementedError("sdf2alpha_type %r: every shipped conf uses 'numerical'" % sdf2alpha_type)
+        self.sdf2alpha_type = sdf2alpha_type
+        self.upsampling_type = upsampling_type
+        self.sparse_scale_factor = sparse_scale_factor
+        self.h_patch_size = h_patch_size
+        self.use_norm_grad_for_cosine = use_norm_grad_for_cosine
+        # knobs that do not exist in the reference (defaults keep its behaviour)
+        self.diagnostics = True            # fill the debug keys of the result dict
+        self.compute_sparse_random = False
+        self.data_parallel = False         # all-reduce the batch-global loss sums over the process group
+        from .patch_projector import PatchProjector
+        self.patch_projector = PatchProjector(self.h_patch_size)
+        self._u_cache = {}
+
+    # ------------------------------------------------------------------------------------
+    def _scalars(self, dev):
+        """inv_s, beta, gamma: 1-element parameter transforms + call-site clips (:373-377)."""
+        inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6).reshape(1)
+        beta = self.beta_network.get_beta().clip(1e-6, 1e6).reshape(1)
+        gamma = self.beta_network.get_gamma().clip(1e-6, 1e6).reshape(1)
+        return inv_s, beta, gamma
+
+    def _quantiles(self, k, dev):
+        key = (k, str(dev))
+        if key not in self._u_cache:
+            self._u_cache[key] = torch.linspace(0. + 0.5 / k, 1. - 0.5 / k, steps=k).to(dev).contiguous()
+        return self._u_cache[key]
+
+    def _udf_at(self, rays_o, rays_d, z, sample_dist):
+        N, M = z.shape
+        pts = torch.empty(N * M, 3, device=z.device)
+        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z), ptr(sample_dist), N, M, 0, ptr(pts))
+        return self.udf_network.udf_only(pts).reshape(N, M)
+
+    def _upsample(self, rays_o, rays_d, z, udf, sample_dist, k, mode, inv_s, beta, gamma, gamma_dev=None):
+        N, M = z.shape
+        dev = z.device
+        a = Upsample()
+        a.rays_o, a.rays_d, a.z, a.udf = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf)
+        a.u, a.sample_dist, a.gamma_dev = ptr(self._quantiles(k, dev)), ptr(sample_dist), ptr(gamma_dev)
+        a.N, a.M, a.K, a.mode = N, M, k, mode
+        a.inv_s, a.beta, a.gamma = float(inv_s), float(beta), float(gamma)
+        z_new = torch.empty(N, k, device=dev)
+        pts_new = torch.empty(N * k, 3, device=dev)
+        a.z_new, a.pts_new = ptr(z_new), ptr(pts_new)
+        call("nudf_upsample", a)
+        return z_new, pts_new
+
+    def _merge(self, z, udf, z_new, udf_new):
+        N, M = z.shape
+        K = z_new.shape[1]
+        zo = torch.empty(N, M + K, device=z.device)
+        uo = torch.empty(N, M + K, device=z.device) if udf_new is not None else None
+        call("nudf_merge", ptr(z), ptr(udf) if uo is not None else None, ptr(z_new), ptr(udf_new), N, M, K, ptr(zo),
+             ptr(uo))
+        return zo, uo
+
+    @torch.no_grad()
+    def importance_sample(self, rays_o, rays_d, z_vals, sample_dist):
+        """classical schedule (:723-755). `sample_dist` is a 1-element device tensor."""
+        N = rays_o.shape[0]
+        udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist)
+        steps = self.up_sample_steps
+        k = self.n_importance // steps
+        for i in range(steps):
+            gamma = float(np.clip(20 * 2 ** (steps - i), 20, 320))
+            z_new, pts_new = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 0, 64 * 2 ** i,
+                                            64 * 2 ** (i + 1), gamma)
+            last = (i + 1 == steps)
+            udf_new = None if last else self.udf_network.udf_only(pts_new).reshape(N, k)
+            z_vals, udf = self._merge(z_vals, udf, z_new, udf_new)
+        return z_vals
+
+    @torch.no_grad()
+    def importance_sample_mix(self, rays_o, rays_d, z_vals, sample_dist):
+        """mix schedule (:762-832): `steps` not-occlusion-aware rounds + one unbiased round."""
+        N = rays_o.shape[0]
+        udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist)
+        steps = self.up_sample_steps
+        k = self.n_importance // (steps + 1)
+        gamma_dev = self.beta_network.get_gamma().clip(1e-6, 1e6).detach().reshape(1).contiguous()
+        for i in range(steps):
+            z_new, pts_new = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 1, 64 * 2 ** i,
+                                            64 * 2 ** (i + 1), 0.0, gamma_dev)
+            udf_new = self.udf_network.udf_only(pts_new).reshape(N, k)
+            z_vals, udf = self._merge(z_vals, udf, z_new, udf_new)
+        i = steps - 1
+        z_new, _ = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 0, 64 * 2 ** i, 64 * 2 ** (i + 1),
+                                  20 if i < 4 else 10)
+        z_vals, _ = self._merge(z_vals, udf, z_new, None)
+        return z_vals
+
+    # ------------------------------------------------------------------------------------
+    def render_core_outside(self, rays_o, rays_d, z_out, sample_dist):
+        """NeRF++ background on the outside samples (:161-195): -> (sigma [N,n_out], rgb [N,n_out,3])."""
+        N, n_out = z_out.shape
+        pts4 = torch.empty(N * n_out, 4, device=z_out.device)
+        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z_out), ptr(sample_dist), N, n_out, 2, ptr(pts4))
+        sigma, rgb = self.nerf.evaluate(pts4, rays_d, n_out)
+        return sigma.reshape(N, n_out), rgb.reshape(N, n_out, 3)
+
+    def render_core(self, rays_o, rays_d, z_vals, sample_dist, cos_anneal_ratio=None, background_rgb=None,
+                    bg_z=None, bg_sigma=None, bg_color=None, flip_saturation=0.0, color_maps=None, w2cs=None,
+                    intrinsics=None, query_c2w=None, img_index=None, rays_uv=None, s_nominal=None):
+        """(:327-584) given sorted samples."""
+        N, S = z_vals.shape
+        dev = z_vals.device
+        P = N * S
+        pts = torch.empty(P, 3, device=dev)
+        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z_vals), ptr(sample_dist), N, S, 1, ptr(pts))
+        ceng = self.color_network.engine()
+        udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld)
+        cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
+        inv_s, beta, gamma = self._scalars(dev)
+        scal = torch.cat([inv_s, beta, gamma])
+        c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,
+                 flip_saturation=flip_saturation, use_norm_grad=self.use_norm_grad_for_cosine,
+                 sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics)
+        outs = _CompositeFn.apply(c, rays_o, rays_d, z_vals, sample_dist, background_rgb, udf.reshape(N, S),
+                                  grad.reshape(N, S, 3), col.reshape(N, S, 3), cb.reshape(N, S, 3), bg_z, bg_sigma,
+                                  bg_color, scal)
+        color, color_base, weights, depth, normals, wsum, wsum_all, sums = outs[:8]
+        diag = dict(zip(_DIAG, outs[8:])) if self.diagnostics else {}
+        if self.data_parallel:
+            sums = nudf_dist.all_reduce_sum(sums)
+        n_rays = float(N) * (nudf_dist.world_size() if self.data_parallel else 1)
+        gradient_error = sums[0] / (sums[1] + 1e-5)                       # (:533)
+        gradient_error_ns = sums[2] / (sums[3] + 1e-5)                    # (:536)
+        sparse_error = sums[4] / n_rays                                   # (:553)
+
+        color_pixel = patch_colors = patch_mask = None
+        if color_maps is not None:
+            from . import blend
+            color_pixel, patch_colors, patch_mask = blend.blend_and_composite(
+                self, pts.reshape(N, S, 3), logits.reshape(N, S, -1), weights, diag.get("inside"), grad.reshape(N, S, 3),
+                rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv, bg_color_all=None)
+
+        g3 = grad.reshape(N, S, 3)
+        ret = {
+            'color_base': color_base, 'color': color, 'color_pixel': color_pixel, 'patch_colors': patch_colors,
+            'patch_mask': patch_mask, 'weights': weights, 's_val': 1.0 / inv_s.reshape(1, 1),
+            'beta': 1.0 / beta, 'gamma': gamma, 'depth': depth, 'gradient_error': gradient_error,
+            'gradient_error_near_surface': gradient_error_ns, 'normals': normals, 'gradients': g3,
+            'udf': udf.reshape(N, S), 'sparse_error': sparse_error, 'weight_sum': wsum, 'weight_sum_fg_bg': wsum_all,
+        }
+        if self.diagnostics:
+            ret.update({
+                'gradients_flip': diag["flip"][:, :, None] * g3, 'inside_sphere': diag["inside"],
+                'gradient_mag': diag["grad_mag"], 'true_cos': diag["true_cos"], 'vis_prob': diag["vis_prob"],
+                'alpha': diag["alpha"], 'alpha_plus': diag["alpha_plus"], 'alpha_minus': diag["alpha_minus"],
+                'mid_z_vals': diag["mid_z"], 'dists': diag["dists"], 'alpha_occ': diag["alpha_occ"],
+                'raw_occ': diag["raw_occ"]})
+        else:
+            for k in ['gradients_flip', 'inside_sphere', 'gradient_mag', 'true_cos', 'vis_prob', 'alpha', 'alpha_plus',
+                      'alpha_minus', 'mid_z_vals', 'dists', 'alpha_occ', 'raw_occ']:
+                ret[k] = None
+        return ret
+
+    # ------------------------------------------------------------------------------------
+    def render(self, rays_o, rays_d, near, far, cos_anneal_ratio=None, perturb_overwrite=-1, background_rgb=None,
+               flip_saturation=0, color_maps=None, w2cs=None, intrinsics=None, query_c2w=None, img_index=None,
+               rays_uv=None):
+        dev = rays_o.device
+        N = len(rays_o)
+        rays_o = rays_o.detach().float().contiguous()
+        rays_d = rays_d.detach().float().contiguous()
+        if not isinstance(near, torch.Tensor):
+            near = torch.tensor([float(near)], device=dev).view(1, 1)
+            far = torch.tensor([float(far)], device=dev).view(1, 1)
+        near = near.detach().float().contiguous()
+        far = far.detach().float().contiguous()
+        nf_stride = 1 if near.shape[0] == N and N > 1 else (1 if near.numel() == N else 0)
+        if near.numel() == 1:
+            nf_stride = 0
+
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        t_rand = None
+        lin = None
+        if self.n_outside > 0:
+            lin = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside)
+        if perturb > 0:
+            t_rand = (torch.rand([N, 1]) - 0.5).to(dev).contiguous()            # (:618)
+            if self.n_outside > 0:                                               # (:621-627) stratified jitter
+                mids = .5 * (lin[..., 1:] + lin[..., :-1])
+                upper = torch.cat([mids, lin[..., -1:]], -1)
+                lower = torch.cat([lin[..., :1], mids], -1)
+                lin = lower + (upper - lower) * torch.rand(lin.shape).to(lin.device)
+        z_vals = torch.empty(N, self.n_samples, device=dev)
+        sample_dist = torch.empty(1, device=dev)
+        call("nudf_coarse_z", ptr(near), ptr(far), nf_stride, ptr(t_rand), N, self.n_samples, ptr(z_vals),
+             ptr(sample_dist))
+        z_out = None
+        if self.n_outside > 0:
+            z_out = torch.empty(N, self.n_outside, device=dev)
+            call("nudf_outside_z", ptr(far), nf_stride, ptr(lin.to(dev).float().contiguous()), N, self.n_outside,
+                 self.n_samples, ptr(z_out))
+
+        n_samples = self.n_samples
+        if self.n_importance > 0:
+            if self.upsampling_type == 'classical':
+                z_vals = self.importance_sample(rays_o, rays_d, z_vals, sample_dist)
+            elif self.upsampling_type == 'mix':
+                z_vals = self.importance_sample_mix(rays_o, rays_d, z_vals, sample_dist)
+            n_samples = self.n_samples + self.n_importance
+
+        bg_sigma = bg_color = None
+        if self.n_outside > 0:
+            bg_sigma, bg_color = self.render_core_outside(rays_o, rays_d, z_out, sample_dist)
+
+        bgrgb = None
+        if background_rgb is not None:
+            bgrgb = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()
+        ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, cos_anneal_ratio, bgrgb, z_out, bg_sigma,
+                               bg_color, flip_saturation, color_maps, w2cs, intrinsics, query_c2w, img_index, rays_uv,
+                               s_nominal=n_samples)
+
+        sparse_random_error = 0.0
+        if perturb > 0 or self.compute_sparse_random:
+            pts_random = torch.rand([1024, 3]).float().to(dev) * 2 - 1          # keeps the RNG stream aligned (:683)
+            if self.compute_sparse_random:
+                with torch.no_grad():
+                    udf_random = self.udf_network.udf(pts_random)
+                if (udf_random < 0.01).sum() > 10:
+                    sparse_random_error = torch.exp(-self.sparse_scale_factor * udf_random[udf_random < 0.01]).mean()
+        ret['variance'] = ret.pop('s_val')
+        ret['z_vals'] = z_vals
+        ret['sparse_random_error'] = sparse_random_error
+        return ret
+
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.01, device='cpu'):
+        raise NotImplementedError("mesh extraction (mcubes / custom_mc) is outside the hot path; use "
+                                  "extract_fields(..., lambda p: renderer.udf_network.udf(p)[:, 0]) for the grid")

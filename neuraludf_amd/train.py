@@ -1,0 +1,104 @@
+"""One training step of the hot path, assembled exactly like the reference runner does it
+(exp_runner_blending.py:125-139 networks + Adam groups, :296-375 loss assembly), for bench.py,
+`__graft_entry__.smoke()` and the tests.  The runner itself is out of scope (it is the caller that
+drops in unchanged); this is the minimum of it needed to time / check a full step."""
+from __future__ import annotations
+
+import contextlib
+import io
+
+import torch
+
+from . import dist as nudf_dist
+from .loss.loss import ColorLoss
+from .models import fields
+from .models.udf_renderer_blending import UDFRendererBlending
+
+# shipped DTU conf (confs/udf_dtu_blending.conf:56-118)
+DTU_MODEL_CONF = dict(
+    nerf=dict(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4],
+              use_viewdirs=True),
+    udf_network=dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                     geometric_init=True, weight_norm=True, udf_type="abs"),
+    variance_network=dict(init_val=0.3),
+    rendering_network=dict(d_feature=256, mode="no_normal", d_in=6, d_out=3, d_hidden=128, n_layers=4,
+                           weight_norm=True, multires_view=4, squeeze_out=True, blending_cand_views=10),
+    beta_network=dict(init_var_beta=0.5, init_var_gamma=0.3, init_var_zeta=0.3, beta_min=0.00005,
+                      requires_grad_beta=True, requires_grad_gamma=False, requires_grad_zeta=False),
+)
+
+
+class Trainer:
+    def __init__(self, device, renderer_conf, color_loss_conf=None, train_conf=None, seed=0, data_parallel=False,
+                 fields_mod=fields, renderer_cls=UDFRendererBlending, loss_cls=ColorLoss, fused_adam=False):
+        torch.manual_seed(seed)
+        c = DTU_MODEL_CONF
+        with contextlib.redirect_stdout(io.StringIO()):
+            self.nerf = fields_mod.NeRF(**c["nerf"]).to(device)
+            self.udf = fields_mod.UDFNetwork(**c["udf_network"]).to(device)
+            self.var = fields_mod.SingleVarianceNetwork(**c["variance_network"]).to(device)
+            self.color = fields_mod.ResidualRenderingNetwork(**c["rendering_network"]).to(device)
+            self.beta = fields_mod.BetaNetwork(**c["beta_network"]).to(device)
+        tc = dict(learning_rate=5e-4, learning_rate_geo=1e-4, igr_weight=0.1, igr_ns_weight=0.0, mask_weight=0.0,
+                  sparse_weight=0.0)
+        tc.update(train_conf or {})
+        self.tc = tc
+        geo = list(self.udf.parameters())
+        other = list(self.var.parameters()) + list(self.color.parameters()) + list(self.beta.parameters())
+        nerf = list(self.nerf.parameters())
+        self.param_groups = [geo, other, nerf]
+        groups = [{'params': geo, 'lr': tc["learning_rate_geo"]}, {'params': other}, {'params': nerf}]
+        if fused_adam:
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(groups, lr=tc["learning_rate"])
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=tc["learning_rate"])
+        self.renderer = renderer_cls(self.nerf, self.udf, self.var, self.color, self.beta, **renderer_conf)
+        lc = dict(color_base_weight=0.01, color_weight=1.0, color_pixel_weight=0.0, color_patch_weight=0.0,
+                  pixel_loss_type="l1", patch_loss_type="ssim", h_patch_size=3)
+        lc.update(color_loss_conf or {})
+        self.lc = lc
+        with contextlib.redirect_stdout(io.StringIO()):
+            self.color_loss = loss_cls(**lc)
+        self.data_parallel = data_parallel
+        if data_parallel:
+            self.renderer.data_parallel = True
+            self.color_loss.set_data_parallel(True)
+            self.bucket = nudf_dist.GradBucket([p for g in self.param_groups for p in g])
+
+    def modules(self):
+        return dict(nerf=self.nerf, udf=self.udf, var=self.var, color=self.color, beta=self.beta)
+
+    def loss(self, batch, cos_anneal_ratio=1.0, flip_saturation=1.0, blend=None, perturb_overwrite=-1):
+        """-> (loss, render_out)."""
+        tc, lc = self.tc, self.lc
+        kw = {}
+        if blend is not None and lc["color_pixel_weight"] > 0:
+            kw = dict(color_maps=blend["color_maps"], w2cs=blend["w2cs"], intrinsics=blend["intrinsics"],
+                      query_c2w=blend["query_c2w"],
+                      rays_uv=batch["rays_uv"].clone() if lc["color_patch_weight"] > 0 else None)
+        out = self.renderer.render(batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
+                                   flip_saturation=flip_saturation, cos_anneal_ratio=cos_anneal_ratio,
+                                   perturb_overwrite=perturb_overwrite, **kw)
+        weight_sum = out["weight_sum"]
+        patch_mask = None
+        if out["patch_mask"] is not None:
+            patch_mask = (out["patch_mask"].float()[:, None] * (weight_sum > 0.5).float()) > 0.
+        pixel_mask = batch["mask"] if tc["mask_weight"] > 0 else None
+        cl = self.color_loss(out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"], pixel_mask,
+                             out["patch_colors"], batch.get("gt_patch_colors"), patch_mask)
+        loss = cl["loss"] + out["gradient_error_near_surface"] * tc["igr_ns_weight"] \
+            + out["sparse_error"] * tc["sparse_weight"] + out["gradient_error"] * tc["igr_weight"]
+        if tc["mask_weight"] > 0:
+            loss = loss + torch.nn.functional.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3),
+                                                                   batch["mask"]) * tc["mask_weight"]
+        return loss, out
+
+    def step(self, batch, **kw):
+        loss, out = self.loss(batch, **kw)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.data_parallel:
+            self.bucket.all_reduce()
+        self.optimizer.step()
+        return loss.detach(), out

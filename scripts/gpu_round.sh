@@ -1,0 +1,11 @@
+#!/bin/bash
+# one GPU-box round: parity tests, smoke, bench, rocprof kernel trace.  Output under gpurun_out/.
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python -m neuraludf_amd.build > gpurun_out/build.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+tail -n 60 gpurun_out/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -n 5 gpurun_out/smoke.log
+timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -n 3 gpurun_out/bench.log
