@@ -38,7 +38,7 @@ class _UDFEvalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, x, want_grad, feat_ld, *params):
         x = x.detach().contiguous()
-        need_state = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_state = any(ctx.needs_input_grad)      # all False under no_grad (grad mode is off inside forward)
         st = engine.forward(x, need_grad_state=(need_state or want_grad), feat_ld=feat_ld)
         g = DA = None
         if want_grad:
@@ -159,7 +159,7 @@ class _ColorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, CIN, rays_d, S, *params):
         P = CIN.shape[0]
-        need = torch.is_grad_enabled() and (CIN.requires_grad or any(p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)
         cb, col, logits, st = engine.forward(CIN.detach(), rays_d.detach().contiguous(), S, P, keep_state=need)
         ctx.engine, ctx.st = engine, st
         ctx.save_for_backward(cb, col)
@@ -236,7 +236,7 @@ class _NerfFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, pts4, rays_d, S, *params):
         P = pts4.shape[0]
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need = any(ctx.needs_input_grad)
         sigma, rgb, st = engine.forward(pts4.detach().contiguous(), rays_d.detach().contiguous(), S, P, keep_state=need)
         ctx.engine, ctx.st = engine, st
         return sigma, rgb

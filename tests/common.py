@@ -52,12 +52,12 @@ def state_dicts(mods):
     return {k: {n: t.detach().clone() for n, t in m.state_dict().items()} for k, m in mods.items()}
 
 
-def oracle_nets(sds, requires_grad=False):
+def oracle_nets(sds, requires_grad=False, dtype=torch.float32):
     from oracle import udf_oracle as O
     def prep(sd):
         out = {}
         for k, v in sd.items():
-            t = v.detach().clone().float()
+            t = v.detach().clone().to(dtype)
             if requires_grad:
                 t.requires_grad_(True)
             out[k] = t

@@ -1,0 +1,68 @@
+"""The oracle against the committed golden fixtures (outputs of the reference code itself, see
+tests/golden/make_golden.py).  Runs anywhere (CPU): rebuilds the seeded weights through the drop-in
+modules' constructors, proves they are the fixture's weights by checksum, and compares."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import build_modules, perturb_, state_dicts, oracle_nets, checksum
+from neuraludf_amd import synth
+from oracle import udf_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = {
+    "cfg1_flat": dict(n_samples=32, n_importance=0, n_outside=0, up_sample_steps=1),
+    "classical_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5),
+    "mix_blend": dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, upsampling_type="mix",
+                      use_norm_grad_for_cosine=True, h_patch_size=3),
+}
+
+
+def _maxrel(a, b):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1.0))
+
+
+@pytest.fixture(scope="module")
+def sds():
+    from neuraludf_amd.models import fields
+    return state_dicts(perturb_(build_modules(fields, seed=0)))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_reproduces_reference_outputs(sds, name):
+    gold = np.load(os.path.join(HERE, "golden", f"ref_{name}.npz"))
+    for k, sd in sds.items():
+        assert abs(checksum(sd) - float(gold["wsum_" + k])) < 1e-6 * max(1.0, abs(float(gold["wsum_" + k]))), k
+    rays = {k[4:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("ray_")}
+    nets = oracle_nets(sds, requires_grad=True)
+    cfg = O.RenderCfg(**CASES[name])
+    blend = None
+    if name == "mix_blend":
+        src = synth.make_source_views(synth.make_scene("tiny"), 0, 8)
+        blend = dict(color_maps=src["color_maps"], w2cs=src["w2cs"], intrinsics=src["intrinsics"],
+                     query_c2w=src["query_c2w"], rays_uv=rays["rays_uv"].clone())
+    out = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                   flip_saturation=0.9, blend=blend)
+    for k in gold.files:
+        if k.startswith("out_"):
+            assert _maxrel(out[k[4:]].detach(), gold[k]) < 5e-6, k
+    loss = ((out["color"] - rays["true_rgb"]).abs().mean() + 0.5 * (out["color_base"] - rays["true_rgb"]).abs().mean()
+            + 0.1 * out["gradient_error"] + 0.01 * out["gradient_error_near_surface"] + 0.001 * out["sparse_error"])
+    if name == "mix_blend":
+        cl = O.color_loss(1.0, 1.0, 0.5, 0.2, 3, out["color_base"], out["color"], rays["true_rgb"], out["color_pixel"],
+                          rays["mask"], out["patch_colors"], torch.from_numpy(gold["gt_patch"]),
+                          torch.from_numpy(gold["pmask"]).clone())
+        for k in cl:
+            assert abs(float(cl[k]) - float(gold["closs_" + k])) < 1e-5 * max(1.0, abs(float(gold["closs_" + k]))), k
+        loss = loss + cl["loss"]
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5
+    loss.backward()
+    for k in gold.files:
+        if k.startswith("grad_"):
+            _, net, pn = k.split("_", 2)
+            g = getattr(nets, net)[pn].grad
+            assert g is not None, k
+            assert _maxrel(g, gold[k]) < 5e-5, k
