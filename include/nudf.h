@@ -31,13 +31,14 @@ enum {
   NUDF_EPI_RELU = 2,      /* C1 = relu(acc+bias)*scale                                   */
   NUDF_EPI_MUL = 3,       /* C1 = acc * X1 * scale                                       */
   NUDF_EPI_MULMASK = 4,   /* C1 = (X1 > 0) ? acc*scale : 0      (ReLU backward)          */
-  NUDF_EPI_TANGENT = 5,   /* C1 = acc*X1*scale ; C2 = acc*X2*100*(1-X1)                   */
-  NUDF_EPI_BWD = 6,       /* C1 = acc*scale*X1 + X2                                      */
+  NUDF_EPI_TANGENT = 5,   /* s from X1 (as MULSP): C1 = acc*s*scale ; C2 = acc*X2*100*(1-s)  */
+  NUDF_EPI_BWD = 6,       /* s from X1 (as MULSP): C1 = acc*scale*s + X2                   */
   NUDF_EPI_SIGMOID = 7,   /* cols < iparam: sigmoid -> C1 (and C2) ; others raw -> C3[row, col-iparam] (or C1) */
   NUDF_EPI_UDFHEAD = 8,   /* col 0: |v|*scale -> C2[row], sign -> C3[row]; col c>0 -> C1[row,c-1] */
-  NUDF_EPI_SKIPSPLIT = 9, /* col < iparam: C1 = acc*X1*scale ; else C2[col-iparam] = acc*scale */
+  NUDF_EPI_SKIPSPLIT = 9, /* col < iparam: C1 = acc*s*scale (s from X1) ; else C2[col-iparam] = acc*scale */
   NUDF_EPI_RELU_DUAL = 10,/* C1 = C2 = relu(acc+bias)                                    */
-  NUDF_EPI_ADDMASK = 11   /* C1 = (X1 > 0) ? (acc + X2)*scale : 0   (ReLU backward at a join) */
+  NUDF_EPI_ADDMASK = 11,  /* C1 = (X1 > 0) ? (acc + X2)*scale : 0   (ReLU backward at a join) */
+  NUDF_EPI_MULSP = 12     /* C1 = acc * softplus'(.) * scale, softplus' recovered from X1 = stored softplus output * (1/xscale) */
 };
 
 typedef struct NudfGemmNN {
@@ -53,10 +54,13 @@ typedef struct NudfGemmNN {
   int32_t epi;                      /* NUDF_EPI_*                                         */
   int32_t iparam;
   float scale;
+  float xscale;                     /* X1 holds softplus output / xscale (MULSP, TANGENT, BWD, SKIPSPLIT) */
 } NudfGemmNN;
 
 /* C[M,N] = epilogue(A[M,K] B[K,N]) */
 int nudf_gemm_nn(const NudfGemmNN* args, void* stream);
+/* tuning hook: 0 = auto tile choice (default), 1..4 force a tile/buffering variant; returns the old value */
+int nudf_set_gemm_variant(int variant);
 
 typedef struct NudfGemmTN {
   const float* A1; int32_t lda1; int32_t na1;   /* [M, na1]                               */
@@ -169,7 +173,7 @@ int nudf_copy_cols(const float* src, int lds, int sdiv, float* dst, int ldd, int
 int nudf_add_cols(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int P, int C, void* stream);
 
 /* heads of the MLP chains */
-int nudf_udf_grad_seed(const float* sign, const float* w_row0, const float* sig, int lds, int P, int C,
+int nudf_udf_grad_seed(const float* sign, const float* w_row0, const float* h, int ldh, float hscale, int P, int C,
                        float inv_scale, float* out, int ldo, void* stream);
 int nudf_udf_head_bwd(const float* sign, const float* dudf, const float* dfeat, int ldf, int P, int F,
                       float scale, float* out, int ldo, void* stream);

@@ -26,7 +26,7 @@ class GemmNN(C.Structure):
     _fields_ = [("A", c_fp), ("lda", i32), ("B", c_fp), ("ldb", i32), ("bias", c_fp),
                 ("C1", c_fp), ("ldc1", i32), ("C2", c_fp), ("ldc2", i32), ("C3", c_fp), ("ldc3", i32),
                 ("X1", c_fp), ("ldx1", i32), ("X2", c_fp), ("ldx2", i32),
-                ("M", i32), ("N", i32), ("K", i32), ("epi", i32), ("iparam", i32), ("scale", f32)]
+                ("M", i32), ("N", i32), ("K", i32), ("epi", i32), ("iparam", i32), ("scale", f32), ("xscale", f32)]
 
 
 class GemmTN(C.Structure):
@@ -66,11 +66,11 @@ class Upsample(C.Structure):
 
 
 EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
-           SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11)
+           SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11, MULSP=12)
 
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_gemm_tn", "nudf_composite_fwd",
+    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_composite_fwd",
     "nudf_composite_bwd", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
@@ -92,7 +92,7 @@ _ARGTYPES = {
     "nudf_posenc_vjp": [_P, _I, _I, _I, _F, _I, _P, _I, _F, _P, _I, _F, _P, _P],
     "nudf_copy_cols": [_P, _I, _I, _P, _I, _I, _I, _F, _P],
     "nudf_add_cols": [_P, _I, _P, _I, _P, _I, _I, _I, _P],
-    "nudf_udf_grad_seed": [_P, _P, _P, _I, _I, _I, _F, _P, _I, _P],
+    "nudf_udf_grad_seed": [_P, _P, _P, _I, _F, _I, _I, _F, _P, _I, _P],
     "nudf_udf_head_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _I, _P],
     "nudf_signed_colsum": [_P, _P, _I, _I, _I, _F, _P, _P],
     "nudf_sigmoid_head_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P],

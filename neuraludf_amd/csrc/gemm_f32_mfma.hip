@@ -10,6 +10,7 @@
 // and their (double-)backward.  MFMA peak for this instruction: 157.3 TFLOP/s.
 #include "nudf_common.h"
 #include "nudf_gemm.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -31,6 +32,22 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nblk) {
   return ((nblk & 7) == 0) ? (b & 7) * (nblk >> 3) + (b >> 3) : b;
 }
 
+// softplus'(a) = s and 1 - s recovered from the STORED activation h = softplus100(a) * (1/xscale):
+//   1 - s = exp(-100 h), s = -expm1(-100 h)  (exact identities; no 1 - s cancellation near s = 1, which
+//   matters for softplus'' = 100 s (1 - s) in the second-order backward).  Above torch's threshold
+//   (100 a > 20 <=> h > 0.2) autograd uses s = 1, s' = 0.
+__device__ __forceinline__ void sp_derivs_from_h(float hstored, float xscale, float& s, float& om) {
+  const float x = 100.0f * xscale * hstored;
+  if (x > 20.0f) {
+    s = 1.0f;
+    om = 0.0f;
+  } else {
+    const float e = __expf(-x);
+    om = e;
+    s = (x < 0.01f) ? x * (1.0f - x * (0.5f - x * 0.16666667f)) : 1.0f - e;
+  }
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const NudfGemmNN& p, int row, int col, float acc) {
   float v = acc;
@@ -39,21 +56,36 @@ __device__ __forceinline__ void epilogue_store(const NudfGemmNN& p, int row, int
   if (EPI == NUDF_EPI_NONE) {
     p.C1[r * p.ldc1 + col] = v * p.scale;
   } else if (EPI == NUDF_EPI_SOFTPLUS) {
-    p.C1[r * p.ldc1 + col] = softplus100(v) * p.scale;
-    if (p.C2) p.C2[r * p.ldc2 + col] = softplus100_grad(v);
+    // nn.Softplus(beta=100, threshold=20) and its derivative from ONE hardware exp (v_exp_f32):
+    //   z = e^{100 v}; h = log(1+z)/100; h' = z/(1+z)   (above the threshold: h = v, h' = 1)
+    const float t = 100.0f * v;
+    float h = v;
+    if (t <= 20.0f) {
+      const float z = __expf(t);
+      h = (z < 1e-4f) ? (z - 0.5f * z * z) * 0.01f : __logf(1.0f + z) * 0.01f;   // log1p series for tiny z
+    }
+    p.C1[r * p.ldc1 + col] = h * p.scale;
+    if (p.C2) p.C2[r * p.ldc2 + col] = (t <= 20.0f) ? __fdividef(__expf(t), 1.0f + __expf(t)) : 1.0f;
   } else if (EPI == NUDF_EPI_RELU) {
     p.C1[r * p.ldc1 + col] = fmaxf(v, 0.0f) * p.scale;
   } else if (EPI == NUDF_EPI_MUL) {
     p.C1[r * p.ldc1 + col] = v * p.X1[r * p.ldx1 + col] * p.scale;
   } else if (EPI == NUDF_EPI_MULMASK) {
     p.C1[r * p.ldc1 + col] = (p.X1[r * p.ldx1 + col] > 0.0f) ? v * p.scale : 0.0f;
-  } else if (EPI == NUDF_EPI_TANGENT) {
-    float sg = p.X1[r * p.ldx1 + col];
+  } else if (EPI == NUDF_EPI_MULSP) {
+    float sg, om;
+    sp_derivs_from_h(p.X1[r * p.ldx1 + col], p.xscale, sg, om);
     p.C1[r * p.ldc1 + col] = v * sg * p.scale;
-    // softplus'' = 100 s (1 - s) below the threshold, 0 above (s == 1 there)
-    p.C2[r * p.ldc2 + col] = v * p.X2[r * p.ldx2 + col] * 100.0f * (1.0f - sg);
+  } else if (EPI == NUDF_EPI_TANGENT) {
+    float sg, om;
+    sp_derivs_from_h(p.X1[r * p.ldx1 + col], p.xscale, sg, om);
+    p.C1[r * p.ldc1 + col] = v * sg * p.scale;
+    // X2 = da = delta * s, so  acc * delta * softplus''  =  acc * da * 100 (1 - s)
+    p.C2[r * p.ldc2 + col] = v * p.X2[r * p.ldx2 + col] * 100.0f * om;
   } else if (EPI == NUDF_EPI_BWD) {
-    p.C1[r * p.ldc1 + col] = v * p.scale * p.X1[r * p.ldx1 + col] + p.X2[r * p.ldx2 + col];
+    float sg, om;
+    sp_derivs_from_h(p.X1[r * p.ldx1 + col], p.xscale, sg, om);
+    p.C1[r * p.ldc1 + col] = v * p.scale * sg + (p.X2 ? p.X2[r * p.ldx2 + col] : 0.0f);
   } else if (EPI == NUDF_EPI_SIGMOID) {
     // first iparam columns through a sigmoid (optionally mirrored into C2), the rest raw
     if (col < p.iparam) {
@@ -77,8 +109,13 @@ __device__ __forceinline__ void epilogue_store(const NudfGemmNN& p, int row, int
   } else if (EPI == NUDF_EPI_SKIPSPLIT) {
     // reverse sweep through the skip concat: columns < iparam belong to the hidden branch
     // (times softplus' and scale), the rest go to the embedding branch (times scale)
-    if (col < p.iparam) p.C1[r * p.ldc1 + col] = v * p.X1[r * p.ldx1 + col] * p.scale;
-    else p.C2[r * p.ldc2 + (col - p.iparam)] = v * p.scale;
+    if (col < p.iparam) {
+      float sg, om;
+      sp_derivs_from_h(p.X1[r * p.ldx1 + col], p.xscale, sg, om);
+      p.C1[r * p.ldc1 + col] = v * sg * p.scale;
+    } else {
+      p.C2[r * p.ldc2 + (col - p.iparam)] = v * p.scale;
+    }
   } else if (EPI == NUDF_EPI_RELU_DUAL) {
     // relu output to two destinations (hidden tap of the colour net, fields.py:472-473)
     float h = fmaxf(v, 0.0f);
@@ -89,115 +126,149 @@ __device__ __forceinline__ void epilogue_store(const NudfGemmNN& p, int row, int
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(NudfGemmNN p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+// ---------------------------------------------------------------------------------------
+// C[M,N] = epilogue(A[M,K] B[K,N]).  Block = 4 waves (2x2); each wave owns (WM*32)x(WN*32) outputs as
+// WMxWN MFMA tiles, so the block tile is (64*WM)x(64*WN).  NBUF = 1: single LDS buffer + register
+// prefetch, two barriers per k-step, small enough (33 KB at 128x128) for 3-4 co-resident blocks per CU
+// whose epilogues (HBM-bound) overlap the other blocks' MFMA phases; NBUF = 2: double-buffered LDS.
+// ---------------------------------------------------------------------------------------
+template <int EPI, int WM, int WN, int NBUF, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nn_kernel(NudfGemmNN p) {
+  constexpr int TBM = 64 * WM, TBN = 64 * WN;
+  constexpr int LDA = TBM + 1, LDB = TBN + 4;
+  constexpr int ATILE = BK * LDA, BTILE = BK * LDB;
+  constexpr int APASS = TBM / 32, BPASS = TBN / 32;  // float4 loads per thread per k-step
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (ATILE + BTILE)];
   float* As = smem;
-  float* Bs = smem + 2 * A_TILE;
+  float* Bs = smem + NBUF * ATILE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + TBN - 1) / TBN;
   const int lb = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int m0 = (lb / tiles_n) * BM;
-  const int n0 = (lb % tiles_n) * BN;
+  const int m0 = (lb / tiles_n) * TBM;
+  const int n0 = (lb % tiles_n) * TBN;
   const int nk = p.K / BK;
 
-  // per-thread global->LDS assignments
-  int a_row[4], a_kq[4], b_k[4], b_c4[4];
-  const float* a_ptr[4];
-  const float* b_ptr[4];
-  bool b_ok[4];
+  int a_off[APASS], b_off[BPASS];
+  int a_lds[APASS], b_lds[BPASS];
+  bool b_ok[BPASS];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
-    int idx = ps * 256 + tid;
-    a_row[ps] = idx >> 3;
-    a_kq[ps] = idx & 7;
-    int gr = m0 + a_row[ps];
+  for (int ps = 0; ps < APASS; ++ps) {
+    const int idx = ps * 256 + tid;
+    const int row = idx >> 3, kq = idx & 7;
+    int gr = m0 + row;
     if (gr > p.M - 1) gr = p.M - 1;
-    a_ptr[ps] = p.A + (size_t)gr * p.lda + a_kq[ps] * 4;
-    b_k[ps] = idx >> 5;
-    b_c4[ps] = idx & 31;
-    int gc = n0 + b_c4[ps] * 4;
+    a_off[ps] = gr * p.lda + kq * 4;
+    a_lds[ps] = (kq * 4) * LDA + row;
+  }
+#pragma unroll
+  for (int ps = 0; ps < BPASS; ++ps) {
+    const int idx = ps * 256 + tid;
+    const int kr = idx / (TBN / 4), c4 = idx % (TBN / 4);
+    const int gc = n0 + c4 * 4;
     b_ok[ps] = gc < p.ldb;
-    b_ptr[ps] = p.B + (size_t)b_k[ps] * p.ldb + (b_ok[ps] ? gc : 0);
+    b_off[ps] = kr * p.ldb + (b_ok[ps] ? gc : 0);
+    b_lds[ps] = kr * LDB + c4 * 4;
   }
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[APASS], rb[BPASS];
   auto gload = [&](int kt) {
+    const float* Ak = p.A + kt * BK;
+    const float* Bk = p.B + (size_t)kt * BK * p.ldb;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      ra[ps] = *reinterpret_cast<const f32x4*>(a_ptr[ps] + kt * BK);
-      rb[ps] = b_ok[ps] ? *reinterpret_cast<const f32x4*>(b_ptr[ps] + (size_t)kt * BK * p.ldb)
-                        : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int ps = 0; ps < APASS; ++ps) ra[ps] = *reinterpret_cast<const f32x4*>(Ak + a_off[ps]);
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps)
+      rb[ps] = b_ok[ps] ? *reinterpret_cast<const f32x4*>(Bk + b_off[ps]) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto sstore = [&](int buf) {
-    float* as = As + buf * A_TILE;
-    float* bs = Bs + buf * B_TILE;
+    float* as = As + buf * ATILE;
+    float* bs = Bs + buf * BTILE;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      float* d = as + (a_kq[ps] * 4) * LDA_S + a_row[ps];
+    for (int ps = 0; ps < APASS; ++ps) {
+      float* d = as + a_lds[ps];
       d[0] = ra[ps].x;
-      d[LDA_S] = ra[ps].y;
-      d[2 * LDA_S] = ra[ps].z;
-      d[3 * LDA_S] = ra[ps].w;
-      *reinterpret_cast<f32x4*>(bs + b_k[ps] * LDB_S + b_c4[ps] * 4) = rb[ps];
+      d[LDA] = ra[ps].y;
+      d[2 * LDA] = ra[ps].z;
+      d[3 * LDA] = ra[ps].w;
     }
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps) *reinterpret_cast<f32x4*>(bs + b_lds[ps]) = rb[ps];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const bool act0 = (n0 + wn * 64) < p.N;
-  const bool act1 = (n0 + wn * 64 + 32) < p.N;
+  // wave-uniform activity of the column tiles (N may end inside the block tile)
+  const int ncol_act = min(WN, max(0, (p.N - (n0 + wn * 32 * WN) + 31) / 32));
 
-  gload(0);
-  sstore(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    if (act0) {
-      const float* as = As + cur * A_TILE + (lane >> 5) * LDA_S + wm * 64 + (lane & 31);
-      const float* bs = Bs + cur * B_TILE + (lane >> 5) * LDB_S + wn * 64 + (lane & 31);
+  auto compute = [&](int buf) {
+    const float* as = As + buf * ATILE + (lane >> 5) * LDA + wm * (32 * WM) + (lane & 31);
+    const float* bs = Bs + buf * BTILE + (lane >> 5) * LDB + wn * (32 * WN) + (lane & 31);
+    if (ncol_act == WN) {
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float a0 = as[(2 * kk) * LDA_S];
-        float a1 = as[(2 * kk) * LDA_S + 32];
-        float b0 = bs[(2 * kk) * LDB_S];
-        acc[0][0] = mfma32(a0, b0, acc[0][0]);
-        acc[1][0] = mfma32(a1, b0, acc[1][0]);
-        if (act1) {
-          float b1 = bs[(2 * kk) * LDB_S + 32];
-          acc[0][1] = mfma32(a0, b1, acc[0][1]);
-          acc[1][1] = mfma32(a1, b1, acc[1][1]);
-        }
+        float a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = as[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = bs[(2 * kk) * LDB + 32 * j];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+      }
+    } else if (ncol_act > 0) {  // only the first column tile is live (WN == 2)
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const float b0 = bs[(2 * kk) * LDB];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[i][0] = mfma32(as[(2 * kk) * LDA + 32 * i], b0, acc[i][0]);
       }
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
+  };
+
+  if (NBUF == 2) {
+    gload(0);
+    sstore(0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      compute(cur);
+      if (kt + 1 < nk) sstore(cur ^ 1);
+      __syncthreads();
+    }
+  } else {
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      sstore(0);
+      __syncthreads();
+      if (kt + 1 < nk) gload(kt + 1);
+      compute(0);
+      __syncthreads();
+    }
   }
 
-  if (!act0) return;
+  if (ncol_act == 0) return;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < WM; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !act1) continue;
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < WN; ++j) {
+      if (j >= ncol_act) continue;
+      const int col = n0 + wn * (32 * WN) + j * 32 + (lane & 31);
       if (col >= p.N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < p.M) epilogue_store<EPI>(p, row, col, acc[i][j][r]);
       }
     }
@@ -336,12 +407,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-template <int EPI>
-static int launch_nn(const NudfGemmNN& p, hipStream_t st) {
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_nn_kernel<EPI>, dim3(tiles), dim3(256), 0, st, p);
+template <int EPI, int WM, int WN, int NBUF, int OCC>
+static int launch_cfg(const NudfGemmNN& p, hipStream_t st) {
+  const int tiles = ((p.M + 64 * WM - 1) / (64 * WM)) * ((p.N + 64 * WN - 1) / (64 * WN));
+  hipLaunchKernelGGL((gemm_nn_kernel<EPI, WM, WN, NBUF, OCC>), dim3(tiles), dim3(256), 0, st, p);
   NUDF_CHECK_LAUNCH("nudf_gemm_nn");
   return 0;
+}
+
+static int g_variant = -1;  // NUDF_GEMM_VARIANT: 0 auto, 1 = 128x128 double-buffered, 2 = 128x128 single,
+                            // 3 = 64x128 single, 4 = 64x64 single   (tuning / A-B measurements only)
+extern "C" int nudf_set_gemm_variant(int v) {
+  const int old = g_variant;
+  g_variant = v;
+  return old;
+}
+
+template <int EPI>
+static int launch_nn(const NudfGemmNN& p, hipStream_t st) {
+  if (g_variant < 0) {
+    const char* e = getenv("NUDF_GEMM_VARIANT");
+    g_variant = e ? atoi(e) : 0;
+  }
+  int v = g_variant;
+  if (v == 0) {
+    // measured on MI355X (scripts/gemm_bench.py, profiles/r01_gemm_variants.txt): the 64x64 tile at 8 waves/SIMD
+    // wins on every shape of this workload -- these layer GEMMs sit at the fp32 ridge (K = 128..256, several
+    // [M,N] epilogue operands), so overlapping many small blocks' epilogues with other blocks' MFMA phases
+    // matters more than LDS reuse; 64x128 is within 5 % on M = 32768
+    v = 4;
+  }
+  switch (v) {
+    case 1: return launch_cfg<EPI, 2, 2, 2, 2>(p, st);
+    case 2: return launch_cfg<EPI, 2, 2, 1, 4>(p, st);
+    case 3: return launch_cfg<EPI, 1, 2, 1, 4>(p, st);
+    default: return launch_cfg<EPI, 1, 1, 1, 6>(p, st);
+  }
 }
 
 extern "C" int nudf_gemm_nn(const NudfGemmNN* args, void* stream) {
@@ -366,6 +467,7 @@ extern "C" int nudf_gemm_nn(const NudfGemmNN* args, void* stream) {
     case NUDF_EPI_SKIPSPLIT: return launch_nn<NUDF_EPI_SKIPSPLIT>(p, st);
     case NUDF_EPI_RELU_DUAL: return launch_nn<NUDF_EPI_RELU_DUAL>(p, st);
     case NUDF_EPI_ADDMASK: return launch_nn<NUDF_EPI_ADDMASK>(p, st);
+    case NUDF_EPI_MULSP: return launch_nn<NUDF_EPI_MULSP>(p, st);
     default:
       nudf_set_error("nudf_gemm_nn: unknown epilogue", hipErrorInvalidValue);
       return (int)hipErrorInvalidValue;

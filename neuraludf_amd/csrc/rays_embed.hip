@@ -207,18 +207,22 @@ extern "C" int nudf_copy_cols(const float* src, int lds, int sdiv, float* dst, i
 //   da_last_hidden[p, c] = sign[p] * W_last[0, c] * inv_scale * softplus'(a)[p, c]
 // ---------------------------------------------------------------------------------------
 __global__ void udf_grad_seed_kernel(const float* __restrict__ sign, const float* __restrict__ wrow,
-                                     const float* __restrict__ sig, int lds, int P, int C, float inv_scale,
-                                     float* __restrict__ out, int ldo) {
+                                     const float* __restrict__ h, int ldh, float hscale, int P, int C,
+                                     float inv_scale, float* __restrict__ out, int ldo) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)P * C) return;
   int p = (int)(idx / C), c = (int)(idx - (long long)p * C);
-  out[(size_t)p * ldo + c] = sign[p] * wrow[c] * inv_scale * sig[(size_t)p * lds + c];
+  // softplus' recovered from the stored activation (see sp_derivs_from_h in gemm_f32_mfma.hip)
+  const float x = 100.0f * hscale * h[(size_t)p * ldh + c];
+  float sg = 1.0f;
+  if (x <= 20.0f) sg = (x < 0.01f) ? x * (1.0f - x * (0.5f - x * 0.16666667f)) : 1.0f - __expf(-x);
+  out[(size_t)p * ldo + c] = sign[p] * wrow[c] * inv_scale * sg;
 }
-extern "C" int nudf_udf_grad_seed(const float* sign, const float* w_row0, const float* sig, int lds, int P, int C,
-                                  float inv_scale, float* out, int ldo, void* stream) {
+extern "C" int nudf_udf_grad_seed(const float* sign, const float* w_row0, const float* h, int ldh, float hscale, int P,
+                                  int C, float inv_scale, float* out, int ldo, void* stream) {
   if (P == 0) return 0;
   hipLaunchKernelGGL(udf_grad_seed_kernel, dim3(nblocks((long long)P * C, 256)), dim3(256), 0, (hipStream_t)stream, sign,
-                     w_row0, sig, lds, P, C, inv_scale, out, ldo);
+                     w_row0, h, ldh, hscale, P, C, inv_scale, out, ldo);
   NUDF_CHECK_LAUNCH("nudf_udf_grad_seed");
   return 0;
 }

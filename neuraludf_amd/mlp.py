@@ -36,7 +36,7 @@ def _buf(P, width, dev, zero=None):
 
 
 def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=0, X1=None, ldx1=0, X2=None, ldx2=0,
-            bias=None, lda=None, ldb=None, iparam=0, scale=1.0, c1_off=0, c2_off=0, x1_off=0, x2_off=0):
+            bias=None, lda=None, ldb=None, iparam=0, scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x1_off=0, x2_off=0):
     """thin wrapper filling NudfGemmNN; *_off are column offsets (in floats) into the buffers."""
     a = GemmNN()
     a.A, a.lda = ptr(A), (lda if lda is not None else A.shape[1])
@@ -52,7 +52,7 @@ def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=
     a.ldx1 = ldx1 or (X1.shape[1] if (X1 is not None and X1.dim() == 2) else 0)
     a.X2 = (ptr(X2) + 4 * x2_off) if X2 is not None else None
     a.ldx2 = ldx2 or (X2.shape[1] if (X2 is not None and X2.dim() == 2) else 0)
-    a.M, a.N, a.K, a.epi, a.iparam, a.scale = M, N, K, EPI[epi], iparam, scale
+    a.M, a.N, a.K, a.epi, a.iparam, a.scale, a.xscale = M, N, K, EPI[epi], iparam, scale, xscale
     if PROFILE is not None:
         _timed("gemm_nn", 2.0 * M * N * getattr(B, "k_true", K), lambda: call("nudf_gemm_nn", a))
         return
@@ -195,12 +195,11 @@ class UDFEngine:
         for pl in self.layers:
             pl.pack()
         X = [_buf(P, pl.inp, dev) for pl in self.layers]
-        SIG = [_buf(P, self.layers[l].out, dev) for l in range(L)] if need_grad_state else [None] * L
         self._embed(x, P, X)
         for l in range(L):
             pl = self.layers[l]
             sc = self.inv_sqrt2 if (l + 1) in self.skip else 1.0
-            gemm_nn(X[l], pl.Wt, P, pl.out, pl.in_pad, "SOFTPLUS", C1=X[l + 1], C2=SIG[l], bias=pl.bias, scale=sc)
+            gemm_nn(X[l], pl.Wt, P, pl.out, pl.in_pad, "SOFTPLUS", C1=X[l + 1], bias=pl.bias, scale=sc)
         pl = self.layers[L]
         udf = torch.empty(P, device=dev)
         sign = torch.empty(P, device=dev) if need_grad_state else None
@@ -213,15 +212,19 @@ class UDFEngine:
                 call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
         gemm_nn(X[L], pl.Wt, P, 1 if udf_only else pl.out, pl.in_pad, "UDFHEAD", C1=feat, C2=udf, ldc2=1, C3=sign,
                 ldc3=1, bias=pl.bias, scale=1.0 / float(self.net.scale))
-        return dict(udf=udf, sign=sign, feat=feat, X=X, SIG=SIG, P=P)
+        return dict(udf=udf, sign=sign, feat=feat, X=X, P=P)
+
+    def _xs(self, j):
+        """softplus output of layer j is stored in X[j+1] divided by this factor (skip concat /sqrt(2))."""
+        return math.sqrt(2.0) if (j + 1) in self.skip else 1.0
 
     def gradient(self, x, st):
         """reverse sweep for d udf / d x given forward state -> (g [P,3], DA list)."""
         P, L, dev = st["P"], self.L, x.device
-        SIG = st["SIG"]
+        X = st["X"]
         DA = [_buf(P, self.layers[l].out, dev) for l in range(L)]
         plL = self.layers[L]
-        call("nudf_udf_grad_seed", ptr(st["sign"]), ptr(plL.W), ptr(SIG[L - 1]), SIG[L - 1].shape[1], P,
+        call("nudf_udf_grad_seed", ptr(st["sign"]), ptr(plL.W), ptr(X[L]), X[L].shape[1], self._xs(L - 1), P,
              self.layers[L - 1].out, 1.0 / float(self.net.scale), ptr(DA[L - 1]), DA[L - 1].shape[1])
         Epad = pad32(self.E)
         demb_skip = None
@@ -231,10 +234,10 @@ class UDFEngine:
                 if demb_skip is not None:
                     raise NotImplementedError("more than one skip layer")
                 demb_skip = torch.zeros(P, Epad, device=dev)
-                gemm_nn(DA[l], pl.W, P, pl.inp, pl.out_pad, "SKIPSPLIT", C1=DA[l - 1], C2=demb_skip, X1=SIG[l - 1],
-                        iparam=self.layers[l - 1].out, scale=self.inv_sqrt2)
+                gemm_nn(DA[l], pl.W, P, pl.inp, pl.out_pad, "SKIPSPLIT", C1=DA[l - 1], C2=demb_skip, X1=X[l],
+                        iparam=self.layers[l - 1].out, scale=self.inv_sqrt2, xscale=self._xs(l - 1))
             else:
-                gemm_nn(DA[l], pl.W, P, pl.inp, pl.out_pad, "MUL", C1=DA[l - 1], X1=SIG[l - 1])
+                gemm_nn(DA[l], pl.W, P, pl.inp, pl.out_pad, "MULSP", C1=DA[l - 1], X1=X[l], xscale=self._xs(l - 1))
         demb0 = torch.zeros(P, Epad, device=dev)
         pl0 = self.layers[0]
         gemm_nn(DA[0], pl0.W, P, pl0.inp, pl0.out_pad, "NONE", C1=demb0)
@@ -247,7 +250,7 @@ class UDFEngine:
         """-> list of parameter gradients in params() order.
         d_udf [P] / d_feat [P, F] (row stride d_feat_ld) / d_g [P,3]; any may be None."""
         P, L, dev = st["P"], self.L, x.device
-        X, SIG, sign = st["X"], st["SIG"], st["sign"]
+        X, sign = st["X"], st["sign"]
         layers = self.layers
         grads = [pl.new_grad_buffers() for pl in layers]
         second = d_g is not None and DA is not None
@@ -260,8 +263,8 @@ class UDFEngine:
             for l in range(L):
                 pl = layers[l]
                 sc = self.inv_sqrt2 if (l + 1) in self.skip else 1.0
-                gemm_nn(R[l], pl.Wt, P, pl.out, pl.in_pad, "TANGENT", C1=R[l + 1], C2=EX[l], X1=SIG[l], X2=DA[l],
-                        scale=sc)
+                gemm_nn(R[l], pl.Wt, P, pl.out, pl.in_pad, "TANGENT", C1=R[l + 1], C2=EX[l], X1=X[l + 1], X2=DA[l],
+                        scale=sc, xscale=self._xs(l))
             # d W_L[0,:] += sum_p sign_p * R_L[p,:] / scale
             call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp,
                  1.0 / float(self.net.scale), ptr(grads[L][0]))
@@ -275,11 +278,8 @@ class UDFEngine:
             pl = layers[l]
             ABAR[l - 1] = _buf(P, layers[l - 1].out, dev)
             sc = self.inv_sqrt2 if l in self.skip else 1.0
-            if second:
-                gemm_nn(ABAR[l], pl.W, P, layers[l - 1].out, pl.out_pad, "BWD", C1=ABAR[l - 1], X1=SIG[l - 1],
-                        X2=EX[l - 1], scale=sc)
-            else:
-                gemm_nn(ABAR[l], pl.W, P, layers[l - 1].out, pl.out_pad, "MUL", C1=ABAR[l - 1], X1=SIG[l - 1], scale=sc)
+            gemm_nn(ABAR[l], pl.W, P, layers[l - 1].out, pl.out_pad, "BWD", C1=ABAR[l - 1], X1=X[l],
+                    X2=EX[l - 1] if second else None, scale=sc, xscale=self._xs(l - 1))
         out = []
         for l, pl in enumerate(layers):
             dW, db = grads[l]

@@ -59,11 +59,18 @@ def test_gemm_nn_plain_and_epilogues(dev):
         assert rel(C, sp) < 1e-5
         sg = torch.where(ref * 100 > 20, torch.ones_like(ref), torch.sigmoid(100 * ref)).float()
         assert rel(C2, sg) < 2e-4       # sigmoid(100 a): fp32 rounding of a (~1e-6) is amplified 25x
-        X1 = torch.rand(M, N, generator=g).to(dev)
+        # softplus'-from-stored-activation epilogues: X1 = softplus(a)/xs  ->  s = sigmoid(100 a)
+        apre = torch.randn(M, N, generator=g) * 0.05
+        xs = 1.4142135
+        X1 = (torch.nn.functional.softplus(apre.double(), beta=100.0, threshold=20.0) / xs).float().to(dev)
+        sref = torch.where(apre.double() * 100 > 20, torch.ones_like(apre.double()), torch.sigmoid(100 * apre.double()))
         X2 = torch.randn(M, N, generator=g).to(dev)
-        mlp.gemm_nn(Ad, Bd, M, N, K, "BWD", C1=C, X1=X1, X2=X2, scale=0.7)
-        refb = (A.double() @ B[:, :N].double()).float() * 0.7 * X1.cpu() + X2.cpu()
-        assert rel(C, refb) < 1e-5
+        acc = A.double() @ B[:, :N].double()
+        mlp.gemm_nn(Ad, Bd, M, N, K, "BWD", C1=C, X1=X1, X2=X2, scale=0.7, xscale=xs)
+        assert rel(C, (acc * 0.7 * sref + X2.cpu().double()).float()) < 1e-5
+        mlp.gemm_nn(Ad, Bd, M, N, K, "TANGENT", C1=C, C2=C2, X1=X1, X2=X2, scale=0.7, xscale=xs)
+        assert rel(C, (acc * 0.7 * sref).float()) < 1e-5
+        assert rel(C2, (acc * X2.cpu().double() * 100.0 * (1.0 - sref)).float()) < 1e-5
 
 
 def test_gemm_tn(dev):
@@ -376,7 +383,11 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
 
     def loss_of(o, rgb):
         return ((o["color"] - rgb).abs().mean() + 0.5 * (o["color_base"] - rgb).abs().mean()
-                + 0.1 * o["gradient_error"] + 0.01 * o["gradient_error_near_surface"] + 0.001 * o["sparse_error"])
+                + 0.1 * o["gradient_error"] + 0.01 * o["gradient_error_near_surface"])
+        # sparse_error = mean sum exp(-25000 udf) is left out of THIS loss on purpose: its gradient
+        # -25000 exp(-25000 u) turns an fp32 ulp-level difference of u (1e-6 abs) into percents, for the
+        # fp32 reference just as much; its backward is checked on identical udf inputs in
+        # test_composite_stagewise instead
 
     loss_of(ref, r["true_rgb"]).backward()
     loss_of(out2, D(r["true_rgb"])).backward()
