@@ -154,6 +154,55 @@ int nudf_merge(const float* z, const float* udf, const float* z_new, const float
                int K, float* z_out, float* udf_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Pixel / patch blending and the SSIM patch loss (gradients reach the blending logits and the
+ * compositing weights only, as in the reference).
+ * ---------------------------------------------------------------------------------- */
+typedef struct NudfPixelBlend {   /* patch_projector.py:21-43, projector_utils.py:8-85, fields.py:498-519 */
+  const float* pts;               /* [P,3] sample points                                    */
+  const float* logits; int32_t nl;/* [P,nl] blending logits (first V columns used)          */
+  const float* proj;              /* [V,12] row-major 3x4 = K_v[:3,:3] @ w2c_v[:3,:]        */
+  const float* imgs;              /* [V,3,H,W] source images                                */
+  int32_t P, V, H, W;
+  float* pix;                     /* [P,3] blended pixel colour per sample                  */
+} NudfPixelBlend;
+int nudf_pixel_blend_fwd(const NudfPixelBlend* a, void* stream);
+int nudf_pixel_blend_bwd(const NudfPixelBlend* a, const float* d_pix, float* d_logits, void* stream);
+
+typedef struct NudfPixelComposite {   /* udf_renderer_blending.py:503-518 */
+  const float* w;                 /* [N,S+n_out] compositing weights                        */
+  const float* pix;               /* [N,S,3]                                                */
+  const float* pts;               /* [N,S,3] (inside-sphere test), used when bg_in != NULL  */
+  const float* bg_in;             /* [N,S,3] background colour at the inside samples / NULL */
+  const float* bg_tail;           /* [N,n_out,3] / NULL                                     */
+  int32_t N, S, n_out;
+  float* out;                     /* [N,3]                                                  */
+} NudfPixelComposite;
+int nudf_pixel_composite_fwd(const NudfPixelComposite* a, void* stream);
+int nudf_pixel_composite_bwd(const NudfPixelComposite* a, const float* d_out, float* d_w, float* d_pix,
+                             float* d_bg_in, float* d_bg_tail, void* stream);
+
+typedef struct NudfPatchBlend {   /* patch_projector.py:45-164, fields.py:521-535, udf_renderer_blending.py:520-524 */
+  const float* pts;               /* [N,S,3]                                                */
+  const float* grad;              /* [N,S,3] d udf/dx (normal = flip * grad/(|grad|+1e-5))  */
+  const float* rays_d;            /* [N,3]                                                  */
+  const float* uv;                /* [N,2] ray pixel in the reference image (pixel units)   */
+  const float* logits; int32_t nl;/* [N,S,nl]                                               */
+  const float* w; int32_t ldw;    /* [N,ldw] compositing weights (first S used)             */
+  const float* ref_cam;           /* [24] K_ref^-1 | R_ref | t_ref | cam centre             */
+  const float* src_cam;           /* [V,24] K_src | R_rel | t_rel | -R_rel^T t_rel          */
+  const float* imgs;              /* [V,3,H,W]                                              */
+  int32_t N, S, V, H, W, hps;
+  float* patch_colors;            /* [N,(2h+1)^2,3]                                         */
+  float* patch_mask;              /* [N] = sum_s w_s [any view sees the whole patch]        */
+} NudfPatchBlend;
+int nudf_patch_blend_fwd(const NudfPatchBlend* a, void* stream);
+int nudf_patch_blend_bwd(const NudfPatchBlend* a, const float* d_patch, float* d_logits, float* d_w, void* stream);
+
+/* loss/patch_metric.py:21-41, 76-84; d_out/d_pred NULL = forward only */
+int nudf_ssim_patch(const float* pred, const float* gt, const float* window, int N, int Npx, float* out,
+                    const float* d_out, float* d_pred, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * ray sampling helpers (models/udf_renderer_blending.py:605-630, 352-357, 164-173, 205)
  * ---------------------------------------------------------------------------------- */
 int nudf_coarse_z(const float* near, const float* far, int nf_stride, const float* t_rand, int N, int S,

@@ -65,6 +65,23 @@ class Upsample(C.Structure):
                 ("z_new", c_fp), ("pts_new", c_fp)]
 
 
+class PixelBlend(C.Structure):
+    _fields_ = [("pts", c_fp), ("logits", c_fp), ("nl", i32), ("proj", c_fp), ("imgs", c_fp),
+                ("P", i32), ("V", i32), ("H", i32), ("W", i32), ("pix", c_fp)]
+
+
+class PixelComposite(C.Structure):
+    _fields_ = [("w", c_fp), ("pix", c_fp), ("pts", c_fp), ("bg_in", c_fp), ("bg_tail", c_fp),
+                ("N", i32), ("S", i32), ("n_out", i32), ("out", c_fp)]
+
+
+class PatchBlend(C.Structure):
+    _fields_ = [("pts", c_fp), ("grad", c_fp), ("rays_d", c_fp), ("uv", c_fp), ("logits", c_fp), ("nl", i32),
+                ("w", c_fp), ("ldw", i32), ("ref_cam", c_fp), ("src_cam", c_fp), ("imgs", c_fp),
+                ("N", i32), ("S", i32), ("V", i32), ("H", i32), ("W", i32), ("hps", i32),
+                ("patch_colors", c_fp), ("patch_mask", c_fp)]
+
+
 EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
            SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11, MULSP=12)
 
@@ -75,6 +92,8 @@ SYMBOLS = [
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
+    "nudf_pixel_blend_fwd", "nudf_pixel_blend_bwd", "nudf_pixel_composite_fwd", "nudf_pixel_composite_bwd",
+    "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -98,6 +117,13 @@ _ARGTYPES = {
     "nudf_sigmoid_head_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P],
     "nudf_weightnorm_pack": [_P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P],
     "nudf_weightnorm_unpack_grad": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "nudf_pixel_blend_fwd": [C.POINTER(PixelBlend), _P],
+    "nudf_pixel_blend_bwd": [C.POINTER(PixelBlend), _P, _P, _P],
+    "nudf_pixel_composite_fwd": [C.POINTER(PixelComposite), _P],
+    "nudf_pixel_composite_bwd": [C.POINTER(PixelComposite), _P, _P, _P, _P, _P, _P],
+    "nudf_patch_blend_fwd": [C.POINTER(PatchBlend), _P],
+    "nudf_patch_blend_bwd": [C.POINTER(PatchBlend), _P, _P, _P, _P],
+    "nudf_ssim_patch": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
 }
 
 _lib = None

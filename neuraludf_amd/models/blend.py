@@ -1,0 +1,147 @@
+"""Image-based blending branch of render_core (models/udf_renderer_blending.py:431-480, 503-524):
+pixel warp + view softmax + composite, and the fused patch warp / blend / composite, on the
+`nudf_pixel_*` / `nudf_patch_*` HIP kernels.  Host code builds the 8 tiny camera matrices (3x3 / 4x4
+inverses and products on [V,4,4] tensors, as the reference does at patch_projector.py:78-97) and wires
+autograd; gradients reach the blending logits and the compositing weights."""
+from __future__ import annotations
+
+import torch
+
+from .._lib import PatchBlend, PixelBlend, PixelComposite, call, ptr
+
+
+def _c(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+class _PixelBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, logits, proj, imgs):
+        pts, logits, proj, imgs = _c(pts), _c(logits), _c(proj), _c(imgs)
+        P = pts.shape[0]
+        V, _, H, W = imgs.shape
+        a = PixelBlend()
+        a.pts, a.logits, a.nl, a.proj, a.imgs = ptr(pts), ptr(logits), logits.shape[1], ptr(proj), ptr(imgs)
+        a.P, a.V, a.H, a.W = P, V, H, W
+        pix = torch.empty(P, 3, device=pts.device)
+        a.pix = ptr(pix)
+        call("nudf_pixel_blend_fwd", a)
+        ctx.save_for_backward(pts, logits, proj, imgs)
+        return pix
+
+    @staticmethod
+    def backward(ctx, d_pix):
+        pts, logits, proj, imgs = ctx.saved_tensors
+        P = pts.shape[0]
+        V, _, H, W = imgs.shape
+        a = PixelBlend()
+        a.pts, a.logits, a.nl, a.proj, a.imgs = ptr(pts), ptr(logits), logits.shape[1], ptr(proj), ptr(imgs)
+        a.P, a.V, a.H, a.W = P, V, H, W
+        d_logits = torch.empty_like(logits)
+        call("nudf_pixel_blend_bwd", a, ptr(d_pix.contiguous()), ptr(d_logits))
+        return None, d_logits, None, None
+
+
+class _PixelCompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, pix, pts, bg_in, bg_tail):
+        w, pix, pts, bg_in, bg_tail = _c(w), _c(pix), _c(pts), _c(bg_in), _c(bg_tail)
+        N, S = pix.shape[0], pix.shape[1]
+        n_out = w.shape[1] - S
+        a = PixelComposite()
+        a.w, a.pix, a.pts, a.bg_in, a.bg_tail = ptr(w), ptr(pix), ptr(pts), ptr(bg_in), ptr(bg_tail)
+        a.N, a.S, a.n_out = N, S, n_out
+        out = torch.empty(N, 3, device=w.device)
+        a.out = ptr(out)
+        call("nudf_pixel_composite_fwd", a)
+        ctx.save_for_backward(w, pix, pts, bg_in, bg_tail)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        w, pix, pts, bg_in, bg_tail = ctx.saved_tensors
+        N, S = pix.shape[0], pix.shape[1]
+        a = PixelComposite()
+        a.w, a.pix, a.pts, a.bg_in, a.bg_tail = ptr(w), ptr(pix), ptr(pts), ptr(bg_in), ptr(bg_tail)
+        a.N, a.S, a.n_out = N, S, w.shape[1] - S
+        d_w = torch.empty_like(w)
+        d_pix = torch.empty_like(pix)
+        d_in = torch.empty_like(bg_in) if bg_in is not None else None
+        d_tail = torch.empty_like(bg_tail) if bg_tail is not None else None
+        call("nudf_pixel_composite_bwd", a, ptr(d_out.contiguous()), ptr(d_w), ptr(d_pix), ptr(d_in), ptr(d_tail))
+        return d_w, d_pix, None, d_in, d_tail
+
+
+def _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps):
+    N, S = pts.shape[0], pts.shape[1]
+    V, _, H, W = imgs.shape
+    a.pts, a.grad, a.rays_d, a.uv = ptr(pts), ptr(grad), ptr(rays_d), ptr(uv)
+    a.logits, a.nl, a.w, a.ldw = ptr(logits), logits.shape[-1], ptr(w), w.shape[1]
+    a.ref_cam, a.src_cam, a.imgs = ptr(ref_cam), ptr(src_cam), ptr(imgs)
+    a.N, a.S, a.V, a.H, a.W, a.hps = N, S, V, H, W, hps
+
+
+class _PatchBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps):
+        pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs = map(_c, (pts, grad, rays_d, uv, logits, w, ref_cam,
+                                                                            src_cam, imgs))
+        N = pts.shape[0]
+        npx = (2 * hps + 1) ** 2
+        a = PatchBlend()
+        _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps)
+        pc = torch.empty(N, npx, 3, device=pts.device)
+        pm = torch.empty(N, device=pts.device)
+        a.patch_colors, a.patch_mask = ptr(pc), ptr(pm)
+        call("nudf_patch_blend_fwd", a)
+        ctx.hps = hps
+        ctx.save_for_backward(pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs)
+        ctx.mark_non_differentiable(pm)      # only ever thresholded by the caller (exp_runner_blending.py:314)
+        return pc, pm
+
+    @staticmethod
+    def backward(ctx, d_pc, _d_pm):
+        pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs = ctx.saved_tensors
+        N, S = pts.shape[0], pts.shape[1]
+        a = PatchBlend()
+        _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, ctx.hps)
+        d_logits = torch.empty_like(logits)
+        d_ws = torch.empty(N, S, device=pts.device)
+        call("nudf_patch_blend_bwd", a, ptr(d_pc.contiguous()), ptr(d_logits), ptr(d_ws))
+        d_w = torch.zeros_like(w)
+        d_w[:, :S] = d_ws
+        return None, None, None, None, d_logits, d_w, None, None, None, None
+
+
+def patch_cameras(ref_intrinsic, src_intrinsics, ref_c2w, src_c2ws):
+    """the per-view constants of PatchProjector.patch_warp (patch_projector.py:78-97)."""
+    K_ref_inv = torch.inverse(ref_intrinsic[:3, :3])
+    K_src = src_intrinsics[:, :3, :3]
+    inv_ref_pose = torch.inverse(ref_c2w)
+    rel = torch.inverse(src_c2ws) @ ref_c2w
+    R_rel, t_rel = rel[:, :3, :3], rel[:, :3, 3:]
+    c2 = (-R_rel.transpose(1, 2) @ t_rel)[..., 0]
+    ref_cam = torch.cat([K_ref_inv.reshape(-1), inv_ref_pose[:3, :3].reshape(-1), inv_ref_pose[:3, 3].reshape(-1),
+                         ref_c2w[:3, 3].reshape(-1)])
+    V = K_src.shape[0]
+    src_cam = torch.cat([K_src.reshape(V, 9), R_rel.reshape(V, 9), t_rel.reshape(V, 3), c2.reshape(V, 3)], dim=1)
+    return ref_cam.float().contiguous(), src_cam.float().contiguous()
+
+
+def blend_and_composite(hps, pts, logits, weights, grad, rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv,
+                        bg_in=None, bg_tail=None):
+    """-> (color_pixel [N,3], patch_colors [N,Npx,3] | None, patch_mask [N] | None)."""
+    N, S = pts.shape[0], pts.shape[1]
+    V, _, H, W = color_maps.shape
+    proj = torch.matmul(intrinsics[:, :3, :3], w2cs[:, :3, :]).reshape(V, 12)      # projector_utils.py:69-70
+    pix = _PixelBlendFn.apply(pts.reshape(-1, 3), logits.reshape(N * S, -1), proj, color_maps)
+    color_pixel = _PixelCompositeFn.apply(weights, pix.reshape(N, S, 3), pts, bg_in, bg_tail)
+    patch_colors = patch_mask = None
+    if rays_uv is not None:
+        # the reference rescales the caller's uv tensor in place from (-1,1) to pixels (patch_projector.py:75-76)
+        rays_uv[:, 0] = (rays_uv[:, 0] + 1) / 2. * (W - 1)
+        rays_uv[:, 1] = (rays_uv[:, 1] + 1) / 2. * (H - 1)
+        ref_cam, src_cam = patch_cameras(intrinsics[0], intrinsics, query_c2w, torch.inverse(w2cs))
+        patch_colors, patch_mask = _PatchBlendFn.apply(pts, grad, rays_d, rays_uv, logits, weights, ref_cam, src_cam,
+                                                       color_maps, hps)
+    return color_pixel, patch_colors, patch_mask

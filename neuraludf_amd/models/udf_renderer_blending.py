@@ -256,17 +256,26 @@ class UDFRendererBlending:
         return z_vals
 
     # ------------------------------------------------------------------------------------
-    def render_core_outside(self, rays_o, rays_d, z_out, sample_dist):
-        """NeRF++ background on the outside samples (:161-195): -> (sigma [N,n_out], rgb [N,n_out,3])."""
+    def render_core_outside(self, rays_o, rays_d, z_out, sample_dist, z_in=None):
+        """NeRF++ background (:161-195): -> (sigma [N,n_out], rgb [N,n_out,3], rgb_inside [N,S,3] | None).
+        Only the outside samples are evaluated unless `z_in` is given (pixel blending mixes the background
+        colour into the inside samples too, :503-506); the outside samples always sort after the inside
+        ones (z_out >= far + 1/n_samples), so cat == sort."""
         N, n_out = z_out.shape
-        pts4 = torch.empty(N * n_out, 4, device=z_out.device)
-        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z_out), ptr(sample_dist), N, n_out, 2, ptr(pts4))
-        sigma, rgb = self.nerf.evaluate(pts4, rays_d, n_out)
-        return sigma.reshape(N, n_out), rgb.reshape(N, n_out, 3)
+        zf = z_out if z_in is None else torch.cat([z_in, z_out], dim=-1).contiguous()
+        M = zf.shape[1]
+        pts4 = torch.empty(N * M, 4, device=z_out.device)
+        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(zf), ptr(sample_dist), N, M, 2, ptr(pts4))
+        sigma, rgb = self.nerf.evaluate(pts4, rays_d, M)
+        sigma, rgb = sigma.reshape(N, M), rgb.reshape(N, M, 3)
+        if z_in is None:
+            return sigma, rgb, None
+        S = z_in.shape[1]
+        return sigma[:, S:].contiguous(), rgb[:, S:].contiguous(), rgb[:, :S].contiguous()
 
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, cos_anneal_ratio=None, background_rgb=None,
                     bg_z=None, bg_sigma=None, bg_color=None, flip_saturation=0.0, color_maps=None, w2cs=None,
-                    intrinsics=None, query_c2w=None, img_index=None, rays_uv=None, s_nominal=None):
+                    intrinsics=None, query_c2w=None, img_index=None, rays_uv=None, s_nominal=None, bg_color_in=None):
         """(:327-584) given sorted samples."""
         N, S = z_vals.shape
         dev = z_vals.device
@@ -296,9 +305,11 @@ class UDFRendererBlending:
         color_pixel = patch_colors = patch_mask = None
         if color_maps is not None:
             from . import blend
+            if img_index is not None:
+                raise NotImplementedError("img_index is None on every call site of the reference")
             color_pixel, patch_colors, patch_mask = blend.blend_and_composite(
-                self, pts.reshape(N, S, 3), logits.reshape(N, S, -1), weights, diag.get("inside"), grad.reshape(N, S, 3),
-                rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv, bg_color_all=None)
+                self.h_patch_size, pts.reshape(N, S, 3), logits.reshape(N, S, -1), weights, grad.reshape(N, S, 3).detach(),
+                rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv, bg_in=bg_color_in, bg_tail=bg_color)
 
         g3 = grad.reshape(N, S, 3)
         ret = {
@@ -334,9 +345,7 @@ class UDFRendererBlending:
             far = torch.tensor([float(far)], device=dev).view(1, 1)
         near = near.detach().float().contiguous()
         far = far.detach().float().contiguous()
-        nf_stride = 1 if near.shape[0] == N and N > 1 else (1 if near.numel() == N else 0)
-        if near.numel() == 1:
-            nf_stride = 0
+        nf_stride = 0 if near.numel() == 1 else 1
 
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         t_rand = None
@@ -368,19 +377,20 @@ class UDFRendererBlending:
                 z_vals = self.importance_sample_mix(rays_o, rays_d, z_vals, sample_dist)
             n_samples = self.n_samples + self.n_importance
 
-        bg_sigma = bg_color = None
+        bg_sigma = bg_color = bg_color_in = None
         if self.n_outside > 0:
-            bg_sigma, bg_color = self.render_core_outside(rays_o, rays_d, z_out, sample_dist)
+            bg_sigma, bg_color, bg_color_in = self.render_core_outside(
+                rays_o, rays_d, z_out, sample_dist, z_vals if color_maps is not None else None)
 
         bgrgb = None
         if background_rgb is not None:
             bgrgb = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, cos_anneal_ratio, bgrgb, z_out, bg_sigma,
                                bg_color, flip_saturation, color_maps, w2cs, intrinsics, query_c2w, img_index, rays_uv,
-                               s_nominal=n_samples)
+                               s_nominal=n_samples, bg_color_in=bg_color_in)
 
         sparse_random_error = 0.0
-        if perturb > 0 or self.compute_sparse_random:
+        if True:
             pts_random = torch.rand([1024, 3]).float().to(dev) * 2 - 1          # keeps the RNG stream aligned (:683)
             if self.compute_sparse_random:
                 with torch.no_grad():

@@ -372,7 +372,7 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
     bg_sigma = bg_color = z_out_d = None
     if cfg.n_outside:
         z_out_d = D(z_out_ref.contiguous())
-        bg_sigma, bg_color = rend.render_core_outside(D(r["rays_o"]), D(r["rays_d"]), z_out_d, sdd)
+        bg_sigma, bg_color, _ = rend.render_core_outside(D(r["rays_o"]), D(r["rays_d"]), z_out_d, sdd)
     out2 = rend.render_core(D(r["rays_o"]), D(r["rays_d"]), D(z_ref), sdd, 0.8, None, z_out_d, bg_sigma, bg_color,
                             0.9, s_nominal=cfg.n_samples + cfg.n_importance)
     for k in ["color", "color_base", "depth", "weights", "udf", "gradients", "normals", "vis_prob", "alpha",
