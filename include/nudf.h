@@ -237,6 +237,33 @@ int nudf_weightnorm_pack(const float* v, const float* g, int out, int in, const 
 int nudf_weightnorm_unpack_grad(const float* dW, int ldw, const float* v, const float* g, const float* inv_norm,
                                 int out, int in, const int* perm, float* dv, float* dg, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-tensor Adam (one launch for all parameters).  Replaces the foreach kernels of
+ * torch.optim.Adam.step() as the runner uses it (exp_runner_blending.py:136-139, :373-375);
+ * same arithmetic, same state (exp_avg, exp_avg_sq, step).  The table is passed by value.
+ * ---------------------------------------------------------------------------------- */
+#define NUDF_ADAM_MAX_TENSORS 64
+#define NUDF_ADAM_MAX_GROUPS 4
+typedef struct NudfAdamTensor {
+  float* p; const float* g; float* m; float* v;  /* param, grad, exp_avg, exp_avg_sq (device) */
+  int32_t n;                                     /* elements                                   */
+  int32_t group;
+  float neg_step_size;                           /* -lr / (1 - beta1^t), t = this tensor's step */
+  float bc2_sqrt;                                /* sqrt(1 - beta2^t)                          */
+} NudfAdamTensor;
+typedef struct NudfAdamGroup {
+  float one_minus_beta1, beta2, one_minus_beta2, eps;
+} NudfAdamGroup;
+typedef struct NudfAdam {
+  int32_t n_tensors; int32_t pad_;
+  NudfAdamTensor t[NUDF_ADAM_MAX_TENSORS];
+  int32_t block_start[NUDF_ADAM_MAX_TENSORS + 1]; /* prefix sums of ceil(n / nudf_adam_chunk())  */
+  int32_t pad2_;
+  NudfAdamGroup group[NUDF_ADAM_MAX_GROUPS];
+} NudfAdam;
+int nudf_adam_step(const NudfAdam* args, void* stream);
+int nudf_adam_chunk(void);                         /* elements one block updates                  */
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,23 @@ class PatchBlend(C.Structure):
                 ("patch_colors", c_fp), ("patch_mask", c_fp)]
 
 
+ADAM_MAX_TENSORS = 64
+ADAM_MAX_GROUPS = 4
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", c_fp), ("g", c_fp), ("m", c_fp), ("v", c_fp), ("n", i32), ("group", i32), ("neg_step_size", f32), ("bc2_sqrt", f32)]
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("one_minus_beta1", f32), ("beta2", f32), ("one_minus_beta2", f32), ("eps", f32)]
+
+
+class Adam(C.Structure):
+    _fields_ = [("n_tensors", i32), ("pad_", i32), ("t", AdamTensor * ADAM_MAX_TENSORS),
+                ("block_start", i32 * (ADAM_MAX_TENSORS + 1)), ("pad2_", i32), ("group", AdamGroup * ADAM_MAX_GROUPS)]
+
+
 EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
            SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11, MULSP=12)
 
@@ -94,6 +111,7 @@ SYMBOLS = [
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
     "nudf_pixel_blend_fwd", "nudf_pixel_blend_bwd", "nudf_pixel_composite_fwd", "nudf_pixel_composite_bwd",
     "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch",
+    "nudf_adam_step", "nudf_adam_chunk",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -124,6 +142,7 @@ _ARGTYPES = {
     "nudf_patch_blend_fwd": [C.POINTER(PatchBlend), _P],
     "nudf_patch_blend_bwd": [C.POINTER(PatchBlend), _P, _P, _P, _P],
     "nudf_ssim_patch": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "nudf_adam_step": [C.POINTER(Adam), _P],
 }
 
 _lib = None
@@ -150,6 +169,7 @@ def lib():
             raise NudfError(f"cannot load {LIB_PATH}: {e}") from e
         _lib.nudf_last_error.restype = C.c_char_p
         _lib.nudf_version.restype = C.c_int
+        _lib.nudf_adam_chunk.restype = C.c_int
         _bind(_lib)
     return _lib
 

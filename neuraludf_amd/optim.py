@@ -1,0 +1,97 @@
+"""Fused Adam for the hot path's five networks: one `nudf_adam_step` launch per <= 64 tensors instead
+of the ~12 foreach kernels (x 3 parameter groups) of torch.optim.Adam.
+
+Same constructor surface as `torch.optim.Adam(param_groups, lr=...)` as the reference runner uses it
+(exp_runner_blending.py:136-139: three groups, per-group `lr`; :167-191 rewrites `g['lr']` every
+iteration) and the same per-parameter state (`step`, `exp_avg`, `exp_avg_sq`), so `state_dict()` /
+`load_state_dict()` interchange with torch.optim.Adam checkpoints (:484-498).  Not supported (never
+used by the reference): amsgrad, weight_decay, maximize."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from ._lib import ADAM_MAX_GROUPS, ADAM_MAX_TENSORS, Adam, call, lib, NudfError
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("FusedAdam: weight_decay / amsgrad are not used by the reference runner")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
+        super().__init__(params, defaults)
+        if len(self.param_groups) > ADAM_MAX_GROUPS:
+            raise NudfError("FusedAdam supports at most %d parameter groups" % ADAM_MAX_GROUPS)
+        self._chunk = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._chunk is None:
+            self._chunk = int(lib().nudf_adam_chunk())
+        chunk = self._chunk
+        a = Adam()
+        keep = []           # keep contiguous grad copies alive until the launch is enqueued
+        nt = 0
+        blocks = 0
+
+        def flush():
+            nonlocal a, nt, blocks
+            if nt:
+                a.n_tensors = nt
+                a.block_start[nt] = blocks
+                call("nudf_adam_step", a)
+            a = Adam()
+            self._fill_groups(a)
+            nt = 0
+            blocks = 0
+
+        self._fill_groups(a)
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise NudfError("FusedAdam needs device parameters (no CPU fallback)")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                g = p.grad
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    keep.append(g)
+                if not p.is_contiguous():
+                    raise NudfError("FusedAdam needs contiguous parameters")
+                if nt == ADAM_MAX_TENSORS:
+                    flush()
+                t = a.t[nt]
+                t.p, t.g, t.m, t.v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                t.n, t.group = p.numel(), gi
+                step = float(st["step"]) + 1.0
+                b1, b2 = group["betas"]
+                t.neg_step_size = -group["lr"] / (1.0 - b1 ** step)
+                t.bc2_sqrt = math.sqrt(1.0 - b2 ** step)
+                a.block_start[nt] = blocks
+                blocks += (p.numel() + chunk - 1) // chunk
+                nt += 1
+        flush()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    self.state[p]["step"] += 1
+        return loss
+
+    def _fill_groups(self, a):
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            g = a.group[gi]
+            g.one_minus_beta1 = 1.0 - b1
+            g.beta2 = b2
+            g.one_minus_beta2 = 1.0 - b2
+            g.eps = group["eps"]

@@ -29,7 +29,8 @@ def test_ctypes_structs_match_header_field_counts():
     for cname, st in [("NudfGemmNN", _lib.GemmNN), ("NudfGemmTN", _lib.GemmTN), ("NudfComposite", _lib.Composite),
                       ("NudfCompositeGrad", _lib.CompositeGrad), ("NudfUpsample", _lib.Upsample),
                       ("NudfPixelBlend", _lib.PixelBlend), ("NudfPixelComposite", _lib.PixelComposite),
-                      ("NudfPatchBlend", _lib.PatchBlend)]:
+                      ("NudfPatchBlend", _lib.PatchBlend), ("NudfAdamTensor", _lib.AdamTensor),
+                      ("NudfAdamGroup", _lib.AdamGroup)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

@@ -1,0 +1,44 @@
+"""`FusedAdam` (one nudf_adam_step launch) against torch.optim.Adam on the same parameters / gradients,
+with the runner's three parameter groups and a per-iteration learning-rate rewrite
+(exp_runner_blending.py:136-139, :167-191), including a parameter that starts frozen."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_adam_matches_torch_adam():
+    from neuraludf_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    shapes = [(256, 39), (256, 1), (256,), (1,), (217, 256), (3, 128), (5000,), (1025,), (1024,), (7, 3, 5)]
+    ref_p = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    new_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+
+    def groups(ps):
+        return [{"params": ps[:3], "lr": 1e-4}, {"params": ps[3:7]}, {"params": ps[7:]}]
+
+    ref = torch.optim.Adam(groups(ref_p), lr=5e-4)
+    new = FusedAdam(groups(new_p), lr=5e-4)
+    for it in range(12):
+        lr = 5e-4 * (1.0 - it / 20.0)
+        for o in (ref, new):
+            for gi, grp in enumerate(o.param_groups):
+                grp["lr"] = lr * (0.2 if gi == 0 else 1.0)
+        for i, (a, b) in enumerate(zip(ref_p, new_p)):
+            if i == 3 and it < 4:          # frozen at first (like the variance network, :353-359)
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g).to(dev) * (10.0 ** ((i % 5) - 3))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step()
+        new.step()
+    torch.cuda.synchronize()
+    for a, b in zip(ref_p, new_p):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), a.shape
+    # state interchange with torch.optim.Adam checkpoints
+    sd = new.state_dict()
+    ref2 = torch.optim.Adam(groups([p.detach().clone().requires_grad_(True) for p in new_p]), lr=5e-4)
+    ref2.load_state_dict(sd)
+    assert int(ref2.state[ref2.param_groups[0]["params"][0]]["step"]) == 12
+    assert int(ref2.state[ref2.param_groups[1]["params"][0]]["step"]) == 8
