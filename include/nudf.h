@@ -264,6 +264,70 @@ typedef struct NudfAdam {
 int nudf_adam_step(const NudfAdam* args, void* stream);
 int nudf_adam_chunk(void);                         /* elements one block updates                  */
 
+/* ------------------------------------------------------------------------------------
+ * Fused MLP layer chains: a tile of points stays resident in LDS across all layers of a sweep
+ * (csrc/mlp_chain.hip).  Replaces, for UDFNetwork (models/fields.py:192-231), the same chains of
+ * F.linear + weight_norm + Softplus and their autograd (double) backward as nudf_gemm_nn, with one
+ * launch per sweep.  Weights are passed in MFMA-B fragment order (nudf_pack_frag).
+ * ROW PADDING: the kernel stores whole 64-point tiles, so every buffer it writes (C1, C2, G0) or reads in
+ * an epilogue (X1, X2, r1_row) must hold roundup(P, 64) rows; rows >= P are scratch.  x, v, A0 of
+ * INIT_LOAD and seed_sign are read with clamped row indices and need only P rows.  P * ld < 2^31.
+ * ---------------------------------------------------------------------------------- */
+enum {
+  NUDF_CH_NONE = 0,      /* out = (acc + bias) * scale                                            */
+  NUDF_CH_SOFTPLUS = 1,  /* out = softplus100(acc + bias) * scale                                 */
+  NUDF_CH_MULSP = 2,     /* out = acc * softplus'(X1) * scale ; cols >= iparam > 0: C2[col-iparam] = acc*scale */
+  NUDF_CH_TANGENT = 3,   /* out = acc * s * scale ; C2 = acc * X2 * 100 (1 - s),  s = softplus'(X1) */
+  NUDF_CH_BWD = 4,       /* out = acc * scale * softplus'(X1) + X2                                */
+  NUDF_CH_UDFHEAD = 5    /* col 0: C2[row] = |acc + bias| * scale, C1[row] = sign                 */
+};
+enum {
+  NUDF_CH_INIT_LOAD = 0,   /* activation tile = A0[rows, 0:k0]                                    */
+  NUDF_CH_INIT_POSENC = 1, /* activation tile = PE(x) (or its JVP with tangent v), zero-padded to k0 */
+  NUDF_CH_INIT_SEED = 2    /* tile[r,c] = seed_sign[r] * seed_wrow[c] * seed_scale * softplus'(A0[r,c]) */
+};
+#define NUDF_CH_MAX_STEPS 12
+typedef struct NudfChainStep {
+  const float* Bp;                 /* packed weights (nudf_pack_frag) of the [K, N] operand          */
+  const float* bias;               /* [N] or NULL                                                    */
+  const float* X1; const float* X2;/* epilogue operands [P, ld] stored by an earlier sweep, or NULL   */
+  float* C1; float* C2;            /* HBM copies of the outputs (NULL = keep in LDS only)            */
+  const float* r1_row;             /* optional rank-1 term: acc += r1_row[row] * r1_col[col]         */
+  const float* r1_col;
+  int32_t K, N;                    /* K % 16 == 0, K <= 256, N <= 256                                */
+  int32_t epi;                     /* NUDF_CH_*                                                      */
+  int32_t iparam;
+  int32_t ldx1, ldx2, ldc1, ldc2;
+  int32_t ldr1;                    /* element stride of r1_row                                       */
+  int32_t act_write;               /* 1: the outputs become the next step's activation tile          */
+  int32_t act_col0;                /* ... at tile columns [act_col0, act_col0 + N)                   */
+  int32_t pe_tail_col;             /* >= 0: afterwards write PE(x)*pe_tail_scale at these tile columns (and C1) */
+  float pe_tail_scale;
+  float scale, xscale;
+} NudfChainStep;
+typedef struct NudfChain {
+  int32_t P, n_steps;
+  int32_t init;                    /* NUDF_CH_INIT_*                                                 */
+  int32_t k0;                      /* initial tile width (multiple of 4, <= 256)                     */
+  int32_t tile_rows;               /* 0 = choose, 32 or 64 points per workgroup                      */
+  int32_t lda0, ldg0;
+  int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */
+  float pe_in_scale;
+  float seed_scale, seed_xscale;
+  const float* A0;                 /* INIT_LOAD source / INIT_SEED stored activation                 */
+  float* G0;                       /* optional HBM copy of the initial tile [P, ldg0]                */
+  const float* x;                  /* [P,3] points (positional encoding), or NULL                    */
+  const float* v;                  /* [P,3] tangent (JVP), or NULL                                   */
+  const float* seed_sign;          /* [P]                                                            */
+  const float* seed_wrow;          /* [k0]                                                           */
+  unsigned long long* dbg;         /* NULL, or [blocks*4 waves][32] timeline: hw_id, t0, per step (t_mma, t_epi) */
+  NudfChainStep step[NUDF_CH_MAX_STEPS];
+} NudfChain;
+int nudf_mlp_chain(const NudfChain* args, void* stream);
+/* out[((g*NT + T)*64 + lane)*4 + j] = B[8g + 4(lane>>5) + j][32T + (lane&31)], zero outside K x N;
+ * out holds roundup(K,16)/8 * roundup(N,32)/32 * 256 floats */
+int nudf_pack_frag(const float* B, int ldb, int K, int N, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

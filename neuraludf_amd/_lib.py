@@ -99,6 +99,25 @@ class Adam(C.Structure):
                 ("block_start", i32 * (ADAM_MAX_TENSORS + 1)), ("pad2_", i32), ("group", AdamGroup * ADAM_MAX_GROUPS)]
 
 
+CH_MAX_STEPS = 12
+CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5)
+CH_INIT = dict(LOAD=0, POSENC=1, SEED=2)
+
+
+class ChainStep(C.Structure):
+    _fields_ = [("Bp", c_fp), ("bias", c_fp), ("X1", c_fp), ("X2", c_fp), ("C1", c_fp), ("C2", c_fp),
+                ("r1_row", c_fp), ("r1_col", c_fp), ("K", i32), ("N", i32), ("epi", i32), ("iparam", i32),
+                ("ldx1", i32), ("ldx2", i32), ("ldc1", i32), ("ldc2", i32), ("ldr1", i32), ("act_write", i32),
+                ("act_col0", i32), ("pe_tail_col", i32), ("pe_tail_scale", f32), ("scale", f32), ("xscale", f32)]
+
+
+class Chain(C.Structure):
+    _fields_ = [("P", i32), ("n_steps", i32), ("init", i32), ("k0", i32), ("tile_rows", i32), ("lda0", i32),
+                ("ldg0", i32), ("pe_L", i32), ("pe_jvp", i32), ("pe_in_scale", f32), ("seed_scale", f32),
+                ("seed_xscale", f32), ("A0", c_fp), ("G0", c_fp), ("x", c_fp), ("v", c_fp), ("seed_sign", c_fp),
+                ("seed_wrow", c_fp), ("dbg", c_fp), ("step", ChainStep * CH_MAX_STEPS)]
+
+
 EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
            SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11, MULSP=12)
 
@@ -111,7 +130,7 @@ SYMBOLS = [
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
     "nudf_pixel_blend_fwd", "nudf_pixel_blend_bwd", "nudf_pixel_composite_fwd", "nudf_pixel_composite_bwd",
     "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch",
-    "nudf_adam_step", "nudf_adam_chunk",
+    "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -143,6 +162,8 @@ _ARGTYPES = {
     "nudf_patch_blend_bwd": [C.POINTER(PatchBlend), _P, _P, _P, _P],
     "nudf_ssim_patch": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "nudf_adam_step": [C.POINTER(Adam), _P],
+    "nudf_mlp_chain": [C.POINTER(Chain), _P],
+    "nudf_pack_frag": [_P, _I, _I, _I, _P, _P],
 }
 
 _lib = None

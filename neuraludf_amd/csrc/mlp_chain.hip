@@ -1,0 +1,428 @@
+// Fused MLP layer chains for the UDF network (gfx950): one workgroup owns a tile of TM points and keeps
+// the [TM x <=256] activation tile RESIDENT IN LDS across all layers of a sweep.  Per layer the tile is
+// the MFMA A operand (ds_read_b128, bank-conflict-free at row stride 260), the weights stream from L2 in
+// MFMA-B fragment order straight into registers (one coalesced global_load_dwordx4 per lane per 32-column
+// tile per 8 k), and the epilogue writes the next layer's activations back into the same LDS tile -- HBM is
+// touched only for what a later backward sweep needs (stored activations) and for epilogue operands that
+// were stored by an earlier sweep.  v_mfma_f32_32x32x2_f32: exact fp32.
+//
+// Four sweeps of models/fields.py:192-231 (UDFNetwork.forward / .gradient and their autograd backward,
+// including the second-order part the reference gets from autograd.grad(create_graph=True)):
+//   forward   X[l+1] = softplus100(X[l] W_l^T + b_l) (* 1/sqrt2 before the skip layer), abs head
+//   gradient  DA[l-1] = (DA[l] W_l) * softplus'(.)          (reverse sweep for d udf / d x)
+//   tangent   R[l+1] = (R[l] W_l^T) * softplus'(.), EX[l] = (R[l] W_l^T) * DA[l] * softplus''/softplus'
+//   adjoint   ABAR[l-1] = (ABAR[l] W_l) * softplus'(.) + EX[l-1]
+// described to the kernel as a table of steps (NudfChain in include/nudf.h).
+//
+// The K index inside each group of 8 is permuted (lane half h contracts k = 8g + 4h + j in MFMA j) so that
+// one 16-byte LDS read / one 16-byte global read feeds 4 consecutive MFMAs; A and B use the same permutation,
+// so only the fp32 summation order differs from a k-ordered GEMM.
+#include "nudf_common.h"
+#include "../../include/nudf.h"
+
+#define CH_LD 260          // activation row stride in floats: m*260 mod 64 = 4m -> conflict-free ds_read_b128
+#define CH_THREADS 256
+
+__device__ __forceinline__ f32x16 ch_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// softplus'(a) = s and 1 - s from the STORED activation h = softplus100(a) / xscale (see gemm_f32_mfma.hip)
+__device__ __forceinline__ void ch_sp_derivs(float hstored, float xscale, float& s, float& om) {
+  const float x = 100.0f * xscale * hstored;
+  if (x > 20.0f) {
+    s = 1.0f;
+    om = 0.0f;
+  } else {
+    const float e = __expf(-x);
+    om = e;
+    s = (x < 0.01f) ? x * (1.0f - x * (0.5f - x * 0.16666667f)) : 1.0f - e;
+  }
+}
+
+// positional-encoding element c of point x (value or JVP with tangent v); same arithmetic as posenc_kernel
+__device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, int L, float in_scale, int jvp) {
+  const int blk = c / 3, j = c - blk * 3;
+  const float xv = x3[j] * in_scale;
+  if (blk == 0) return jvp ? v3[j] * in_scale : xv;
+  const int k = (blk - 1) >> 1;
+  const float f = (float)(1 << k);
+  const float a = xv * f;
+  const bool is_sin = ((blk - 1) & 1) == 0;
+  if (!jvp) return is_sin ? sinf(a) : cosf(a);
+  return (is_sin ? cosf(a) : -sinf(a)) * f * v3[j] * in_scale;
+}
+
+template <int TM>
+struct ChainSmem {
+  float act[TM * CH_LD];
+  float xs[TM * 3];
+  float vs[TM * 3];
+};
+
+// write PE(x) (or its JVP) * scale into activation columns [col0, col0 + E) (+ optional global mirror)
+template <int TM>
+__device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& p, int m0, int col0, float scale,
+                                            float* gdst, int ldg, int gcol0, int zero_to) {
+  const int E = 3 * (2 * p.pe_L + 1);
+  for (int e = threadIdx.x; e < TM * E; e += CH_THREADS) {
+    const int r = e / E, c = e - r * E;
+    const float val = ch_pe(sm.xs + r * 3, sm.vs + r * 3, c, p.pe_L, p.pe_in_scale, p.pe_jvp) * scale;
+    sm.act[r * CH_LD + col0 + c] = val;
+    if (gdst && (m0 + r) < p.P) gdst[(size_t)(m0 + r) * ldg + gcol0 + c] = val;
+  }
+  // zero padding columns [col0 + E, zero_to) so that the K padding of the next GEMM multiplies finite zeros
+  const int npad = zero_to - (col0 + E);
+  if (npad > 0)
+    for (int e = threadIdx.x; e < TM * npad; e += CH_THREADS) {
+      const int r = e / npad, c = e - r * npad;
+      sm.act[r * CH_LD + col0 + E + c] = 0.0f;
+    }
+}
+
+// K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
+// the body, so the compiler's s_waitcnt counters let the NEXT group's LDS / L2 reads stay in flight under the
+// current group's 4*NRT*NCT MFMAs.  G (groups of 8 k) is even; the last prefetch re-reads the last group.
+template <int NRT, int NCT>
+__device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32x4* __restrict__ bptr, size_t bstride,
+                                       int G, f32x16 (&acc)[2][2]) {
+  f32x4 a0[NRT], a1[NRT], b0[NCT], b1[NCT];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD);
+#pragma unroll
+  for (int j = 0; j < NCT; ++j) b0[j] = bptr[j * 64];
+#pragma unroll 1
+  for (int g = 0; g < G; g += 2) {
+    {
+      const f32x4* bq = bptr + (size_t)(g + 1) * bstride;
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) b1[j] = bq[j * 64];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) a1[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + (g + 1) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMA block (the scheduler would sink it)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(a0[i][jj], b0[j][jj], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int gn = (g + 2 < G) ? g + 2 : g;
+      const f32x4* bq = bptr + (size_t)gn * bstride;
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) b0[j] = bq[j * 64];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + gn * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(a1[i][jj], b1[j][jj], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
+// One 32x32 accumulator tile of a step's epilogue.  Branch-free per element: uniform options are tested once
+// around whole 16-element loops, the column predicate (N may end inside the tile) is one exec region, rows
+// need no predicate because every output / operand buffer is row-padded to the tile size (see nudf.h).
+// Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
+#define CH_KOFF(r) (((r) & 3) + 8 * ((r) >> 2))
+template <int EPI>
+__device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
+                                                 int h, int ln, f32x16 a) {
+  const int col = ctile * 32 + ln;
+  const bool col_ok = col < st.N;
+  const unsigned colc = col_ok ? col : 0;
+  const int r0 = rtile * 32 + 4 * h;
+  const unsigned grow0 = (unsigned)(m0 + r0);
+  float v[16], out[16];
+  {
+    const float bias = st.bias ? st.bias[colc] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = a[r] + bias;
+  }
+  if (st.r1_row) {  // rank-1 term (column 0 of the abs head in the adjoint sweep)
+    const float r1c = st.r1_col[colc];
+    const unsigned vo = grow0 * (unsigned)st.ldr1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo] * r1c;
+  }
+  float x1[16], x2[16];
+  if (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD) {
+    const unsigned vo = grow0 * (unsigned)st.ldx1 + colc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
+  }
+  if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD) {
+    if (st.X2) {
+      const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
+    }
+  }
+  float out2[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (EPI == NUDF_CH_SOFTPLUS) {
+      const float t = 100.0f * v[r];
+      const float z = __expf(t);
+      const float lg = __logf(1.0f + z) * 0.01f;
+      const float ser = (z - 0.5f * z * z) * 0.01f;          // log1p series for tiny z
+      out[r] = ((t > 20.0f) ? v[r] : ((z < 1e-4f) ? ser : lg)) * st.scale;
+    } else if (EPI == NUDF_CH_NONE) {
+      out[r] = v[r] * st.scale;
+    } else if (EPI == NUDF_CH_UDFHEAD) {
+      out[r] = fabsf(v[r]) * st.scale;
+      out2[r] = (v[r] > 0.0f) ? 1.0f : ((v[r] < 0.0f) ? -1.0f : 0.0f);
+    } else {
+      // softplus'(a) = s and 1 - s recovered from the stored activation (see ch_sp_derivs)
+      const float x = 100.0f * st.xscale * x1[r];
+      const float e = __expf(-x);
+      const float poly = x * (1.0f - x * (0.5f - x * 0.16666667f));
+      const float sg = (x > 20.0f) ? 1.0f : ((x < 0.01f) ? poly : 1.0f - e);
+      const float om = (x > 20.0f) ? 0.0f : e;
+      if (EPI == NUDF_CH_MULSP) {
+        const bool hid = st.iparam <= 0 || col < st.iparam;
+        out[r] = hid ? v[r] * sg * st.scale : 0.0f;
+        out2[r] = v[r] * st.scale;                            // embedding branch of the skip split
+      } else if (EPI == NUDF_CH_TANGENT) {
+        out[r] = v[r] * sg * st.scale;
+        out2[r] = v[r] * x2[r] * 100.0f * om;
+      } else {  // NUDF_CH_BWD
+        out[r] = v[r] * st.scale * sg + x2[r];
+      }
+    }
+  }
+  // ---- stores ----
+  if (EPI == NUDF_CH_UDFHEAD) {
+    if (col == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (st.C2) st.C2[grow0 + CH_KOFF(r)] = out[r];
+        if (st.C1) st.C1[grow0 + CH_KOFF(r)] = out2[r];
+      }
+    }
+    return;
+  }
+  if (col_ok) {
+    if (EPI == NUDF_CH_MULSP && st.iparam > 0 && col >= st.iparam) {
+      if (st.C2) {
+        const unsigned vo = grow0 * (unsigned)st.ldc2 + (col - st.iparam);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+      }
+    } else if (st.C1) {
+      const unsigned vo = grow0 * (unsigned)st.ldc1 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+    }
+    if (EPI == NUDF_CH_TANGENT) {
+      const unsigned vo = grow0 * (unsigned)st.ldc2 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+    }
+  }
+  if (st.act_write) {
+    float* ap = act + r0 * CH_LD + st.act_col0 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
+  }
+}
+
+// epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
+template <int EPI>
+__device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
+                                            int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2]) {
+  const int ntiles = nrt * nct;
+#pragma unroll 1
+  for (int t = 0; t < ntiles; ++t) {
+    const int i = (nct == 2) ? (t >> 1) : t, j = (nct == 2) ? (t & 1) : 0;
+    f32x16 a;
+    switch (2 * i + j) {   // one copy of the tile body in the code; the accumulators are selected by moves
+      case 0: a = acc[0][0]; break;
+      case 1: a = acc[0][1]; break;
+      case 2: a = acc[1][0]; break;
+      default: a = acc[1][1]; break;
+    }
+    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a);
+  }
+}
+
+template <int TM>
+__global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kernel(NudfChain p) {
+  constexpr int WMT = TM / 32;  // row tiles per wave in the wide layout
+  __shared__ __attribute__((aligned(16))) ChainSmem<TM> sm;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5, ln = lane & 31;
+  const int m0 = blockIdx.x * TM;
+
+  // ---- tile initialisation ---------------------------------------------------------------------
+  if (p.x) {
+    for (int e = tid; e < TM * 3; e += CH_THREADS) {
+      int r = m0 + e / 3;
+      if (r > p.P - 1) r = p.P - 1;
+      sm.xs[e] = p.x[(size_t)r * 3 + (e % 3)];
+      sm.vs[e] = p.v ? p.v[(size_t)r * 3 + (e % 3)] : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (p.init == NUDF_CH_INIT_LOAD) {
+    const int k4 = p.k0 >> 2;
+    for (int e = tid; e < TM * k4; e += CH_THREADS) {
+      const int r = e / k4, c4 = e - r * k4;
+      int gr = m0 + r;
+      if (gr > p.P - 1) gr = p.P - 1;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(p.A0 + (size_t)gr * p.lda0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(sm.act + r * CH_LD + c4 * 4) = val;
+    }
+  } else if (p.init == NUDF_CH_INIT_POSENC) {
+    ch_write_pe<TM>(sm, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0);
+  } else if (p.init == NUDF_CH_INIT_SEED) {
+    // da[r, c] = sign[r] * w_row0[c] * inv_scale * softplus'(.)   (reverse-sweep seed, fields.py:219-231)
+    const int C = p.k0;
+    for (int e = tid; e < TM * C; e += CH_THREADS) {
+      const int r = e / C, c = e - r * C;
+      int gr = m0 + r;
+      const bool live = gr < p.P;
+      if (!live) gr = p.P - 1;
+      float s, om;
+      ch_sp_derivs(p.A0[(size_t)gr * p.lda0 + c], p.seed_xscale, s, om);
+      const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
+      sm.act[r * CH_LD + c] = val;
+      if (p.G0 && live) p.G0[(size_t)gr * p.ldg0 + c] = val;
+    }
+  }
+  __syncthreads();
+
+  // Workgroups that share a CU start in lock-step and would then always be in the same phase (K loop: both
+  // want the MFMA pipe; epilogue: both want the VALU).  Delay the waves in odd hardware wave slots once, so
+  // that one workgroup's epilogues run under the other's MFMA phases.  Speed only.
+  if (gridDim.x > 256) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
+    const unsigned k = (TM == 64) ? (slot & 1u) * 2u : (slot % 3u);
+    for (unsigned d = 0; d < k; ++d) __builtin_amdgcn_s_sleep(127);
+  }
+
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 32 : nullptr;
+  if (dbg && lane == 0) {
+    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    dbg[1] = __builtin_amdgcn_s_memtime();
+  }
+
+  // ---- the layer chain ---------------------------------------------------------------------------
+  for (int si = 0; si < p.n_steps; ++si) {
+    const NudfChainStep& st = p.step[si];
+    const int G = st.K >> 3;                 // k groups of 8
+    const int NT = (st.N + 31) >> 5;         // 32-column tiles
+    const f32x4* __restrict__ Bp = reinterpret_cast<const f32x4*>(st.Bp);
+
+    // tile ownership of this wave: nrt x nct tiles of 32x32 starting at (rt0, ct0)
+    int rt0, ct0, nrt, nct;
+    if (WMT == 2) {
+      if (NT <= 2) { rt0 = wave >> 1; ct0 = wave & 1; nrt = 1; nct = (ct0 < NT) ? 1 : 0; }
+      else if (NT <= 4) { rt0 = wave >> 1; ct0 = 2 * (wave & 1); nrt = 1; nct = min(2, max(0, NT - ct0)); }
+      else { rt0 = 0; ct0 = 2 * wave; nrt = 2; nct = min(2, max(0, NT - ct0)); }
+    } else {
+      rt0 = 0; nrt = 1;
+      if (NT <= 4) { ct0 = wave; nct = (ct0 < NT) ? 1 : 0; }
+      else { ct0 = 2 * wave; nct = min(2, max(0, NT - ct0)); }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (nct > 0) {
+      const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
+      const f32x4* bptr = Bp + (size_t)ct0 * 64 + lane;
+      const size_t bstride = (size_t)NT * 64;  // float4 per k group
+      if (nrt == 2 && nct == 2) ch_mma<2, 2>(arow, bptr, bstride, G, acc);
+      else if (nrt == 2) ch_mma<2, 1>(arow, bptr, bstride, G, acc);
+      else if (nct == 2) ch_mma<1, 2>(arow, bptr, bstride, G, acc);
+      else ch_mma<1, 1>(arow, bptr, bstride, G, acc);
+    }
+    if (dbg && lane == 0) dbg[2 + 2 * si] = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // every wave is done reading the activation tile
+
+    if (nct > 0) {
+      switch (st.epi) {
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+      }
+    }
+    if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();
+    if (st.pe_tail_col >= 0) {
+      __syncthreads();
+      ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.C1, st.ldc1, st.pe_tail_col, 0);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
+  const NudfChain& p = *args;
+  if (p.P <= 0 || p.n_steps <= 0) return 0;
+  bool bad = p.n_steps > NUDF_CH_MAX_STEPS || (p.k0 & 3) || p.k0 > 256;
+  for (int i = 0; i < p.n_steps && !bad; ++i) {
+    const NudfChainStep& s = p.step[i];
+    bad = (s.K & 15) || s.K <= 0 || s.K > 256 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
+          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 256);
+  }
+  if (bad) {
+    nudf_set_error("nudf_mlp_chain: K%16, K<=256, N<=256, 16-byte aligned packed weights required", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
+  if (p.tile_rows == 32 || (p.tile_rows == 0 && p.P <= 256 * 64)) {
+    hipLaunchKernelGGL(mlp_chain_kernel<32>, dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(mlp_chain_kernel<64>, dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+  }
+  NUDF_CHECK_LAUNCH("nudf_mlp_chain");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weights -> MFMA-B fragment order.  B is the [K, N] row-major GEMM operand (W^T for forward sweeps, W for
+// reverse sweeps; row stride ldb).  out[((g*NT + T)*64 + lane)*4 + j] = B[8g + 4(lane>>5) + j][32T + (lane&31)],
+// zero outside K x N.  Kpad = roundup(K, 16).
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_frag_kernel(const float* __restrict__ B, int ldb, int K, int N, int NT, int total,
+                                 float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx & 3, lane = (idx >> 2) & 63, gt = idx >> 8;
+  const int T = gt % NT, g = gt / NT;
+  const int k = 8 * g + 4 * (lane >> 5) + j, n = 32 * T + (lane & 31);
+  out[idx] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.0f;
+}
+
+extern "C" int nudf_pack_frag(const float* B, int ldb, int K, int N, float* out, void* stream) {
+  if (K <= 0 || N <= 0) return 0;
+  const int G = 2 * ((K + 15) / 16), NT = (N + 31) / 32;
+  const int total = G * NT * 256;
+  hipLaunchKernelGGL(pack_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, ldb, K, N, NT,
+                     total, out);
+  NUDF_CHECK_LAUNCH("nudf_pack_frag");
+  return 0;
+}

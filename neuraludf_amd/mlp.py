@@ -20,19 +20,27 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from ._lib import EPI, GemmNN, GemmTN, call, ptr
+import os
+
+from ._lib import CH, CH_INIT, CH_MAX_STEPS, EPI, Chain, GemmNN, GemmTN, call, ptr
 
 
 def pad32(n: int) -> int:
     return (n + 31) // 32 * 32
 
 
+def pad_rows(P: int) -> int:
+    """the fused chain kernels store whole 64-point tiles: their buffers carry roundup(P, 64) rows."""
+    return (P + 63) // 64 * 64
+
+
 def _buf(P, width, dev, zero=None):
-    """[P, pad32(width)] fp32; zero-filled when there are pad columns (or when asked)."""
+    """[pad_rows(P), pad32(width)] fp32 (rows >= P are scratch for the tile kernels); zero-filled when there
+    are pad columns (or when asked)."""
     ld = pad32(width)
     if zero is None:
         zero = ld != width
-    return (torch.zeros if zero else torch.empty)((P, ld), device=dev, dtype=torch.float32)
+    return (torch.zeros if zero else torch.empty)((pad_rows(P), ld), device=dev, dtype=torch.float32)
 
 
 def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=0, X1=None, ldx1=0, X2=None, ldx2=0,
@@ -89,6 +97,89 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
     call("nudf_gemm_tn", a)
 
 
+# ------------------------------------------------------------------------------------------
+# fused layer chains (csrc/mlp_chain.hip)
+# ------------------------------------------------------------------------------------------
+USE_CHAIN = os.environ.get("NUDF_CHAIN", "1") != "0"     # 0: per-layer GEMM launches (A/B measurements, cross-checks)
+CHAIN_DEBUG = None     # int64 tensor [blocks * 4, 32]: per-wave timeline written by the kernel (scripts/chain_timeline.py)
+CHAIN_TILE = int(os.environ.get("NUDF_CHAIN_TILE", "0"))  # 0 = auto, 32 / 64 force the points-per-workgroup tile
+
+
+def k8(n: int) -> int:
+    """reduction length of a chain step: the K loop runs two groups of 8 per iteration."""
+    return (n + 15) // 16 * 16
+
+
+def pack_frag(B, ldb, K, N, off=0):
+    """[K, N] operand (row stride ldb, starting `off` floats into B) -> MFMA-B fragment order."""
+    out = torch.empty(k8(K) // 8 * ((N + 31) // 32) * 256, device=B.device, dtype=torch.float32)
+    call("nudf_pack_frag", ptr(B) + 4 * off, ldb, K, N, ptr(out))
+    out.k_true, out.n_true = K, N
+    return out
+
+
+class ChainBuilder:
+    """fills a NudfChain; keeps the tensors it points at alive until the launch is enqueued."""
+
+    def __init__(self, P, init, k0, tile_rows=0):
+        self.c = Chain()
+        self.c.P, self.c.init, self.c.k0, self.c.tile_rows = P, CH_INIT[init], k0, (tile_rows or CHAIN_TILE)
+        self.n = 0
+        self.flops = 0.0
+        self.keep = []
+
+    def _p(self, t, off=0):
+        if t is None:
+            return None
+        self.keep.append(t)
+        return ptr(t) + 4 * off
+
+    def posenc(self, x, L, in_scale, tangent=None):
+        self.c.x, self.c.v = self._p(x), self._p(tangent)
+        self.c.pe_L, self.c.pe_jvp, self.c.pe_in_scale = L, (1 if tangent is not None else 0), in_scale
+
+    def init_store(self, G0):
+        if G0 is not None:
+            self.c.G0, self.c.ldg0 = self._p(G0), G0.shape[1]
+
+    def init_load(self, A0, lda0):
+        self.c.A0, self.c.lda0 = self._p(A0), lda0
+
+    def init_seed(self, A0, lda0, sign, wrow, scale, xscale):
+        self.c.A0, self.c.lda0 = self._p(A0), lda0
+        self.c.seed_sign, self.c.seed_wrow = self._p(sign), self._p(wrow)
+        self.c.seed_scale, self.c.seed_xscale = scale, xscale
+
+    def step(self, epi, Bp, K, N, bias=None, bias_off=0, X1=None, X2=None, C1=None, C2=None, ldc1=0, ldc2=0, r1_row=None,
+             ldr1=1, r1_col=None, iparam=0, act_write=1, act_col0=0, pe_tail_col=-1, pe_tail_scale=0.0, scale=1.0,
+             xscale=1.0):
+        if self.n >= CH_MAX_STEPS:
+            raise _lib.NudfError("too many chain steps")
+        s = self.c.step[self.n]
+        s.Bp, s.bias = self._p(Bp), self._p(bias, bias_off)
+        s.X1, s.X2, s.C1, s.C2 = self._p(X1), self._p(X2), self._p(C1), self._p(C2)
+        s.ldx1 = X1.shape[1] if X1 is not None else 0
+        s.ldx2 = X2.shape[1] if X2 is not None else 0
+        s.ldc1 = ldc1 or (C1.shape[1] if (C1 is not None and C1.dim() == 2) else 0)
+        s.ldc2 = ldc2 or (C2.shape[1] if (C2 is not None and C2.dim() == 2) else 0)
+        s.r1_row, s.ldr1, s.r1_col = self._p(r1_row), ldr1, self._p(r1_col)
+        s.K, s.N, s.epi, s.iparam = K, N, CH[epi], iparam
+        s.act_write, s.act_col0, s.pe_tail_col, s.pe_tail_scale = act_write, act_col0, pe_tail_col, pe_tail_scale
+        s.scale, s.xscale = scale, xscale
+        self.n += 1
+        self.flops += 2.0 * self.c.P * getattr(Bp, "k_true", K) * getattr(Bp, "n_true", N)
+
+    def launch(self):
+        self.c.n_steps = self.n
+        if CHAIN_DEBUG is not None:
+            self.c.dbg = ptr(CHAIN_DEBUG)
+        if PROFILE is not None:
+            _timed("mlp_chain", self.flops, lambda: call("nudf_mlp_chain", self.c))
+        else:
+            call("nudf_mlp_chain", self.c)
+        self.keep = []
+
+
 class PackedLinear:
     """one (weight-normed or plain) nn.Linear packed for the GEMM kernels."""
 
@@ -102,6 +193,7 @@ class PackedLinear:
         self.perm = None
         self.W = self.Wt = self.inv_norm = None
         self._ver = None
+        self._frags = {}
 
     def params(self):
         if self.weight_norm:
@@ -128,7 +220,32 @@ class PackedLinear:
              self.out, self.inp, ptr(self.perm), ptr(self.W), self.in_pad, ptr(self.Wt), self.out_pad,
              ptr(self.inv_norm))
         self._ver = ver
+        self._frags = {}
         return self
+
+    def frag(self, kind):
+        """fragment-ordered copies for the fused chains (cached until the parameters change):
+        'fwd'  B = W^T [inp, out]            'bwd'  B = W [out, inp]
+        'fwd_head0' / 'fwd_feat'  column 0 / columns 1.. of W^T (the UDF head, fields.py:184-190)
+        'bwd_feat'  rows 1.. of W"""
+        f = self._frags.get(kind)
+        if f is None:
+            if kind == "fwd":
+                f = pack_frag(self.Wt, self.out_pad, self.inp, self.out)
+            elif kind == "bwd":
+                f = pack_frag(self.W, self.in_pad, self.out, self.inp)
+            elif kind == "fwd_head0":
+                f = pack_frag(self.Wt, self.out_pad, self.inp, 1)
+            elif kind == "fwd_feat":
+                f = pack_frag(self.Wt, self.out_pad, self.inp, self.out - 1, off=1)
+            elif kind == "bwd_feat":
+                f = pack_frag(self.W, self.in_pad, self.out - 1, self.inp, off=self.in_pad)
+            elif kind.startswith("bwd_hid:"):
+                f = pack_frag(self.W, self.in_pad, self.out, int(kind.split(":")[1]))
+            else:
+                raise KeyError(kind)
+            self._frags[kind] = f
+        return f
 
     @property
     def bias(self):
@@ -186,8 +303,159 @@ class UDFEngine:
             call("nudf_posenc", ptr(x), 3, 1, ptr(tangent), net.d_in, net.multires, float(net.scale), P,
                  ptr(dst) + 4 * off, dst.shape[1], self.inv_sqrt2, None, 0, 0.0)
 
+    # -- dispatch: fused LDS-resident chains (default) or per-layer GEMM launches -------------------
+    def _chain_ok(self):
+        net = self.net
+        widths_ok = all(pl.out <= 256 and pl.inp <= 256 for pl in self.layers[:-1]) and self.layers[-1].inp <= 256 \
+            and self.layers[-1].out - 1 <= 256
+        skip_ok = len(self.skip) <= 1 and all(0 < s < self.L for s in self.skip)
+        return USE_CHAIN and net.multires > 0 and net.d_in == 3 and widths_ok and skip_ok and self.L + 2 <= CH_MAX_STEPS
+
     def forward(self, x, need_grad_state, feat_ld=0, udf_only=False):
-        """x [P,3] -> dict(udf [P], sign [P], feat [P, max(feat_ld, F)], state...).
+        if self._chain_ok():
+            return self._forward_chain(x, need_grad_state, feat_ld, udf_only)
+        return self._forward_layers(x, need_grad_state, feat_ld, udf_only)
+
+    def gradient(self, x, st):
+        if self._chain_ok():
+            return self._gradient_chain(x, st)
+        return self._gradient_layers(x, st)
+
+    def backward(self, x, st, DA, d_udf, d_feat, d_feat_ld, d_g):
+        if self._chain_ok():
+            return self._backward_chain(x, st, DA, d_udf, d_feat, d_feat_ld, d_g)
+        return self._backward_layers(x, st, DA, d_udf, d_feat, d_feat_ld, d_g)
+
+    def _skip_col(self, l):
+        """tile column where PE(x)/sqrt(2) starts in the input of skip layer l."""
+        return self.layers[l].inp - self.E
+
+    def _forward_chain(self, x, need_grad_state, feat_ld=0, udf_only=False):
+        """one launch: posenc -> 8 softplus layers -> abs head, activations resident in LDS."""
+        P, dev, L = x.shape[0], x.device, self.L
+        net = self.net
+        for pl in self.layers:
+            pl.pack()
+        X = [_buf(P, pl.inp, dev) for pl in self.layers] if need_grad_state else None
+        cb = ChainBuilder(P, "POSENC", k8(self.E))
+        cb.posenc(x, net.multires, float(net.scale))
+        if need_grad_state:
+            cb.init_store(X[0])
+        for l in range(L):
+            pl = self.layers[l]
+            nxt_skip = (l + 1) in self.skip
+            cb.step("SOFTPLUS", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias,
+                    C1=X[l + 1] if need_grad_state else None,
+                    scale=self.inv_sqrt2 if nxt_skip else 1.0,
+                    pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2)
+        pl = self.layers[L]
+        Pp = pad_rows(P)
+        udf = torch.empty(Pp, device=dev)
+        sign = torch.empty(Pp, device=dev) if need_grad_state else None
+        F = pl.out - 1
+        feat = None
+        if not udf_only:
+            ld = max(feat_ld, F)
+            feat = (torch.zeros if ld > F else torch.empty)((Pp, ld), device=dev)
+            if ld >= F + 3:
+                call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
+            cb.step("NONE", pl.frag("fwd_feat"), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat, act_write=0)
+        cb.step("UDFHEAD", pl.frag("fwd_head0"), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,
+                act_write=0, scale=1.0 / float(net.scale))
+        cb.launch()
+        return dict(udf=udf[:P], sign=(sign[:P] if sign is not None else None),
+                    feat=(feat[:P] if feat is not None else None), X=X, P=P)
+
+    def _gradient_chain(self, x, st):
+        """one launch: seed -> reverse sweep DA[L-1..0] -> d/d(embedding); then the encoding's VJP."""
+        P, L, dev = st["P"], self.L, x.device
+        X = st["X"]
+        net = self.net
+        DA = [_buf(P, self.layers[l].out, dev) for l in range(L)]
+        plL = self.layers[L]
+        Epad = pad32(self.E)
+        cb = ChainBuilder(P, "SEED", k8(self.layers[L - 1].out))
+        cb.init_seed(X[L], X[L].shape[1], st["sign"], plL.W, 1.0 / float(net.scale), self._xs(L - 1))
+        cb.init_store(DA[L - 1])
+        demb_skip = None
+        for l in range(L - 1, 0, -1):
+            pl = self.layers[l]
+            if l in self.skip:
+                demb_skip = torch.zeros(pad_rows(P), Epad, device=dev)
+                cb.step("MULSP", pl.frag("bwd"), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], C2=demb_skip,
+                        iparam=self.layers[l - 1].out, scale=self.inv_sqrt2, xscale=self._xs(l - 1))
+            else:
+                cb.step("MULSP", pl.frag("bwd"), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], xscale=self._xs(l - 1))
+        demb0 = torch.zeros(pad_rows(P), Epad, device=dev)
+        pl0 = self.layers[0]
+        cb.step("NONE", pl0.frag("bwd"), k8(pl0.out), pl0.inp, C1=demb0, act_write=0)
+        cb.launch()
+        g = torch.empty(P, 3, device=dev)
+        call("nudf_posenc_vjp", ptr(x), 3, net.d_in, net.multires, float(net.scale), P,
+             ptr(demb0), Epad, 1.0, ptr(demb_skip), Epad, 1.0, ptr(g))
+        return g, DA
+
+    def _backward_chain(self, x, st, DA, d_udf, d_feat, d_feat_ld, d_g):
+        """tangent sweep (second order) and adjoint sweep as one launch each; weight gradients as TN GEMMs."""
+        P, L, dev = st["P"], self.L, x.device
+        X, sign = st["X"], st["sign"]
+        layers = self.layers
+        net = self.net
+        grads = [pl.new_grad_buffers() for pl in layers]
+        second = d_g is not None and DA is not None
+        R = EX = None
+        if second:
+            R = [_buf(P, pl.inp, dev) for pl in layers]
+            EX = [_buf(P, layers[l].out, dev) for l in range(L)]
+            cb = ChainBuilder(P, "POSENC", k8(self.E))
+            cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
+            cb.init_store(R[0])
+            for l in range(L):
+                pl = layers[l]
+                nxt_skip = (l + 1) in self.skip
+                cb.step("TANGENT", pl.frag("fwd"), k8(pl.inp), pl.out, X1=X[l + 1], X2=DA[l], C1=R[l + 1], C2=EX[l],
+                        scale=self.inv_sqrt2 if nxt_skip else 1.0, xscale=self._xs(l),
+                        pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2)
+            cb.launch()
+            call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp,
+                 1.0 / float(net.scale), ptr(grads[L][0]))
+        plL = layers[L]
+        F = plL.out - 1
+        ABAR = [None] * (L + 1)
+        ABAR[L] = _buf(P, plL.out, dev)
+        call("nudf_udf_head_bwd", ptr(sign), ptr(d_udf), ptr(d_feat), d_feat_ld, P, F,
+             1.0 / float(net.scale), ptr(ABAR[L]), ABAR[L].shape[1])
+        for l in range(L):
+            ABAR[l] = _buf(P, layers[l].out, dev)
+        # adjoint sweep: the tile starts as d feat (ABAR[L] columns 1..F); column 0 enters as a rank-1 term
+        cb = ChainBuilder(P, "LOAD", k8(F))
+        if d_feat is None:
+            d_feat, d_feat_ld = torch.zeros(P, k8(F), device=dev), k8(F)
+        cb.init_load(d_feat, d_feat_ld)
+        for l in range(L, 0, -1):
+            pl = layers[l]
+            sc = self.inv_sqrt2 if l in self.skip else 1.0
+            if l == L:
+                cb.step("BWD", pl.frag("bwd_feat"), k8(F), layers[l - 1].out, X1=X[l], X2=EX[l - 1] if second else None,
+                        C1=ABAR[l - 1], r1_row=ABAR[L], ldr1=ABAR[L].shape[1], r1_col=pl.W, scale=sc,
+                        xscale=self._xs(l - 1))
+            else:
+                n_hid = layers[l - 1].out           # the skip layer's embedding columns carry no parameter gradient
+                cb.step("BWD", pl.frag("bwd" if n_hid == pl.inp else "bwd_hid:%d" % n_hid), k8(pl.out), n_hid, X1=X[l],
+                        X2=EX[l - 1] if second else None, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
+        cb.launch()
+        out = []
+        for l, pl in enumerate(layers):
+            dW, db = grads[l]
+            if second and l < L:
+                gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db, A2=DA[l], na2=pl.out, B2=R[l])
+            else:
+                gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db)
+            out += pl.unpack_grads(dW, db)
+        return out
+
+    def _forward_layers(self, x, need_grad_state, feat_ld=0, udf_only=False):
+        """per-layer GEMM launches.  x [P,3] -> dict(udf [P], sign [P], feat [P, max(feat_ld, F)], state...).
         feat_ld > F additionally writes x into cols F..F+2 (the colour net's base-input layout)."""
         P = x.shape[0]
         dev = x.device
@@ -218,7 +486,7 @@ class UDFEngine:
         """softplus output of layer j is stored in X[j+1] divided by this factor (skip concat /sqrt(2))."""
         return math.sqrt(2.0) if (j + 1) in self.skip else 1.0
 
-    def gradient(self, x, st):
+    def _gradient_layers(self, x, st):
         """reverse sweep for d udf / d x given forward state -> (g [P,3], DA list)."""
         P, L, dev = st["P"], self.L, x.device
         X = st["X"]
@@ -246,7 +514,7 @@ class UDFEngine:
              ptr(demb0), Epad, 1.0, ptr(demb_skip), Epad, 1.0, ptr(g))
         return g, DA
 
-    def backward(self, x, st, DA, d_udf, d_feat, d_feat_ld, d_g):
+    def _backward_layers(self, x, st, DA, d_udf, d_feat, d_feat_ld, d_g):
         """-> list of parameter gradients in params() order.
         d_udf [P] / d_feat [P, F] (row stride d_feat_ld) / d_g [P,3]; any may be None."""
         P, L, dev = st["P"], self.L, x.device
@@ -407,7 +675,7 @@ class ColorEngine:
         out = []
         for pl, (dW, db) in zip(self.view + self.base, gv + gb):
             out += pl.unpack_grads(dW, db)
-        return out, dCIN
+        return out, dCIN[:P]
 
 
 class NerfEngine:
