@@ -173,11 +173,13 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (EPI == NUDF_CH_SOFTPLUS) {
+      // softplus100(v) = [max(t, 0) + log1p(exp(-|t|))] / 100, t = 100 v, from the two hardware transcendentals
+      // (v_exp_f32 / v_log_f32 are base 2).  Select-free on purpose: the compiler turns selects around
+      // transcendentals into per-element branches.  Above torch's threshold (t > 20) the log term is < 2.1e-9,
+      // i.e. the result equals v to fp32 resolution; for t << 0 the absolute error of log2(1 + z) is < 1e-9.
       const float t = 100.0f * v[r];
-      const float z = __expf(t);
-      const float lg = __logf(1.0f + z) * 0.01f;
-      const float ser = (z - 0.5f * z * z) * 0.01f;          // log1p series for tiny z
-      out[r] = ((t > 20.0f) ? v[r] : ((z < 1e-4f) ? ser : lg)) * st.scale;
+      const float z = __builtin_amdgcn_exp2f(fabsf(t) * -1.44269504f);
+      out[r] = (fmaxf(t, 0.0f) + __builtin_amdgcn_logf(1.0f + z) * 0.69314718f) * (0.01f * st.scale);
     } else if (EPI == NUDF_CH_NONE) {
       out[r] = v[r] * st.scale;
     } else if (EPI == NUDF_CH_UDFHEAD) {
@@ -185,11 +187,10 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       out2[r] = (v[r] > 0.0f) ? 1.0f : ((v[r] < 0.0f) ? -1.0f : 0.0f);
     } else {
       // softplus'(a) = s and 1 - s recovered from the stored activation (see ch_sp_derivs)
+      // stored h = softplus100(a) / xscale  ->  1 - s = exp(-100 h xscale), s = softplus'(a) = sigmoid(100 a)
       const float x = 100.0f * st.xscale * x1[r];
-      const float e = __expf(-x);
-      const float poly = x * (1.0f - x * (0.5f - x * 0.16666667f));
-      const float sg = (x > 20.0f) ? 1.0f : ((x < 0.01f) ? poly : 1.0f - e);
-      const float om = (x > 20.0f) ? 0.0f : e;
+      const float om = __builtin_amdgcn_exp2f(x * -1.44269504f);
+      const float sg = 1.0f - om;
       if (EPI == NUDF_CH_MULSP) {
         const bool hid = st.iparam <= 0 || col < st.iparam;
         out[r] = hid ? v[r] * sg * st.scale : 0.0f;

@@ -43,6 +43,26 @@ def _buf(P, width, dev, zero=None):
     return (torch.zeros if zero else torch.empty)((pad_rows(P), ld), device=dev, dtype=torch.float32)
 
 
+def _zero_cols(t, c0):
+    """zero the pad columns [c0, ld) of a [P, ld] buffer (they multiply zero weight rows, so they must be finite)."""
+    if c0 < t.shape[1]:
+        t[:, c0:].zero_()
+    return t
+
+
+def alloc_grads(layers):
+    """one zero-filled flat buffer for the packed weight / bias gradients of `layers` -> [(dW, db), ...] views."""
+    sizes = [(pl.out_pad * pl.in_pad, pl.out_pad) for pl in layers]     # db padded to out_pad keeps 16-byte alignment
+    flat = torch.zeros(sum(a + b for a, b in sizes), device=layers[0].W.device)
+    out, off = [], 0
+    for pl, (a, b) in zip(layers, sizes):
+        dW = flat[off:off + a].view(pl.out_pad, pl.in_pad)
+        db = flat[off + a:off + a + pl.out]
+        out.append((dW, db))
+        off += a + b
+    return out
+
+
 def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=0, X1=None, ldx1=0, X2=None, ldx2=0,
             bias=None, lda=None, ldb=None, iparam=0, scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x1_off=0, x2_off=0):
     """thin wrapper filling NudfGemmNN; *_off are column offsets (in floats) into the buffers."""
@@ -336,7 +356,7 @@ class UDFEngine:
         net = self.net
         for pl in self.layers:
             pl.pack()
-        X = [_buf(P, pl.inp, dev) for pl in self.layers] if need_grad_state else None
+        X = [_buf(P, pl.inp, dev, zero=False) for pl in self.layers] if need_grad_state else None
         cb = ChainBuilder(P, "POSENC", k8(self.E))
         cb.posenc(x, net.multires, float(net.scale))
         if need_grad_state:
@@ -356,9 +376,12 @@ class UDFEngine:
         feat = None
         if not udf_only:
             ld = max(feat_ld, F)
-            feat = (torch.zeros if ld > F else torch.empty)((Pp, ld), device=dev)
+            feat = torch.empty((Pp, ld), device=dev)
             if ld >= F + 3:
                 call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
+                _zero_cols(feat, F + 3)
+            else:
+                _zero_cols(feat, F)
             cb.step("NONE", pl.frag("fwd_feat"), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat, act_write=0)
         cb.step("UDFHEAD", pl.frag("fwd_head0"), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,
                 act_write=0, scale=1.0 / float(net.scale))
@@ -371,7 +394,7 @@ class UDFEngine:
         P, L, dev = st["P"], self.L, x.device
         X = st["X"]
         net = self.net
-        DA = [_buf(P, self.layers[l].out, dev) for l in range(L)]
+        DA = [_buf(P, self.layers[l].out, dev, zero=False) for l in range(L)]
         plL = self.layers[L]
         Epad = pad32(self.E)
         cb = ChainBuilder(P, "SEED", k8(self.layers[L - 1].out))
@@ -381,12 +404,12 @@ class UDFEngine:
         for l in range(L - 1, 0, -1):
             pl = self.layers[l]
             if l in self.skip:
-                demb_skip = torch.zeros(pad_rows(P), Epad, device=dev)
+                demb_skip = torch.empty(pad_rows(P), Epad, device=dev)
                 cb.step("MULSP", pl.frag("bwd"), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], C2=demb_skip,
                         iparam=self.layers[l - 1].out, scale=self.inv_sqrt2, xscale=self._xs(l - 1))
             else:
                 cb.step("MULSP", pl.frag("bwd"), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], xscale=self._xs(l - 1))
-        demb0 = torch.zeros(pad_rows(P), Epad, device=dev)
+        demb0 = torch.empty(pad_rows(P), Epad, device=dev)
         pl0 = self.layers[0]
         cb.step("NONE", pl0.frag("bwd"), k8(pl0.out), pl0.inp, C1=demb0, act_write=0)
         cb.launch()
@@ -401,12 +424,12 @@ class UDFEngine:
         X, sign = st["X"], st["sign"]
         layers = self.layers
         net = self.net
-        grads = [pl.new_grad_buffers() for pl in layers]
+        grads = alloc_grads(layers)
         second = d_g is not None and DA is not None
         R = EX = None
         if second:
-            R = [_buf(P, pl.inp, dev) for pl in layers]
-            EX = [_buf(P, layers[l].out, dev) for l in range(L)]
+            R = [_buf(P, pl.inp, dev, zero=False) for pl in layers]
+            EX = [_buf(P, layers[l].out, dev, zero=False) for l in range(L)]
             cb = ChainBuilder(P, "POSENC", k8(self.E))
             cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
             cb.init_store(R[0])
@@ -422,11 +445,11 @@ class UDFEngine:
         plL = layers[L]
         F = plL.out - 1
         ABAR = [None] * (L + 1)
-        ABAR[L] = _buf(P, plL.out, dev)
+        ABAR[L] = _buf(P, plL.out, dev, zero=False)
         call("nudf_udf_head_bwd", ptr(sign), ptr(d_udf), ptr(d_feat), d_feat_ld, P, F,
              1.0 / float(net.scale), ptr(ABAR[L]), ABAR[L].shape[1])
         for l in range(L):
-            ABAR[l] = _buf(P, layers[l].out, dev)
+            ABAR[l] = _buf(P, layers[l].out, dev, zero=False)
         # adjoint sweep: the tile starts as d feat (ABAR[L] columns 1..F); column 0 enters as a rank-1 term
         cb = ChainBuilder(P, "LOAD", k8(F))
         if d_feat is None:
@@ -567,7 +590,7 @@ def relu_chain_bwd(layers, inputs, outs, D_last, P, first_needs_input_grad, add_
     gradient is D_last [P, out_pad]).  Returns (grads per layer, d_input of layer 0 or None).
     add_at = {layer_index: tensor} adds an extra adjoint to that layer's *output* before the mask."""
     n = len(layers)
-    grads = [pl.new_grad_buffers() for pl in layers]
+    grads = alloc_grads(layers)
     D = D_last
     d_in0 = None
     for i in range(n - 1, -1, -1):
@@ -624,7 +647,7 @@ class ColorEngine:
         n = self.n
         for pl in self.base + self.view:
             pl.pack()
-        VIN = torch.zeros(P, pad32(self.H + self.npe + self.dout), device=dev)
+        VIN = _zero_cols(torch.empty(P, pad32(self.H + self.npe + self.dout), device=dev), self.H + self.npe + self.dout)
         # PE(view_dirs) (fields.py:453-454); directions are per ray -> xdiv = S
         call("nudf_posenc", ptr(rays_d), 3, S, None, 3, self.net.multires_view, 1.0, P,
              ptr(VIN) + 4 * self.H, VIN.shape[1], 1.0, None, 0, 0.0)
