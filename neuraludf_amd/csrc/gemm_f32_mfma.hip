@@ -304,6 +304,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
   const int t_c4 = tid & 31;  // float4 column
 
   f32x4 ra[4], rb[4];
+  int ld_rows = 0;
+  // branch-free: column indices are clamped into the buffer (columns past NA / NB only feed outputs that are
+  // never stored), rows are clamped and rows >= mend are zeroed by selects
   auto gload = [&](int kt) {
     const int pair = kt / nk1;
     const int kk = kt - pair * nk1;
@@ -311,24 +314,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
     const float* B = pair ? p.B2 : p.B1;
     const int lda = pair ? p.lda2 : p.lda1;
     const int ldb = pair ? p.ldb2 : p.ldb1;
-    const int na = pair ? p.na2 : p.na1;
-    const int ci = i0 + t_c4 * 4;
-    const int cj = j0 + t_c4 * 4;
+    const int ci = min(i0 + t_c4 * 4, lda - 4);
+    const int cj = min(j0 + t_c4 * 4, ldb - 4);
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int m = mbeg + kk * BK + ps * 8 + t_k;
-      const bool okm = m < mend;
-      ra[ps] = (okm && ci < na) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + ci)
-                                : f32x4{0.f, 0.f, 0.f, 0.f};
-      rb[ps] = (okm && cj < ldb) ? *reinterpret_cast<const f32x4*>(B + (size_t)m * ldb + cj)
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int mc = min(m, p.M - 1);
+      ra[ps] = *reinterpret_cast<const f32x4*>(A + (size_t)mc * lda + ci);
+      rb[ps] = *reinterpret_cast<const f32x4*>(B + (size_t)mc * ldb + cj);
     }
+    ld_rows = mend - (mbeg + kk * BK);   // rows of this k-step that exist (zeroed at the LDS store)
   };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-      *reinterpret_cast<f32x4*>(As + buf * T_TILE + (ps * 8 + t_k) * LDT_S + t_c4 * 4) = ra[ps];
-      *reinterpret_cast<f32x4*>(Bs + buf * T_TILE + (ps * 8 + t_k) * LDT_S + t_c4 * 4) = rb[ps];
+      const bool ok = (ps * 8 + t_k) < ld_rows;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(As + buf * T_TILE + (ps * 8 + t_k) * LDT_S + t_c4 * 4) = ok ? ra[ps] : z;
+      *reinterpret_cast<f32x4*>(Bs + buf * T_TILE + (ps * 8 + t_k) * LDT_S + t_c4 * 4) = ok ? rb[ps] : z;
     }
   };
 
@@ -353,10 +356,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
   }
   __syncthreads();
 
+  const bool full = acti && acti1 && actj0 && actj1;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
-    if (acti && actj0) {
+    __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+    if (full) {
+      // straight-line, software-pipelined in chunks of 4 k pairs: the 16 LDS reads of chunk c+1 are in flight
+      // under the 16 MFMAs of chunk c (two register sets)
+      const float* as = As + cur * T_TILE + (lane >> 5) * LDT_S + wm * 64 + (lane & 31);
+      const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT_S + wn * 64 + (lane & 31);
+      float av[2][4][2], bv[2][4][2];
+      auto rd = [&](int set, int c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = c * 4 + q;
+          av[set][q][0] = as[(2 * kk) * LDT_S];
+          av[set][q][1] = as[(2 * kk) * LDT_S + 32];
+          bv[set][q][0] = bs[(2 * kk) * LDT_S];
+          bv[set][q][1] = bs[(2 * kk) * LDT_S + 32];
+        }
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        if (c + 1 < BK / 8) rd((c + 1) & 1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0][0] = mfma32(av[c & 1][q][0], bv[c & 1][q][0], acc[0][0]);
+          acc[1][0] = mfma32(av[c & 1][q][1], bv[c & 1][q][0], acc[1][0]);
+          acc[0][1] = mfma32(av[c & 1][q][0], bv[c & 1][q][1], acc[0][1]);
+          acc[1][1] = mfma32(av[c & 1][q][1], bv[c & 1][q][1], acc[1][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (acti && actj0) {
       const float* as = As + cur * T_TILE + (lane >> 5) * LDT_S + wm * 64 + (lane & 31);
       const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT_S + wn * 64 + (lane & 31);
 #pragma unroll
@@ -376,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (do_bias && kt < nk1) {  // column sums of the first pair's A (bias gradient)
       const float* as = As + cur * T_TILE + tid;
 #pragma unroll
