@@ -259,6 +259,8 @@ def composite_roofline(dev, N, S, reps=50):
                     torch.empty(n, device=dev), torch.zeros(5, device=dev)]
             (a.weights, a.out_color, a.out_color_base, a.out_depth, a.out_normals, a.out_wsum, a.out_wsum_all,
              a.sums) = [ptr(b) for b in bufs]
+            ws = torch.empty(5 * ((n + 3) // 4), device=dev)
+            a.ws = ptr(ws)
             e0.record()
             for _ in range(reps):
                 call("nudf_composite_fwd", a)

@@ -106,6 +106,9 @@ typedef struct NudfComposite {
   float* out_normals;                          /* [N,3]                                     */
   float* out_wsum; float* out_wsum_all;        /* [N]                                       */
   float* sums;                                 /* [5] += {eik_num, eik_den, eikns_num, eikns_den, sparse_sum} (caller zeroes) */
+  float* ws;                                   /* scratch [5 * ceil(N/4)] for per-block partial sums (two-stage,
+                                                  deterministic; NULL = one atomic per block and sum, which serialises
+                                                  at the memory side for large N) */
   /* optional diagnostics, [N,S] each or NULL */
   float* o_alpha; float* o_alpha_plus; float* o_alpha_minus; float* o_vis_prob;
   float* o_alpha_occ; float* o_raw_occ; float* o_true_cos; float* o_grad_mag;
@@ -127,6 +130,7 @@ typedef struct NudfCompositeGrad {
   float* o_d_bg_sigma;                                /* [N,n_out] or NULL                  */
   float* o_d_bg_color;                                /* [N,n_out,3] or NULL                */
   float* o_d_scal;                                    /* [3] += d inv_s, d beta, d gamma (caller zeroes) */
+  float* ws;                                          /* scratch [3 * ceil(N/4)] or NULL (see NudfComposite.ws) */
 } NudfCompositeGrad;
 
 int nudf_composite_fwd(const NudfComposite* args, void* stream);

@@ -44,7 +44,7 @@ class Composite(C.Structure):
                 ("has_anneal", i32), ("cos_anneal", f32), ("flip_saturation", f32),
                 ("use_norm_grad", i32), ("sparse_scale", f32),
                 ("weights", c_fp), ("out_color", c_fp), ("out_color_base", c_fp), ("out_depth", c_fp),
-                ("out_normals", c_fp), ("out_wsum", c_fp), ("out_wsum_all", c_fp), ("sums", c_fp),
+                ("out_normals", c_fp), ("out_wsum", c_fp), ("out_wsum_all", c_fp), ("sums", c_fp), ("ws", c_fp),
                 ("o_alpha", c_fp), ("o_alpha_plus", c_fp), ("o_alpha_minus", c_fp), ("o_vis_prob", c_fp),
                 ("o_alpha_occ", c_fp), ("o_raw_occ", c_fp), ("o_true_cos", c_fp), ("o_grad_mag", c_fp),
                 ("o_mid_z", c_fp), ("o_dists", c_fp), ("o_inside", c_fp), ("o_flip", c_fp)]
@@ -54,7 +54,7 @@ class CompositeGrad(C.Structure):
     _fields_ = [("d_color", c_fp), ("d_color_base", c_fp), ("d_weights", c_fp), ("d_depth", c_fp),
                 ("d_normals", c_fp), ("d_wsum", c_fp), ("d_wsum_all", c_fp), ("d_sums", c_fp),
                 ("o_d_udf", c_fp), ("o_d_grad", c_fp), ("o_d_color", c_fp), ("o_d_color_base", c_fp),
-                ("o_d_bg_sigma", c_fp), ("o_d_bg_color", c_fp), ("o_d_scal", c_fp)]
+                ("o_d_bg_sigma", c_fp), ("o_d_bg_color", c_fp), ("o_d_scal", c_fp), ("ws", c_fp)]
 
 
 class Upsample(C.Structure):

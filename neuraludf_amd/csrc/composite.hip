@@ -12,6 +12,14 @@
 #include "nudf_common.h"
 #include "../../include/nudf.h"
 
+// The kernel is VALU-bound with libm-accurate exp / divide / sqrt (~400 instructions per sample); the hardware
+// transcendentals (v_exp_f32, v_rcp_f32, v_sqrt_f32: <= 1 ulp) cut that ~3x and make it HBM-bound.  Their error
+// (1e-7 relative) is the same class as the fp32 rounding differences between two torch back ends.
+#define CEXP(x) __expf(x)
+#define CRCP(x) __builtin_amdgcn_rcpf(x)
+#define CSQRT(x) __builtin_amdgcn_sqrtf(x)
+__device__ __forceinline__ float csigmoid(float x) { return CRCP(1.0f + CEXP(-x)); }
+
 struct PerSample {
   float z, dist, mid, u, gx, gy, gz, gm, tc, flip, raw, aocc, E_occ;
   float px, py, pz;
@@ -35,38 +43,58 @@ __device__ __forceinline__ AlphaOut sdf2alpha_f(float sdf, float ic, float dist,
   AlphaOut o;
   o.en = sdf + ic * dist * 0.5f;
   o.ep = sdf - ic * dist * 0.5f;
-  o.P = sigmoidf_(o.ep * inv_s);
-  o.Nx = sigmoidf_(o.en * inv_s);
+  o.P = csigmoid(o.ep * inv_s);
+  o.Nx = csigmoid(o.en * inv_s);
   o.num = o.P - o.Nx + 1e-5f;
   o.den = o.P + 1e-5f;
-  o.a = o.num / o.den;
+  o.a = o.num * CRCP(o.den);
   return o;
 }
 __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
-// shared per-sample evaluation (phase A)
-__device__ __forceinline__ void eval_sample(const NudfComposite& p, const RayConst& rc, int ray, int i, PerSample& s) {
+// raw per-sample inputs.  ALL chunks of a ray are loaded before any arithmetic or store, so the HBM latency
+// is paid once per ray instead of once per 64-sample chunk (stores to the diagnostic outputs would otherwise
+// fence the next chunk's loads).
+struct RawSample {
+  float z, zn, u, gx, gy, gz;
+};
+__device__ __forceinline__ void load_raw(const NudfComposite& p, int ray, int i, RawSample& r) {
+  // branch-free: the index is clamped into the ray (a divergent branch around a load makes the compiler wait
+  // for all outstanding loads at the join); lanes past S load a valid duplicate that is never used
   const int S = p.S;
-  const size_t b = (size_t)ray * S + i;
-  s.z = p.z[b];
-  float zn = (i < S - 1) ? p.z[b + 1] : 0.f;
-  s.dist = (i < S - 1) ? (zn - s.z) : rc.sdist;
+  const int ic = min(i, S - 1);
+  const size_t b = (size_t)ray * S + ic;
+  r.z = p.z[b];
+  r.zn = p.z[b + ((ic < S - 1) ? 1 : 0)];
+  r.u = p.udf[b];
+  r.gx = p.grad[b * 3 + 0];
+  r.gy = p.grad[b * 3 + 1];
+  r.gz = p.grad[b * 3 + 2];
+}
+
+// shared per-sample evaluation (phase A)
+__device__ __forceinline__ void eval_sample(const NudfComposite& p, const RayConst& rc, int i, const RawSample& r,
+                                            PerSample& s) {
+  const int S = p.S;
+  s.z = r.z;
+  s.dist = (i < S - 1) ? (r.zn - s.z) : rc.sdist;
   s.mid = s.z + s.dist * 0.5f;
   s.px = rc.ox + rc.dx * s.mid;
   s.py = rc.oy + rc.dy * s.mid;
   s.pz = rc.oz + rc.dz * s.mid;
-  s.u = p.udf[b];
-  s.gx = p.grad[b * 3 + 0];
-  s.gy = p.grad[b * 3 + 1];
-  s.gz = p.grad[b * 3 + 2];
-  s.gm = sqrtf(s.gx * s.gx + s.gy * s.gy + s.gz * s.gz);
-  const float gme = s.gm + 1e-5f;  // gradients / (|g| + 1e-5)  (:370-371)
-  const float cn = rc.dx * (s.gx / gme) + rc.dy * (s.gy / gme) + rc.dz * (s.gz / gme);
+  s.u = r.u;
+  s.gx = r.gx;
+  s.gy = r.gy;
+  s.gz = r.gz;
+  s.gm = CSQRT(s.gx * s.gx + s.gy * s.gy + s.gz * s.gz);
+  const float rgme = CRCP(s.gm + 1e-5f);  // gradients / (|g| + 1e-5)  (:370-371)
+  const float cn = rc.dx * (s.gx * rgme) + rc.dy * (s.gy * rgme) + rc.dz * (s.gz * rgme);
   s.tc = p.use_norm_grad ? cn : (rc.dx * s.gx + rc.dy * s.gy + rc.dz * s.gz);
   s.flip = (cn > 0.0f) ? -1.0f : 1.0f;  // -sign(cos), 0 -> 1  (:386-388)
-  const float e = expf(-rc.beta * s.u);
-  s.raw = rc.beta * e / ((1.0f + e) * (1.0f + e));  // udf2logistic(udf, beta, 1, 1)
-  s.E_occ = expf(-fmaxf(s.raw, 0.0f) * rc.gamma * s.dist);
+  const float e = CEXP(-rc.beta * s.u);
+  const float r1e = CRCP(1.0f + e);
+  s.raw = rc.beta * e * r1e * r1e;  // udf2logistic(udf, beta, 1, 1)
+  s.E_occ = CEXP(-fmaxf(s.raw, 0.0f) * rc.gamma * s.dist);
   s.aocc = 1.0f - s.E_occ;
 }
 
@@ -87,30 +115,63 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     float tcv[NC], aocc[NC], alpha[NC], apv[NC], amv[NC], flipv[NC], midv[NC];
     float cr[NC], cg[NC], cb[NC], br[NC], bg[NC], bb[NC], nx[NC], ny[NC], nz[NC];
 
+    // ---- phase 0: every load of this ray, branch-free --------------------------------------
+    RawSample raw[NC];
+    float bgz[NC], bgzn[NC], bgs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = c * 64 + l;
+      load_raw(p, ray, i, raw[c]);
+      const size_t b = (size_t)ray * S + min(i, S - 1);
+      cr[c] = p.color[b * 3 + 0]; cg[c] = p.color[b * 3 + 1]; cb[c] = p.color[b * 3 + 2];
+      br[c] = p.color_base[b * 3 + 0]; bg[c] = p.color_base[b * 3 + 1]; bb[c] = p.color_base[b * 3 + 2];
+      bgz[c] = bgzn[c] = bgs[c] = 0.f;
+    }
+    if (NO > 0) {  // uniform
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + l;
+        if ((c + 1) * 64 <= S) continue;  // uniform: this chunk holds no outside sample
+        const int j = min(max(i - S, 0), NO - 1);
+        const size_t b = (size_t)ray * NO + j;
+        bgz[c] = p.bg_z[b];
+        bgzn[c] = p.bg_z[b + ((j < NO - 1) ? 1 : 0)];
+        bgs[c] = p.bg_sigma[b];
+        const float q0 = p.bg_color[b * 3 + 0], q1 = p.bg_color[b * 3 + 1], q2 = p.bg_color[b * 3 + 2];
+        const bool out = i >= S;
+        cr[c] = out ? q0 : cr[c]; cg[c] = out ? q1 : cg[c]; cb[c] = out ? q2 : cb[c];
+        br[c] = out ? q0 : br[c]; bg[c] = out ? q1 : bg[c]; bb[c] = out ? q2 : bb[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool live = (c * 64 + l) < ST;
+      cr[c] = live ? cr[c] : 0.f; cg[c] = live ? cg[c] : 0.f; cb[c] = live ? cb[c] : 0.f;
+      br[c] = live ? br[c] : 0.f; bg[c] = live ? bg[c] : 0.f; bb[c] = live ? bb[c] : 0.f;
+    }
+
     // ---- phase A: per-sample quantities --------------------------------------------------
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
       tcv[c] = 0.f; aocc[c] = 0.f; alpha[c] = 0.f; apv[c] = 0.f; amv[c] = 0.f; flipv[c] = 1.f; midv[c] = 0.f;
-      cr[c] = cg[c] = cb[c] = br[c] = bg[c] = bb[c] = nx[c] = ny[c] = nz[c] = 0.f;
+      nx[c] = ny[c] = nz[c] = 0.f;
       if (i < S) {
         PerSample s;
-        eval_sample(p, rc, ray, i, s);
+        eval_sample(p, rc, i, raw[c], s);
         tcv[c] = s.tc; aocc[c] = s.aocc; flipv[c] = s.flip; midv[c] = s.mid;
         nx[c] = s.flip * s.gx; ny[c] = s.flip * s.gy; nz[c] = s.flip * s.gz;
         const size_t b = (size_t)ray * S + i;
-        cr[c] = p.color[b * 3 + 0]; cg[c] = p.color[b * 3 + 1]; cb[c] = p.color[b * 3 + 2];
-        br[c] = p.color_base[b * 3 + 0]; bg[c] = p.color_base[b * 3 + 1]; bb[c] = p.color_base[b * 3 + 2];
         // sdf2alpha(+-udf, -|true_cos|, dist, inv_s, cos_anneal_ratio)  (:414-417)
         const float ic = iter_cos_of(-fabsf(s.tc), p.has_anneal, p.cos_anneal);
         apv[c] = clip01(sdf2alpha_f(s.u, ic, s.dist, rc.inv_s).a);
         amv[c] = clip01(sdf2alpha_f(-s.u, ic, s.dist, rc.inv_s).a);
         // eikonal / sparsity partial sums (:484-487, 531-536, 553)
-        const float pn = sqrtf(s.px * s.px + s.py * s.py + s.pz * s.pz);
+        const float pn = CSQRT(s.px * s.px + s.py * s.py + s.pz * s.pz);
         const float ge = (s.gm - 1.0f) * (s.gm - 1.0f);
         if (pn < 1.2f) { s_relax_n += ge; s_relax_d += 1.0f; }
         if (s.u < 0.05f) { s_near_n += ge; s_near_d += 1.0f; }
-        s_sparse += expf(-p.sparse_scale * s.u);
+        s_sparse += CEXP(-p.sparse_scale * s.u);
         if (p.o_alpha_occ) p.o_alpha_occ[b] = s.aocc;
         if (p.o_raw_occ) p.o_raw_occ[b] = s.raw;
         if (p.o_true_cos) p.o_true_cos[b] = s.tc;
@@ -120,13 +181,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
         if (p.o_inside) p.o_inside[b] = (pn < 1.0f) ? 1.0f : 0.0f;
         if (p.o_flip) p.o_flip[b] = s.flip;
       } else if (i < ST) {
-        const size_t b = (size_t)ray * NO + (i - S);
-        const float zo = p.bg_z[b];
-        const float dist = (i < ST - 1) ? (p.bg_z[b + 1] - zo) : rc.sdist;
-        alpha[c] = 1.0f - expf(-fmaxf(p.bg_sigma[b], 0.0f) * dist);  // :181
-        cr[c] = br[c] = p.bg_color[b * 3 + 0];
-        cg[c] = bg[c] = p.bg_color[b * 3 + 1];
-        cb[c] = bb[c] = p.bg_color[b * 3 + 2];
+        const float dist = (i < ST - 1) ? (bgzn[c] - bgz[c]) : rc.sdist;
+        alpha[c] = 1.0f - CEXP(-fmaxf(bgs[c], 0.0f) * dist);  // :181
       }
     }
 
@@ -136,15 +192,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
       // vis_mask shifted by one sample: mask_i = (true_cos_{i+1} < 0.01), last = 1
-      float tnext = __shfl_down(tcv[c], 1, 64);
-      float tn_other = (c + 1 < NC) ? __shfl(tcv[(c + 1 < NC) ? c + 1 : c], 0, 64) : 0.f;
-      if (l == 63) tnext = tn_other;
+      const float tn_other = (c + 1 < NC) ? wave_bcast(tcv[(c + 1 < NC) ? c + 1 : c], 0) : 0.f;
+      const float tnext = wave_shift_down1(tcv[c], tn_other);
       float vm = (i < S - 1) ? ((tnext < 0.01f) ? 1.0f : 0.0f) : 1.0f;
       float q = (i < S) ? (clip01(1.0f - aocc[c] + p.flip_saturation * vm) + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(q) * carry;
-      float exc = __shfl_up(inc, 1, 64);
-      if (l == 0) exc = carry;
-      carry = __shfl(inc, 63, 64);
+      const float exc = wave_shift_up1(inc, carry);
+      carry = wave_bcast(inc, 63);
       if (i < S) {
         const float vis = clip01(exc);
         alpha[c] = apv[c] * vis + amv[c] * (1.0f - vis);
@@ -165,9 +219,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
       const int i = c * 64 + l;
       const float f = (i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(f) * carry;
-      float exc = __shfl_up(inc, 1, 64);
-      if (l == 0) exc = carry;
-      carry = __shfl(inc, 63, 64);
+      const float exc = wave_shift_up1(inc, carry);
+      carry = wave_bcast(inc, 63);
       const float w = (i < ST) ? alpha[c] * exc : 0.0f;
       if (i < ST) p.weights[(size_t)ray * ST + i] = w;
       a_cr += w * cr[c]; a_cg += w * cg[c]; a_cb += w * cb[c];
@@ -209,7 +262,26 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
   __syncthreads();
   if (threadIdx.x < 5) {
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(p.sums + threadIdx.x, t);
+    if (p.ws) p.ws[(size_t)blockIdx.x * 5 + threadIdx.x] = t;   // summed by partial_sums_kernel
+    else atomicAdd(p.sums + threadIdx.x, t);
+  }
+}
+
+// out[k] += sum_b ws[b * K + k]  (one block; fixed order -> deterministic batch-global sums)
+__global__ __launch_bounds__(256) void partial_sums_kernel(const float* __restrict__ ws, int nblk, int K,
+                                                           float* __restrict__ out) {
+  __shared__ float red[256];
+  for (int k = 0; k < K; ++k) {
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) acc += ws[(size_t)b * K + k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] += red[0];
+    __syncthreads();
   }
 }
 
@@ -250,6 +322,42 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     float q[NC], inner[NC], Vraw[NC], vis[NC], ap_raw[NC], am_raw[NC], alpha[NC], T[NC], w[NC], f[NC], dw[NC], icv[NC];
     float bg_dist[NC], bg_E[NC];
 
+    // ---- phase 0: every load of this ray, branch-free (see load_raw) ------------------------------
+    RawSample raw[NC];
+    float cdot[NC], dwup[NC], bgz[NC], bgzn[NC], bgs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = c * 64 + l;
+      load_raw(p, ray, i, raw[c]);
+      const size_t b = (size_t)ray * S + min(i, S - 1);
+      // the colours only enter the backward through <upstream, colour>
+      cdot[c] = dCr * p.color[b * 3 + 0] + dCg * p.color[b * 3 + 1] + dCb * p.color[b * 3 + 2] +
+                dBr * p.color_base[b * 3 + 0] + dBg * p.color_base[b * 3 + 1] + dBb * p.color_base[b * 3 + 2];
+      dwup[c] = g.d_weights ? g.d_weights[(size_t)ray * ST + min(i, ST - 1)] : 0.f;
+      bgz[c] = bgzn[c] = bgs[c] = 0.f;
+    }
+    if (NO > 0) {  // uniform
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int i = c * 64 + l;
+        if ((c + 1) * 64 <= S) continue;  // uniform
+        const int j = min(max(i - S, 0), NO - 1);
+        const size_t b = (size_t)ray * NO + j;
+        bgz[c] = p.bg_z[b];
+        bgzn[c] = p.bg_z[b + ((j < NO - 1) ? 1 : 0)];
+        bgs[c] = p.bg_sigma[b];
+        const float q = (dCr + dBr) * p.bg_color[b * 3 + 0] + (dCg + dBg) * p.bg_color[b * 3 + 1] +
+                        (dCb + dBb) * p.bg_color[b * 3 + 2];
+        cdot[c] = (i >= S) ? q : cdot[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool live = (c * 64 + l) < ST;
+      cdot[c] = live ? cdot[c] : 0.f;
+      dwup[c] = live ? dwup[c] : 0.f;
+    }
+
     // ---- recompute phase A ------------------------------------------------------------------
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -257,13 +365,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       ps[c].tc = 0.f; ps[c].aocc = 0.f; alpha[c] = 0.f; bg_dist[c] = 0.f; bg_E[c] = 1.f; icv[c] = 0.f;
       ap_raw[c] = am_raw[c] = 0.f;
       if (i < S) {
-        eval_sample(p, rc, ray, i, ps[c]);
+        eval_sample(p, rc, i, raw[c], ps[c]);
         icv[c] = iter_cos_of(-fabsf(ps[c].tc), p.has_anneal, p.cos_anneal);
       } else if (i < ST) {
-        const size_t b = (size_t)ray * NO + (i - S);
-        const float zo = p.bg_z[b];
-        bg_dist[c] = (i < ST - 1) ? (p.bg_z[b + 1] - zo) : rc.sdist;
-        bg_E[c] = expf(-fmaxf(p.bg_sigma[b], 0.0f) * bg_dist[c]);
+        bg_dist[c] = (i < ST - 1) ? (bgzn[c] - bgz[c]) : rc.sdist;
+        bg_E[c] = CEXP(-fmaxf(bgs[c], 0.0f) * bg_dist[c]);
         alpha[c] = 1.0f - bg_E[c];
       }
     }
@@ -272,16 +378,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      float tnext = __shfl_down(ps[c].tc, 1, 64);
-      float tn_other = (c + 1 < NC) ? __shfl(ps[(c + 1 < NC) ? c + 1 : c].tc, 0, 64) : 0.f;
-      if (l == 63) tnext = tn_other;
+      const float tn_other = (c + 1 < NC) ? wave_bcast(ps[(c + 1 < NC) ? c + 1 : c].tc, 0) : 0.f;
+      const float tnext = wave_shift_down1(ps[c].tc, tn_other);
       float vm = (i < S - 1) ? ((tnext < 0.01f) ? 1.0f : 0.0f) : 1.0f;
       inner[c] = 1.0f - ps[c].aocc + p.flip_saturation * vm;
       q[c] = (i < S) ? (clip01(inner[c]) + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(q[c]) * carry;
-      float exc = __shfl_up(inc, 1, 64);
-      if (l == 0) exc = carry;
-      carry = __shfl(inc, 63, 64);
+      const float exc = wave_shift_up1(inc, carry);
+      carry = wave_bcast(inc, 63);
       Vraw[c] = exc;
       vis[c] = clip01(exc);
       if (i < S) {
@@ -297,20 +401,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       const int i = c * 64 + l;
       f[c] = (i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(f[c]) * carry;
-      float exc = __shfl_up(inc, 1, 64);
-      if (l == 0) exc = carry;
-      carry = __shfl(inc, 63, 64);
+      const float exc = wave_shift_up1(inc, carry);
+      carry = wave_bcast(inc, 63);
       T[c] = exc;
       w[c] = (i < ST) ? alpha[c] * exc : 0.0f;
       float d = 0.f;
       if (i < ST) {
-        d = dWall + (g.d_weights ? g.d_weights[(size_t)ray * ST + i] : 0.f);
+        d = dWall + dwup[c] + cdot[c];
         if (i < p.s_nominal) d += dWs;
       }
       if (i < S) {
         const size_t b = (size_t)ray * S + i;
-        d += dCr * p.color[b * 3 + 0] + dCg * p.color[b * 3 + 1] + dCb * p.color[b * 3 + 2];
-        d += dBr * p.color_base[b * 3 + 0] + dBg * p.color_base[b * 3 + 1] + dBb * p.color_base[b * 3 + 2];
         d += dDepth * ps[c].mid + ps[c].flip * (dNx * ps[c].gx + dNy * ps[c].gy + dNz * ps[c].gz);
         // colours receive w * upstream
         if (g.o_d_color) {
@@ -322,8 +423,6 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
         }
       } else if (i < ST) {
         const size_t b = (size_t)ray * NO + (i - S);
-        const float c0 = p.bg_color[b * 3 + 0], c1 = p.bg_color[b * 3 + 1], c2 = p.bg_color[b * 3 + 2];
-        d += (dCr + dBr) * c0 + (dCg + dBg) * c1 + (dCb + dBb) * c2;
         if (g.o_d_bg_color) {
           g.o_d_bg_color[b * 3 + 0] = w[c] * (dCr + dBr); g.o_d_bg_color[b * 3 + 1] = w[c] * (dCg + dBg);
           g.o_d_bg_color[b * 3 + 2] = w[c] * (dCb + dBb);
@@ -341,8 +440,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       const float v = dw[c] * w[c];
       float incl = wave_incl_rscan_add(v) + rcarry;  // sum_{j>=i}
       float excl = incl - v;                          // sum_{j>i}
-      rcarry = __shfl(incl, 0, 64);
-      dalpha[c] = dw[c] * T[c] - excl / f[c];
+      rcarry = wave_bcast(incl, 0);
+      dalpha[c] = dw[c] * T[c] - excl * CRCP(f[c]);
     }
 
     // ---- local backward to vis / alpha+- ; reverse scan 2 through the visibility product ---
@@ -358,7 +457,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       } else if (i < ST) {
         // background alpha = 1 - exp(-relu(sigma) dist)
         const size_t b = (size_t)ray * NO + (i - S);
-        if (g.o_d_bg_sigma) g.o_d_bg_sigma[b] = (p.bg_sigma[b] > 0.0f) ? dalpha[c] * bg_E[c] * bg_dist[c] : 0.0f;
+        if (g.o_d_bg_sigma) g.o_d_bg_sigma[b] = (bgs[c] > 0.0f) ? dalpha[c] * bg_E[c] * bg_dist[c] : 0.0f;
       }
     }
     rcarry = 0.0f;
@@ -368,18 +467,18 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       const float v = dV_V[c];
       float incl = wave_incl_rscan_add(v) + rcarry;
       float excl = incl - v;
-      rcarry = __shfl(incl, 0, 64);
+      rcarry = wave_bcast(incl, 0);
       if (i < S) {
         const PerSample& s = ps[c];
-        const float dq = excl / q[c];
+        const float dq = excl * CRCP(q[c]);
         const float daocc = (inner[c] >= 0.0f && inner[c] <= 1.0f) ? -dq : 0.0f;
         // alpha_occ = 1 - exp(-relu(raw) gamma dist)
         const float rr = fmaxf(s.raw, 0.0f);
         const float draw = (s.raw > 0.0f) ? daocc * s.E_occ * rc.gamma * s.dist : 0.0f;
         d_gamma += daocc * s.E_occ * rr * s.dist;
         // raw = beta * sg (1 - sg), sg = sigmoid(beta u)
-        const float e = expf(-rc.beta * s.u);
-        const float sg = 1.0f / (1.0f + e);
+        const float e = CEXP(-rc.beta * s.u);
+        const float sg = CRCP(1.0f + e);
         const float ll = sg * (1.0f - sg);
         const float dl = ll * (1.0f - 2.0f * sg);
         float du = draw * rc.beta * rc.beta * dl;
@@ -395,8 +494,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
           const float da = sgn ? dam : dap;
           if (a_raw >= 0.0f && a_raw <= 1.0f) {
             AlphaOut o = sdf2alpha_f(sign * s.u, icv[c], s.dist, rc.inv_s);
-            const float dnum = da / o.den;
-            const float dden = -da * o.num / (o.den * o.den);
+            const float rden = CRCP(o.den);
+            const float dnum = da * rden;
+            const float dden = -da * o.num * rden * rden;
             const float tP = (dnum + dden) * o.P * (1.0f - o.P);
             const float tN = (-dnum) * o.Nx * (1.0f - o.Nx);
             d_invs += tP * o.ep + tN * o.en;
@@ -415,28 +515,28 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
         // gradient-vector adjoint
         float dgx, dgy, dgz;
         if (p.use_norm_grad) {
-          const float gme = s.gm + 1e-5f;
+          const float rg = CRCP(s.gm + 1e-5f);
           const float dotg = dtc * (rc.dx * s.gx + rc.dy * s.gy + rc.dz * s.gz);
-          const float k2 = (s.gm > 0.0f) ? dotg / (s.gm * gme * gme) : 0.0f;
-          dgx = dtc * rc.dx / gme - s.gx * k2;
-          dgy = dtc * rc.dy / gme - s.gy * k2;
-          dgz = dtc * rc.dz / gme - s.gz * k2;
+          const float k2 = (s.gm > 0.0f) ? dotg * CRCP(s.gm) * rg * rg : 0.0f;
+          dgx = dtc * rc.dx * rg - s.gx * k2;
+          dgy = dtc * rc.dy * rg - s.gy * k2;
+          dgz = dtc * rc.dz * rg - s.gz * k2;
         } else {
           dgx = dtc * rc.dx; dgy = dtc * rc.dy; dgz = dtc * rc.dz;
         }
         // normals = sum w * flip * g
         dgx += w[c] * s.flip * dNx; dgy += w[c] * s.flip * dNy; dgz += w[c] * s.flip * dNz;
         // eikonal sums
-        const float pn = sqrtf(s.px * s.px + s.py * s.py + s.pz * s.pz);
+        const float pn = CSQRT(s.px * s.px + s.py * s.py + s.pz * s.pz);
         float dgm = 0.f;
         if (pn < 1.2f) dgm += k_relax * 2.0f * (s.gm - 1.0f);
         if (s.u < 0.05f) dgm += k_near * 2.0f * (s.gm - 1.0f);
         if (s.gm > 0.0f) {
-          const float t = dgm / s.gm;
+          const float t = dgm * CRCP(s.gm);
           dgx += t * s.gx; dgy += t * s.gy; dgz += t * s.gz;
         }
         // sparsity sum
-        du += k_sparse * (-p.sparse_scale) * expf(-p.sparse_scale * s.u);
+        du += k_sparse * (-p.sparse_scale) * CEXP(-p.sparse_scale * s.u);
 
         const size_t b = (size_t)ray * S + i;
         g.o_d_udf[b] = du;
@@ -450,7 +550,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
   __syncthreads();
   if (threadIdx.x < 3 && g.o_d_scal) {
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(g.o_d_scal + threadIdx.x, t);
+    if (g.ws) g.ws[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
+    else atomicAdd(g.o_d_scal + threadIdx.x, t);
   }
 }
 
@@ -476,6 +577,7 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
     case 6: hipLaunchKernelGGL(composite_fwd_kernel<6>, grid, block, 0, st, p); break;
     default: hipLaunchKernelGGL(composite_fwd_kernel<8>, grid, block, 0, st, p); break;
   }
+  if (p.ws) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(256), 0, st, p.ws, (int)grid.x, 5, p.sums);
   NUDF_CHECK_LAUNCH("nudf_composite_fwd");
   return 0;
 }
@@ -500,6 +602,8 @@ extern "C" int nudf_composite_bwd(const NudfComposite* args, const NudfComposite
     case 6: hipLaunchKernelGGL(composite_bwd_kernel<6>, grid, block, 0, st, p, *grads); break;
     default: hipLaunchKernelGGL(composite_bwd_kernel<8>, grid, block, 0, st, p, *grads); break;
   }
+  if (grads->ws && grads->o_d_scal)
+    hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(256), 0, st, grads->ws, (int)grid.x, 3, grads->o_d_scal);
   NUDF_CHECK_LAUNCH("nudf_composite_bwd");
   return 0;
 }

@@ -62,9 +62,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      float zn = __shfl_down(z[c], 1, 64);
-      float zo = (c + 1 < NC) ? __shfl(z[(c + 1 < NC) ? c + 1 : c], 0, 64) : 0.f;
-      if (l == 63) zn = zo;
+      const float zo = (c + 1 < NC) ? wave_bcast(z[(c + 1 < NC) ? c + 1 : c], 0) : 0.f;
+      const float zn = wave_shift_down1(z[c], zo);
       const float dist = (i < M - 1) ? (zn - z[c]) : sdist;
       const float e = expf(-p.beta * u[c]);
       const float raw = p.beta * e / ((1.0f + e) * (1.0f + e)) * gamma;  // udf2logistic(udf, beta, gamma, 1)
@@ -77,10 +76,9 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      float zn = __shfl_down(z[c], 1, 64), un = __shfl_down(u[c], 1, 64), rn = __shfl_down(rad[c], 1, 64);
       const int cn = (c + 1 < NC) ? c + 1 : c;
-      float zo = __shfl(z[cn], 0, 64), uo = __shfl(u[cn], 0, 64), ro = __shfl(rad[cn], 0, 64);
-      if (l == 63) { zn = zo; un = uo; rn = ro; }
+      const float zo = wave_bcast(z[cn], 0), uo = wave_bcast(u[cn], 0), ro = wave_bcast(rad[cn], 0);
+      const float zn = wave_shift_down1(z[c], zo), un = wave_shift_down1(u[c], uo), rn = wave_shift_down1(rad[c], ro);
       const bool sec = i < M - 1;
       dists[c] = sec ? (zn - z[c]) : 0.f;
       midu[c] = (u[c] + un) * 0.5f;
@@ -99,11 +97,10 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
       const float cur = -fabsf(tc[c]);
-      float prev = __shfl_up(cur, 1, 64);
-      float tprev = __shfl_up(tc[c], 1, 64);
       const int cp = (c > 0) ? c - 1 : c;
-      float prev_o = __shfl(-fabsf(tc[cp]), 63, 64), tprev_o = __shfl(tc[cp], 63, 64);
-      if (l == 0) { prev = (c > 0) ? prev_o : 0.0f; tprev = tprev_o; }
+      const float prev_o = wave_bcast(-fabsf(tc[cp]), 63), tprev_o = wave_bcast(tc[cp], 63);
+      const float prev = wave_shift_up1(cur, (c > 0) ? prev_o : 0.0f);
+      const float tprev = wave_shift_up1(tc[c], tprev_o);
       const float inside = cosv[c];
       float cv = fminf(prev, cur);
       cv = fminf(fmaxf(cv, -1e3f), 0.0f) * inside;
@@ -111,9 +108,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
       const float vm = (i == 0) ? 1.0f : ((tprev < 0.05f) ? 1.0f : 0.0f);
       const float q = (i < M) ? (clip01u(1.0f - aocc[c] + vm) + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(q) * carry;
-      float exc = __shfl_up(inc, 1, 64);
-      if (l == 0) exc = carry;
-      carry = __shfl(inc, 63, 64);
+      const float exc = wave_shift_up1(inc, carry);
+      carry = wave_bcast(inc, 63);
       vis[c] = exc;
     }
     carry = 1.0f;
@@ -128,9 +124,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
       }
       const float f = (i < M - 1) ? (1.0f - alpha + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(f) * carry;
-      float exc = __shfl_up(inc, 1, 64);
-      if (l == 0) exc = carry;
-      carry = __shfl(inc, 63, 64);
+      const float exc = wave_shift_up1(inc, carry);
+      carry = wave_bcast(inc, 63);
       w[c] = (i < M - 1) ? alpha * exc : 0.0f;
     }
   }
@@ -151,7 +146,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
     const int i = c * 64 + l;
     const float pdf = w[c] / tot;
     float inc = wave_incl_scan_add(pdf) + scarry;
-    scarry = __shfl(inc, 63, 64);
+    scarry = wave_bcast(inc, 63);
     if (i < M - 1) cdf[i + 1] = inc;
   }
   __builtin_amdgcn_wave_barrier();

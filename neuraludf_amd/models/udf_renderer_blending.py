@@ -65,6 +65,8 @@ class _CompositeFn(torch.autograd.Function):
         wsum = torch.empty(N, 1, device=dev)
         wsum_all = torch.empty(N, 1, device=dev)
         sums = torch.zeros(5, device=dev)
+        ws = torch.empty(5 * ((N + 3) // 4), device=dev)     # per-block partial sums (two-stage reduction)
+        a.ws = ptr(ws)
         a.weights, a.out_color, a.out_color_base = ptr(weights), ptr(out_color), ptr(out_cb)
         a.out_depth, a.out_normals, a.out_wsum, a.out_wsum_all, a.sums = (ptr(depth), ptr(normals), ptr(wsum),
                                                                           ptr(wsum_all), ptr(sums))
@@ -107,6 +109,8 @@ class _CompositeFn(torch.autograd.Function):
         o_sig = torch.empty(N, n_out, device=dev) if n_out else None
         o_bgc = torch.empty(N, n_out, 3, device=dev) if n_out else None
         o_scal = torch.zeros(3, device=dev)
+        ws = torch.empty(3 * ((N + 3) // 4), device=dev)
+        g.ws = ptr(ws)
         g.o_d_udf, g.o_d_grad, g.o_d_color, g.o_d_color_base = ptr(o_udf), ptr(o_grad), ptr(o_col), ptr(o_cb)
         g.o_d_bg_sigma, g.o_d_bg_color, g.o_d_scal = ptr(o_sig), ptr(o_bgc), ptr(o_scal)
         call("nudf_composite_bwd", a, g)
