@@ -11,10 +11,11 @@ Workload (BASELINE.json configs[1]): 512 rays x 128 samples per GPU (64 coarse +
 packed loss all-reduce + one gradient all-reduce per step (weak scaling).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel of the step (the fp32 MFMA layer GEMM `gemm_nn_kernel`):
+  roofline     -- the dominant kernel of the step (the fused fp32 MFMA layer-chain kernel `mlp_chain_kernel`):
                   algorithmic FLOPs of its launches / their summed duration, measured with HIP
                   events on the launch stream during one extra instrumented step; peak = 157.3 TFLOP/s
-                  (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md).
+                  (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); traffic = HBM bytes per launch from the
+                  committed rocprofv3 PMC passes over this command (profiles/r01_traffic_mlp_chain.json).
   roofline_composite -- the fused sample+composite kernels against the 8 TB/s HBM roof
                   (48 B/sample + 68 B/ray forward, 84 B/sample + 68 B/ray backward).
   cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path) timed on this host's
@@ -207,6 +208,7 @@ def main():
                               "algorithmic_gflop_per_step": fl / 1e9}
         result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
                                  "tflops": v[1] / v[2] / 1e12} for k, v in agg.items()}
+        result["roofline"]["traffic"] = pmc_traffic(dom, args.workload)
         # ---- fused composite kernel alone (HBM roof) ----
         try:
             result["roofline_composite"] = composite_roofline(dev, rays_per_gpu, s_core)
@@ -223,12 +225,36 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes over this same command (FETCH_SIZE and
+    WRITE_SIZE, separate passes, scripts/pmc_traffic.sh; committed under profiles/).  rocprofv3 cannot wrap the
+    timed process from inside, so the counters are collected beforehand; corrected as MI355X_MICROARCH.md
+    prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
+    if workload != "dtu_scan24_512x128":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % kernel)
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        f = w = n = 0
+        for name, c in d.items():
+            if kernel not in name:
+                continue
+            f += sum(c["FETCH_SIZE"]["list_KB"]) * c["FETCH_SIZE"]["n"] / max(1, len(c["FETCH_SIZE"]["list_KB"]))
+            w += sum(c["WRITE_SIZE"]["list_KB"]) * c["WRITE_SIZE"]["n"] / max(1, len(c["WRITE_SIZE"]["list_KB"]))
+            n += c["FETCH_SIZE"]["n"]
+        return (2.0 * f + w) * 1024.0 / n if n else None
+    except Exception:
+        return None
+
+
 def composite_roofline(dev, N, S, reps=50):
     """time nudf_composite_fwd / _bwd alone on resident inputs (L2/MALL-resident at this size; the
     larger 8192x256 shape is reported next to it)."""
     from neuraludf_amd.models.udf_renderer_blending import _CompositeFn
     out = {}
-    for (n, s) in [(N, S), (8192, 256)]:
+    for (n, s) in [(N, S), (8192, 256), (32768, 256)]:
         g = torch.Generator(device="cpu").manual_seed(0)
         z = torch.sort(torch.rand(n, s, generator=g) * 2 + 1.5, -1)[0].to(dev)
         ro = torch.randn(n, 3, generator=g).to(dev)

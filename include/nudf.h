@@ -332,6 +332,49 @@ int nudf_mlp_chain(const NudfChain* args, void* stream);
  * out holds roundup(K,16)/8 * roundup(N,32)/32 * 256 floats */
 int nudf_pack_frag(const float* B, int ldb, int K, int N, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-layer weight packing in ONE launch (table by value): weight_norm (W = g v/|v|), the two GEMM layouts
+ * and the MFMA-fragment copies the fused chains read (nudf_pack_frag layout), for up to 16 layers; and the
+ * matching multi-layer backward of the packing.  Same arithmetic as nudf_weightnorm_pack / _unpack_grad
+ * (torch.nn.utils.weight_norm at fields.py:175-176, 433-446).
+ * ---------------------------------------------------------------------------------- */
+#define NUDF_PACK_MAX_LAYERS 16
+#define NUDF_PACK_MAX_FRAGS 3
+typedef struct NudfPackFrag {
+  float* dst;                      /* fragment-ordered [K, N] operand (zero-initialised by the caller once)     */
+  int32_t transpose;               /* 1: B[k][n] = W[o0 + n][i0 + k] (W^T, forward sweeps); 0: B[k][n] = W[o0 + k][i0 + n] */
+  int32_t o0, i0;                  /* offsets into the packed [out, in] matrix                                  */
+  int32_t K, N;
+  int32_t pad_;
+} NudfPackFrag;
+typedef struct NudfPackLayer {
+  const float* v; const float* g;  /* weight_v [out,in], weight_g [out] (NULL: plain Linear)                    */
+  const int32_t* perm;             /* input-column permutation or NULL                                          */
+  float* W; float* Wt;             /* [out_pad, ldw], [in_pad, ldwt] (either may be NULL)                       */
+  float* inv_norm;                 /* [out] 1/|v_row| (kept for the backward) or NULL                           */
+  int32_t out, in, ldw, ldwt;
+  int32_t nfrag, row_start;        /* row_start: prefix sum of `out` over the preceding layers                  */
+  NudfPackFrag frag[NUDF_PACK_MAX_FRAGS];
+} NudfPackLayer;
+typedef struct NudfPackMulti {
+  int32_t n_layers, total_rows;
+  NudfPackLayer layer[NUDF_PACK_MAX_LAYERS];
+} NudfPackMulti;
+int nudf_weightnorm_pack_multi(const NudfPackMulti* args, void* stream);
+
+typedef struct NudfUnpackLayer {
+  const float* dW;                 /* [out_pad, ldw] packed weight gradient                                     */
+  const float* v; const float* g; const float* inv_norm;
+  const int32_t* perm;
+  float* dv; float* dg;            /* [out,in], [out] (dg NULL for a plain Linear)                              */
+  int32_t out, in, ldw, row_start;
+} NudfUnpackLayer;
+typedef struct NudfUnpackMulti {
+  int32_t n_layers, total_rows;
+  NudfUnpackLayer layer[NUDF_PACK_MAX_LAYERS];
+} NudfUnpackMulti;
+int nudf_weightnorm_unpack_grad_multi(const NudfUnpackMulti* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

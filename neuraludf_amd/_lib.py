@@ -118,6 +118,33 @@ class Chain(C.Structure):
                 ("seed_wrow", c_fp), ("dbg", c_fp), ("step", ChainStep * CH_MAX_STEPS)]
 
 
+PACK_MAX_LAYERS = 16
+PACK_MAX_FRAGS = 3
+
+
+class PackFrag(C.Structure):
+    _fields_ = [("dst", c_fp), ("transpose", i32), ("o0", i32), ("i0", i32), ("K", i32), ("N", i32), ("pad_", i32)]
+
+
+class PackLayer(C.Structure):
+    _fields_ = [("v", c_fp), ("g", c_fp), ("perm", c_fp), ("W", c_fp), ("Wt", c_fp), ("inv_norm", c_fp),
+                ("out", i32), ("in_", i32), ("ldw", i32), ("ldwt", i32), ("nfrag", i32), ("row_start", i32),
+                ("frag", PackFrag * PACK_MAX_FRAGS)]
+
+
+class PackMulti(C.Structure):
+    _fields_ = [("n_layers", i32), ("total_rows", i32), ("layer", PackLayer * PACK_MAX_LAYERS)]
+
+
+class UnpackLayer(C.Structure):
+    _fields_ = [("dW", c_fp), ("v", c_fp), ("g", c_fp), ("inv_norm", c_fp), ("perm", c_fp), ("dv", c_fp),
+                ("dg", c_fp), ("out", i32), ("in_", i32), ("ldw", i32), ("row_start", i32)]
+
+
+class UnpackMulti(C.Structure):
+    _fields_ = [("n_layers", i32), ("total_rows", i32), ("layer", UnpackLayer * PACK_MAX_LAYERS)]
+
+
 EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
            SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11, MULSP=12)
 
@@ -131,6 +158,7 @@ SYMBOLS = [
     "nudf_pixel_blend_fwd", "nudf_pixel_blend_bwd", "nudf_pixel_composite_fwd", "nudf_pixel_composite_bwd",
     "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch",
     "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
+    "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -164,6 +192,8 @@ _ARGTYPES = {
     "nudf_adam_step": [C.POINTER(Adam), _P],
     "nudf_mlp_chain": [C.POINTER(Chain), _P],
     "nudf_pack_frag": [_P, _I, _I, _I, _P, _P],
+    "nudf_weightnorm_pack_multi": [C.POINTER(PackMulti), _P],
+    "nudf_weightnorm_unpack_grad_multi": [C.POINTER(UnpackMulti), _P],
 }
 
 _lib = None

@@ -387,3 +387,92 @@ extern "C" int nudf_weightnorm_unpack_grad(const float* dW, int ldw, const float
   NUDF_CHECK_LAUNCH("nudf_weightnorm_unpack_grad");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// multi-layer versions (one launch per network): table by value, one wave per (layer, output row)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void frag_store(const NudfPackFrag& f, int o, int c, float w) {
+  // element (o, c) of the packed [out, in] matrix -> its slot in the fragment-ordered operand
+  const int k = f.transpose ? (c - f.i0) : (o - f.o0);
+  const int n = f.transpose ? (o - f.o0) : (c - f.i0);
+  if (k < 0 || n < 0 || k >= f.K || n >= f.N) return;
+  const int NT = (f.N + 31) >> 5;
+  const int g = k >> 3, r = k & 7;
+  const int lane = 32 * (r >> 2) + (n & 31);
+  f.dst[((size_t)(g * NT + (n >> 5)) * 64 + lane) * 4 + (r & 3)] = w;
+}
+
+__global__ __launch_bounds__(256) void wn_pack_multi_kernel(NudfPackMulti a) {
+  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow >= a.total_rows) return;
+  int li = 0;
+  while (li + 1 < a.n_layers && a.layer[li + 1].row_start <= grow) ++li;
+  const NudfPackLayer& L = a.layer[li];
+  const int row = grow - L.row_start;
+  const int l = threadIdx.x & 63;
+  float sc = 1.0f;
+  if (L.g) {
+    float ss = 0.f;
+    for (int i = l; i < L.in; i += 64) {
+      const float t = L.v[(size_t)row * L.in + i];
+      ss += t * t;
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss);
+    if (l == 0 && L.inv_norm) L.inv_norm[row] = inv;
+    sc = L.g[row] * inv;
+  }
+  for (int i = l; i < L.in; i += 64) {
+    const int c = L.perm ? L.perm[i] : i;
+    const float w = L.v[(size_t)row * L.in + i] * sc;
+    if (L.W) L.W[(size_t)row * L.ldw + c] = w;
+    if (L.Wt) L.Wt[(size_t)c * L.ldwt + row] = w;
+    for (int f = 0; f < L.nfrag; ++f) frag_store(L.frag[f], row, c, w);
+  }
+}
+extern "C" int nudf_weightnorm_pack_multi(const NudfPackMulti* args, void* stream) {
+  if (args->n_layers <= 0 || args->total_rows <= 0) return 0;
+  if (args->n_layers > NUDF_PACK_MAX_LAYERS) {
+    nudf_set_error("nudf_weightnorm_pack_multi: too many layers", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(wn_pack_multi_kernel, dim3((args->total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+  NUDF_CHECK_LAUNCH("nudf_weightnorm_pack_multi");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void wn_unpack_multi_kernel(NudfUnpackMulti a) {
+  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow >= a.total_rows) return;
+  int li = 0;
+  while (li + 1 < a.n_layers && a.layer[li + 1].row_start <= grow) ++li;
+  const NudfUnpackLayer& L = a.layer[li];
+  const int row = grow - L.row_start;
+  const int l = threadIdx.x & 63;
+  if (!L.g) {
+    for (int i = l; i < L.in; i += 64)
+      L.dv[(size_t)row * L.in + i] = L.dW[(size_t)row * L.ldw + (L.perm ? L.perm[i] : i)];
+    return;
+  }
+  float dot = 0.f;
+  for (int i = l; i < L.in; i += 64)
+    dot += L.dW[(size_t)row * L.ldw + (L.perm ? L.perm[i] : i)] * L.v[(size_t)row * L.in + i];
+  dot = wave_sum(dot);
+  const float inv = L.inv_norm[row];
+  const float gg = L.g[row];
+  if (l == 0) L.dg[row] = dot * inv;
+  const float c1 = gg * inv, c2 = gg * inv * inv * inv * dot;
+  for (int i = l; i < L.in; i += 64)
+    L.dv[(size_t)row * L.in + i] =
+        c1 * L.dW[(size_t)row * L.ldw + (L.perm ? L.perm[i] : i)] - c2 * L.v[(size_t)row * L.in + i];
+}
+extern "C" int nudf_weightnorm_unpack_grad_multi(const NudfUnpackMulti* args, void* stream) {
+  if (args->n_layers <= 0 || args->total_rows <= 0) return 0;
+  if (args->n_layers > NUDF_PACK_MAX_LAYERS) {
+    nudf_set_error("nudf_weightnorm_unpack_grad_multi: too many layers", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(wn_unpack_multi_kernel, dim3((args->total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+  NUDF_CHECK_LAUNCH("nudf_weightnorm_unpack_grad_multi");
+  return 0;
+}

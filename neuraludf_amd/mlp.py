@@ -220,6 +220,16 @@ class PackedLinear:
             return [self.lin.weight_v, self.lin.weight_g, self.lin.bias]
         return [self.lin.weight, self.lin.bias]
 
+    def _ensure_buffers(self, dev):
+        if self.W is None or self.W.device != dev:
+            self.W = torch.zeros(self.out_pad, self.in_pad, device=dev)
+            self.Wt = torch.zeros(self.in_pad, self.out_pad, device=dev)
+            self.inv_norm = torch.empty(self.out, device=dev)
+            self.Wt.k_true, self.W.k_true = self.inp, self.out      # unpadded reduction lengths (flop accounting)
+            self._frags = {}
+            if self._perm_list is not None:
+                self.perm = torch.tensor(self._perm_list, dtype=torch.int32, device=dev)
+
     def pack(self):
         """(re)pack if the parameters changed; returns self."""
         ps = self.params()
@@ -291,6 +301,106 @@ class PackedLinear:
         return [dv, db]
 
 
+def _frag_spec(pl, kind):
+    """(transpose, o0, i0, K, N) of a fragment-ordered operand cut from the packed [out, in] matrix."""
+    if kind == "fwd":
+        return (1, 0, 0, pl.inp, pl.out)
+    if kind == "bwd":
+        return (0, 0, 0, pl.out, pl.inp)
+    if kind == "fwd_head0":
+        return (1, 0, 0, pl.inp, 1)
+    if kind == "fwd_feat":
+        return (1, 1, 0, pl.inp, pl.out - 1)
+    if kind == "bwd_feat":
+        return (0, 1, 0, pl.out - 1, pl.inp)
+    if kind.startswith("bwd_hid:"):
+        return (0, 0, 0, pl.out, int(kind.split(":")[1]))
+    raise KeyError(kind)
+
+
+def pack_group(layers, kinds=None):
+    """(re)pack every layer of a network in ONE launch if any parameter changed: weight_norm, W / W^T and the
+    fragment-ordered copies named in `kinds` (one tuple of kinds per layer)."""
+    kinds = kinds or [()] * len(layers)
+    dev = layers[0].params()[0].device
+    stale = False
+    for pl, ks in zip(layers, kinds):
+        ps = pl.params()
+        ver = tuple((p.data_ptr(), p._version) for p in ps[:-1])
+        if ver != pl._ver or pl.W is None or pl.W.device != dev or any(k not in pl._frags for k in ks):
+            stale = True
+        pl._new_ver = ver
+    if not stale:
+        return
+    for base in range(0, len(layers), _lib.PACK_MAX_LAYERS):
+        chunk = layers[base:base + _lib.PACK_MAX_LAYERS]
+        a = _lib.PackMulti()
+        rows = 0
+        keep = []
+        for li, pl in enumerate(chunk):
+            ks = kinds[base + li]
+            if len(ks) > _lib.PACK_MAX_FRAGS:
+                raise _lib.NudfError("too many fragment copies for one layer")
+            pl._ensure_buffers(dev)
+            ps = pl.params()
+            v = ps[0].detach().contiguous()
+            g = ps[1].detach().contiguous() if pl.weight_norm else None
+            keep += [v, g]
+            L = a.layer[li]
+            L.v, L.g, L.perm = ptr(v), ptr(g), ptr(pl.perm)
+            L.W, L.Wt, L.inv_norm = ptr(pl.W), ptr(pl.Wt), ptr(pl.inv_norm)
+            L.out, L.in_, L.ldw, L.ldwt = pl.out, pl.inp, pl.in_pad, pl.out_pad
+            L.nfrag, L.row_start = len(ks), rows
+            for fi, kind in enumerate(ks):
+                tr, o0, i0, K, N = _frag_spec(pl, kind)
+                f = pl._frags.get(kind)
+                if f is None:
+                    f = torch.zeros(k8(K) // 8 * ((N + 31) // 32) * 256, device=dev, dtype=torch.float32)
+                    f.k_true, f.n_true = K, N
+                    pl._frags[kind] = f
+                F = L.frag[fi]
+                F.dst, F.transpose, F.o0, F.i0, F.K, F.N = ptr(f), tr, o0, i0, K, N
+            rows += pl.out
+        a.n_layers, a.total_rows = len(chunk), rows
+        call("nudf_weightnorm_pack_multi", a)
+        del keep
+    for pl in layers:
+        pl._ver = pl._new_ver
+
+
+def unpack_group(layers, grads):
+    """packed (dW, db) per layer -> parameter gradients in params() order, ONE launch per <= 16 layers."""
+    out_per_layer = []
+    for base in range(0, len(layers), _lib.PACK_MAX_LAYERS):
+        chunk = layers[base:base + _lib.PACK_MAX_LAYERS]
+        a = _lib.UnpackMulti()
+        rows = 0
+        keep = []
+        for li, pl in enumerate(chunk):
+            dW, db = grads[base + li]
+            ps = pl.params()
+            v = ps[0].detach().contiguous()
+            dv = torch.empty_like(v)
+            L = a.layer[li]
+            L.dW, L.v, L.perm, L.dv = ptr(dW), ptr(v), ptr(pl.perm), ptr(dv)
+            L.out, L.in_, L.ldw, L.row_start = pl.out, pl.inp, pl.in_pad, rows
+            if pl.weight_norm:
+                g = ps[1].detach().contiguous()
+                dg = torch.empty_like(g)
+                L.g, L.inv_norm, L.dg = ptr(g), ptr(pl.inv_norm), ptr(dg)
+                out_per_layer.append([dv, dg, db])
+                keep += [v, g]
+            else:
+                out_per_layer.append([dv, db])
+                keep += [v]
+            rows += pl.out
+        a.n_layers, a.total_rows = len(chunk), rows
+        call("nudf_weightnorm_unpack_grad_multi", a)
+        del keep
+    return [t for lay in out_per_layer for t in lay]
+
+
+
 # =========================================================================================
 # UDF network
 # =========================================================================================
@@ -346,6 +456,18 @@ class UDFEngine:
             return self._backward_chain(x, st, DA, d_udf, d_feat, d_feat_ld, d_g)
         return self._backward_layers(x, st, DA, d_udf, d_feat, d_feat_ld, d_g)
 
+    def _frag_kinds(self):
+        """fragment-ordered weight copies each layer needs for the four sweeps."""
+        kinds = []
+        for l, pl in enumerate(self.layers):
+            if l == self.L:
+                kinds.append(("fwd_head0", "fwd_feat", "bwd_feat"))
+            elif l in self.skip:
+                kinds.append(("fwd", "bwd", "bwd_hid:%d" % self.layers[l - 1].out))
+            else:
+                kinds.append(("fwd", "bwd"))
+        return kinds
+
     def _skip_col(self, l):
         """tile column where PE(x)/sqrt(2) starts in the input of skip layer l."""
         return self.layers[l].inp - self.E
@@ -354,8 +476,7 @@ class UDFEngine:
         """one launch: posenc -> 8 softplus layers -> abs head, activations resident in LDS."""
         P, dev, L = x.shape[0], x.device, self.L
         net = self.net
-        for pl in self.layers:
-            pl.pack()
+        pack_group(self.layers, self._frag_kinds())
         X = [_buf(P, pl.inp, dev, zero=False) for pl in self.layers] if need_grad_state else None
         cb = ChainBuilder(P, "POSENC", k8(self.E))
         cb.posenc(x, net.multires, float(net.scale))
@@ -467,15 +588,13 @@ class UDFEngine:
                 cb.step("BWD", pl.frag("bwd" if n_hid == pl.inp else "bwd_hid:%d" % n_hid), k8(pl.out), n_hid, X1=X[l],
                         X2=EX[l - 1] if second else None, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
         cb.launch()
-        out = []
         for l, pl in enumerate(layers):
             dW, db = grads[l]
             if second and l < L:
                 gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db, A2=DA[l], na2=pl.out, B2=R[l])
             else:
                 gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db)
-            out += pl.unpack_grads(dW, db)
-        return out
+        return unpack_group(layers, grads)
 
     def _forward_layers(self, x, need_grad_state, feat_ld=0, udf_only=False):
         """per-layer GEMM launches.  x [P,3] -> dict(udf [P], sign [P], feat [P, max(feat_ld, F)], state...).
@@ -483,8 +602,7 @@ class UDFEngine:
         P = x.shape[0]
         dev = x.device
         L = self.L
-        for pl in self.layers:
-            pl.pack()
+        pack_group(self.layers)
         X = [_buf(P, pl.inp, dev) for pl in self.layers]
         self._embed(x, P, X)
         for l in range(L):
@@ -645,8 +763,7 @@ class ColorEngine:
         """CIN [P, pad(F+3)] = [feature F | pts 3 | 0] (written by the UDF head + nudf_copy_cols)."""
         dev = CIN.device
         n = self.n
-        for pl in self.base + self.view:
-            pl.pack()
+        pack_group(self.base + self.view)
         VIN = _zero_cols(torch.empty(P, pad32(self.H + self.npe + self.dout), device=dev), self.H + self.npe + self.dout)
         # PE(view_dirs) (fields.py:453-454); directions are per ray -> xdiv = S
         call("nudf_posenc", ptr(rays_d), 3, S, None, 3, self.net.multires_view, 1.0, P,
@@ -695,10 +812,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (self.H + self.npe), dVIN.shape[1],
              self.dout, None, 0, 0, P, ptr(Db), Db.shape[1])
         gb, dCIN = relu_chain_bwd(self.base, HB, HB[1:], Db, P, True, add_at={n - 2: (dVIN, dVIN.shape[1], 0)})
-        out = []
-        for pl, (dW, db) in zip(self.view + self.base, gv + gb):
-            out += pl.unpack_grads(dW, db)
-        return out, dCIN[:P]
+        return unpack_group(self.view + self.base, gv + gb), dCIN[:P]
 
 
 class NerfEngine:
@@ -738,8 +852,7 @@ class NerfEngine:
 
     def forward(self, pts4, rays_d, S, P, keep_state=True):
         dev = pts4.device
-        for pl in self._all():
-            pl.pack()
+        pack_group(self._all())
         Hin = [_buf(P, pl.inp, dev) for pl in self.pts]
         skip_layers = [i + 1 for i in sorted(self.skips) if i + 1 < self.D]
         d2 = Hin[skip_layers[0]] if skip_layers else None
@@ -798,7 +911,4 @@ class NerfEngine:
         gemm_nn(dVIN, self.feature.W, P, self.W, self.feature.out_pad, "ADDMASK", C1=Dh, X1=outs[-1],
                 ldx1=outs[-1].shape[1], X2=T1)
         gp, _ = relu_chain_bwd(self.pts, Hin, outs, Dh, P, False)
-        out = []
-        for pl, (dW, db) in zip(self._all(), gp + [g_views, g_feat, g_alpha, g_rgb]):
-            out += pl.unpack_grads(dW, db)
-        return out
+        return unpack_group(self._all(), gp + [g_views, g_feat, g_alpha, g_rgb])

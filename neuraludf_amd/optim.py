@@ -85,6 +85,9 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is not None:
                     self.state[p]["step"] += 1
+                    # the kernel wrote through a raw pointer: tell autograd (and every cache keyed on the version
+                    # counter, e.g. the packed weights of mlp.PackedLinear) that the tensor changed
+                    torch.autograd.graph.increment_version(p)
         return loss
 
     def _fill_groups(self, a):

@@ -42,3 +42,28 @@ def test_fused_adam_matches_torch_adam():
     ref2.load_state_dict(sd)
     assert int(ref2.state[ref2.param_groups[0]["params"][0]]["step"]) == 12
     assert int(ref2.state[ref2.param_groups[1]["params"][0]]["step"]) == 8
+
+
+def test_fused_adam_invalidates_packed_weight_cache():
+    """the optimizer writes parameters through raw pointers; the engines' packed-weight caches are keyed on the
+    tensors' version counters, so a stale cache would silently freeze the network."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from common import build_modules, perturb_
+    from neuraludf_amd.models import fields
+    from neuraludf_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    mods = perturb_(build_modules(fields, seed=0))
+    udf = mods["udf"].to(dev)
+    x = (torch.rand(300, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+    opt = FusedAdam(udf.parameters(), lr=1e-2)
+    y0 = udf(x).detach().clone()
+    for p in udf.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    y1 = udf(x).detach()
+    assert float((y1 - y0).abs().max()) > 1e-4, "forward did not see the updated parameters"
+    fresh = build_modules(fields, seed=0)["udf"].to(dev)
+    fresh.load_state_dict(udf.state_dict())
+    y2 = fresh(x).detach()
+    assert float((y1 - y2).abs().max()) <= 1e-6 * max(1.0, float(y2.abs().max()))
