@@ -1,0 +1,161 @@
+"""BASELINE.json configurations at FULL size on the GPU, checked through size-independent properties of the
+domain (the CPU oracle would take minutes at these sizes): sample positions stay sorted and inside the ray
+segment, compositing weights form a sub-probability, colours are convex combinations, the composite is linear
+in the colours, merging is a sorted permutation, forward results are run-to-run identical, every parameter
+receives a finite gradient, and a few optimiser steps on a fixed batch reduce the loss."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG2 = dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)           # 512 x 128
+CFG_DTU = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, perturb=1.0)       # shipped DTU conf
+CFG3 = dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
+            use_norm_grad_for_cosine=True, h_patch_size=3)                                        # 1024 x 128, blending
+CFG5 = dict(n_samples=128, n_importance=128, n_outside=0, up_sample_steps=4, perturb=1.0)         # 1024 x 256 per GPU
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _trainer(dev, rconf, **kw):
+    from neuraludf_amd.train import Trainer
+    tr = Trainer(dev, rconf, seed=0, **kw)
+    tr.renderer.diagnostics = True
+    return tr
+
+
+def _batch(dev, kind, n, seed=1234, margin=0):
+    from neuraludf_amd import synth
+    scene = synth.make_scene(kind)
+    rays = synth.make_rays(scene, 0, n, seed=seed, margin=margin)
+    return scene, {k: v.to(dev) for k, v in rays.items()}
+
+
+def _check_render_invariants(out, batch, n_in, n_out):
+    z = out["z_vals"]
+    assert z.shape[1] == n_in
+    assert bool((z[:, 1:] >= z[:, :-1]).all()), "sample positions must stay sorted"
+    assert bool((z >= batch["near"] - 0.05).all()) and bool((z <= batch["far"] + 0.05).all())
+    w = out["weights"]
+    assert w.shape[1] == n_in + n_out
+    assert bool(torch.isfinite(w).all())
+    assert float(w.min()) >= 0.0 and float(w.max()) <= 1.0 + 1e-6
+    assert float(out["weight_sum_fg_bg"].max()) <= 1.0 + 1e-4, "weights form a sub-probability"
+    for k in ("color", "color_base"):
+        c = out[k]
+        assert bool(torch.isfinite(c).all())
+        if n_out == 0:   # sigmoid colours, convex combination (the background NeRF has no sigmoid on rgb)
+            assert float(c.min()) >= -1e-6 and float(c.max()) <= 1.0 + 1e-4
+    assert bool((out["udf"] >= 0).all()), "abs head"
+    for k in ("gradient_error", "gradient_error_near_surface", "sparse_error"):
+        assert bool(torch.isfinite(out[k]).all())
+
+
+@pytest.mark.parametrize("name,rconf,n_rays", [("cfg2", CFG2, 512), ("dtu_shipped", CFG_DTU, 512), ("cfg5", CFG5, 1024)])
+def test_full_size_render_invariants_and_gradients(dev, name, rconf, n_rays):
+    tr = _trainer(dev, rconf)
+    _, batch = _batch(dev, "dtu", n_rays)
+    loss, out = tr.loss(batch, cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
+    n_in = rconf["n_samples"] + rconf["n_importance"]
+    _check_render_invariants(out, batch, n_in, rconf["n_outside"])
+    loss.backward()
+    torch.cuda.synchronize()
+    for mod_name, m in tr.modules().items():
+        if mod_name == "nerf" and rconf["n_outside"] == 0:
+            continue
+        for n, p in m.named_parameters():
+            if not p.requires_grad:
+                continue
+            assert p.grad is not None, (mod_name, n)
+            assert bool(torch.isfinite(p.grad).all()), (mod_name, n)
+    assert float(sum(p.grad.abs().sum() for p in tr.udf.parameters())) > 0
+    # forward is run-to-run identical (no atomics on the forward path)
+    with torch.no_grad():
+        _, out2 = tr.loss(batch, cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
+    assert torch.equal(out["z_vals"], out2["z_vals"])
+    assert torch.equal(out["color"].detach(), out2["color"])
+    assert torch.equal(out["weights"].detach(), out2["weights"])
+
+
+def test_cfg3_blending_full_size(dev):
+    """1024 rays x 128 samples (mix schedule), pixel + patch blending over 8 source views of 1024 x 1024."""
+    from neuraludf_amd import synth
+    lc = dict(color_pixel_weight=0.5, color_patch_weight=0.1)
+    tr = _trainer(dev, CFG3, color_loss_conf=lc)
+    scene, batch = _batch(dev, "garment", 1024, margin=8)
+    src = synth.make_source_views(scene, 0, 8)
+    blend = {k: v.to(dev) for k, v in src.items()}
+    g = torch.Generator().manual_seed(5)
+    batch["gt_patch_colors"] = torch.rand(1024, 49, 3, generator=g).to(dev)
+    loss, out = tr.loss(batch, blend=blend, perturb_overwrite=0)
+    _check_render_invariants(out, batch, out["z_vals"].shape[1], 0)
+    assert out["color_pixel"].shape == (1024, 3) and out["patch_colors"].shape == (1024, 49, 3)
+    assert bool(torch.isfinite(out["color_pixel"]).all()) and bool(torch.isfinite(out["patch_colors"]).all())
+    # source images are U[0,1): blended colours are convex combinations scaled by weights that sum to <= 1
+    assert float(out["color_pixel"].min()) >= -1e-5 and float(out["color_pixel"].max()) <= 1.0 + 1e-4
+    assert float(out["patch_colors"].min()) >= -1e-5 and float(out["patch_colors"].max()) <= 1.0 + 1e-4
+    loss.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss))
+    for n, p in tr.color.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+def test_composite_is_linear_in_colours_at_8192x256(dev):
+    from neuraludf_amd.models.udf_renderer_blending import _CompositeFn
+    n, s = 8192, 256
+    g = torch.Generator().manual_seed(0)
+    z = torch.sort(torch.rand(n, s, generator=g) * 2 + 1.5, -1)[0].to(dev)
+    ro = torch.randn(n, 3, generator=g).to(dev)
+    rd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    udf = (torch.rand(n, s, generator=g) * 0.3).to(dev)
+    grad = torch.randn(n, s, 3, generator=g).to(dev)
+    c1, c2 = torch.rand(n, s, 3, generator=g).to(dev), torch.rand(n, s, 3, generator=g).to(dev)
+    scal = torch.tensor([64.0, 128.0, 20.0], device=dev)
+    sd = torch.tensor([2.0 / 64], device=dev)
+    c = dict(s_nominal=s, cos_anneal=1.0, flip_saturation=1.0, use_norm_grad=False, sparse_scale=25000.0,
+             diagnostics=False)
+
+    def comp(col):
+        with torch.no_grad():
+            return _CompositeFn.apply(c, ro, rd, z, sd, None, udf, grad, col, col, None, None, None, scal)
+    a, b = 0.3, 1.7
+    o1, o2, o12 = comp(c1), comp(c2), comp(a * c1 + b * c2)
+    assert float((o12[0] - (a * o1[0] + b * o2[0])).abs().max()) < 2e-5
+    assert torch.equal(o1[2], o2[2]), "weights do not depend on the colours"
+    w = o1[2]
+    assert float(w.min()) >= 0 and float(w.sum(-1).max()) <= 1.0 + 1e-4
+    # checksum of checksums: sum over rays of the composited colour == <weights, colours>
+    assert abs(float(o1[0].double().sum()) - float((w[..., None].double() * c1.double()).sum())) < 1e-3 * n
+
+
+def test_merge_is_a_sorted_permutation_at_4096_rays(dev):
+    from neuraludf_amd._lib import call, ptr
+    n, m, k = 4096, 128, 32
+    g = torch.Generator().manual_seed(3)
+    za = torch.sort(torch.rand(n, m, generator=g), -1)[0].to(dev)
+    zb = torch.sort(torch.rand(n, k, generator=g), -1)[0].to(dev)
+    ua, ub = torch.rand(n, m, generator=g).to(dev), torch.rand(n, k, generator=g).to(dev)
+    zo, uo = torch.empty(n, m + k, device=dev), torch.empty(n, m + k, device=dev)
+    call("nudf_merge", ptr(za), ptr(ua), ptr(zb), ptr(ub), n, m, k, ptr(zo), ptr(uo))
+    ref, idx = torch.sort(torch.cat([za, zb], -1), dim=-1, stable=True)
+    assert torch.equal(zo, ref)
+    assert torch.equal(uo, torch.gather(torch.cat([ua, ub], -1), 1, idx))
+    # idempotence: merging with nothing new changes nothing beyond the K duplicated entries
+    assert abs(float(zo.double().sum()) - float(za.double().sum() + zb.double().sum())) < 1e-6 * n * (m + k)
+
+
+def test_a_few_fused_adam_steps_reduce_the_loss(dev):
+    tr = _trainer(dev, CFG2, fused_adam=True)
+    tr.renderer.diagnostics = False
+    _, batch = _batch(dev, "dtu", 512)
+    losses = []
+    for _ in range(8):
+        l, _ = tr.step(batch, perturb_overwrite=0)
+        losses.append(float(l))
+    assert all(x == x for x in losses)
+    assert losses[-1] < losses[0], losses

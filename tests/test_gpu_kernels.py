@@ -138,6 +138,37 @@ def test_udf_forward_gradient_and_param_grads(dev, nets):
         assert rel(net.udf_only(x.to(dev)), y_ref[:, 0]) < VTOL
 
 
+@pytest.mark.parametrize("mode", ["chain64", "layers"])
+def test_udf_other_paths_match_the_default(dev, nets, mode):
+    """the 64-point-tile chain kernel (used for P > 16 k) and the per-layer GEMM path against the default
+    (32-point tiles at this size, itself checked against the oracle above)."""
+    from neuraludf_amd import mlp
+    mods, _ = nets
+    eng = mods["udf"].engine()
+    g = torch.Generator().manual_seed(9)
+    P = 1000
+    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    d_udf, d_feat, d_g = (torch.randn(P, generator=g).to(dev), torch.randn(P, 288, generator=g).to(dev),
+                          torch.randn(P, 3, generator=g).to(dev))
+
+    def run():
+        st = eng.forward(x, True, 288)
+        gr, DA = eng.gradient(x, st)
+        grads = eng.backward(x, st, DA, d_udf, d_feat, 288, d_g)
+        return [st["udf"], st["feat"][:, :256], gr] + list(grads)
+    ref = run()
+    try:
+        if mode == "chain64":
+            mlp.CHAIN_TILE = 64
+        else:
+            mlp.USE_CHAIN = False
+        got = run()
+    finally:
+        mlp.CHAIN_TILE, mlp.USE_CHAIN = 0, True
+    for a, b in zip(got, ref):
+        assert rel(a, b) < 2e-5
+
+
 def test_color_network(dev, nets):
     mods, sds = nets
     g = torch.Generator().manual_seed(4)
