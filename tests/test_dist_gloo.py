@@ -73,7 +73,6 @@ def _worker(rank, world, port, ret):
         loss = l1 + 0.1 * ge + 0.05 * gens + 0.01 * sp + 0.5 * lp
         loss.backward()
         bucket = nd.GradBucket([theta])
-        bucket.flat = bucket.flat.double()
         bucket.all_reduce()
         ret[rank] = (float(loss), theta.grad.clone())
     finally:
