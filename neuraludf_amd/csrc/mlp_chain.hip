@@ -83,16 +83,27 @@ __device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& 
 // K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
 // the body, so the compiler's s_waitcnt counters let the NEXT group's LDS / L2 reads stay in flight under the
 // current group's 4*NRT*NCT MFMAs.  G (groups of 8 k) is even; the last prefetch re-reads the last group.
-template <int NRT, int NCT>
+#define CH_KOFF(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// Stored-activation operand of the epilogue (X1), fetched for ALL tiles of the wave while the last two k groups
+// are still being multiplied: the HBM latency of the epilogue operands then hides under MFMAs instead of
+// sitting between the barrier and the first epilogue instruction.
+struct ChPrefetch {
+  const float* X1;
+  int ldx1;
+  unsigned vo[2][2];   // per-lane element offset of (row tile i, col tile j), r = 0
+};
+
+template <int NRT, int NCT, bool PF>
 __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32x4* __restrict__ bptr, size_t bstride,
-                                       int G, f32x16 (&acc)[2][2]) {
+                                       int G, f32x16 (&acc)[2][2], const ChPrefetch& pf, float (&px1)[2][2][16]) {
   f32x4 a0[NRT], a1[NRT], b0[NCT], b1[NCT];
 #pragma unroll
   for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD);
 #pragma unroll
   for (int j = 0; j < NCT; ++j) b0[j] = bptr[j * 64];
 #pragma unroll 1
-  for (int g = 0; g < G; g += 2) {
+  for (int g = 0; g < G - 2; g += 2) {
     {
       const f32x4* bq = bptr + (size_t)(g + 1) * bstride;
 #pragma unroll
@@ -109,12 +120,11 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
         for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(a0[i][jj], b0[j][jj], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
     {
-      const int gn = (g + 2 < G) ? g + 2 : g;
-      const f32x4* bq = bptr + (size_t)gn * bstride;
+      const f32x4* bq = bptr + (size_t)(g + 2) * bstride;
 #pragma unroll
       for (int j = 0; j < NCT; ++j) b0[j] = bq[j * 64];
 #pragma unroll
-      for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + gn * 8);
+      for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + (g + 2) * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -125,6 +135,38 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
         for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(a1[i][jj], b1[j][jj], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // last two groups (G is even): no further weight prefetch; the epilogue operands are issued AFTER the last
+  // weight loads so that the in-order vmcnt lets them stay in flight under the remaining MFMAs
+  {
+    const f32x4* bq = bptr + (size_t)(G - 1) * bstride;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) b1[j] = bq[j * 64];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) a1[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + (G - 1) * 8);
+    if (PF) {
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) px1[i][j][r] = (pf.X1 + (size_t)CH_KOFF(r) * pf.ldx1)[pf.vo[i][j]];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(a0[i][jj], b0[j][jj], acc[i][j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(a1[i][jj], b1[j][jj], acc[i][j]);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
@@ -132,10 +174,9 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
 // around whole 16-element loops, the column predicate (N may end inside the tile) is one exec region, rows
 // need no predicate because every output / operand buffer is row-padded to the tile size (see nudf.h).
 // Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
-#define CH_KOFF(r) (((r) & 3) + 8 * ((r) >> 2))
 template <int EPI>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
-                                                 int h, int ln, f32x16 a) {
+                                                 int h, int ln, f32x16 a, const float (&x1)[16]) {
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -153,12 +194,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo] * r1c;
   }
-  float x1[16], x2[16];
-  if (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD) {
-    const unsigned vo = grow0 * (unsigned)st.ldx1 + colc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
-  }
+  float x2[16];   // x1 (the stored activation) was prefetched under the K loop
   if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD) {
     if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
@@ -242,19 +278,48 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
 template <int EPI>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
-                                            int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2]) {
+                                            int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
+                                            const float (&px1)[2][2][16]) {
+  constexpr bool PF = (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD);
   const int ntiles = nrt * nct;
 #pragma unroll 1
   for (int t = 0; t < ntiles; ++t) {
     const int i = (nct == 2) ? (t >> 1) : t, j = (nct == 2) ? (t & 1) : 0;
     f32x16 a;
+    float x1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x1[r] = 0.0f;
     switch (2 * i + j) {   // one copy of the tile body in the code; the accumulators are selected by moves
-      case 0: a = acc[0][0]; break;
-      case 1: a = acc[0][1]; break;
-      case 2: a = acc[1][0]; break;
-      default: a = acc[1][1]; break;
+      case 0:
+        a = acc[0][0];
+        if (PF) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x1[r] = px1[0][0][r];
+        }
+        break;
+      case 1:
+        a = acc[0][1];
+        if (PF) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x1[r] = px1[0][1][r];
+        }
+        break;
+      case 2:
+        a = acc[1][0];
+        if (PF) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x1[r] = px1[1][0][r];
+        }
+        break;
+      default:
+        a = acc[1][1];
+        if (PF) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x1[r] = px1[1][1][r];
+        }
+        break;
     }
-    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a);
+    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1);
   }
 }
 
@@ -341,33 +406,55 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
     }
 
     f32x16 acc[2][2];
+    float px1[2][2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          acc[i][j][r] = 0.0f;
+          px1[i][j][r] = 0.0f;
+        }
 
     if (nct > 0) {
       const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
       const f32x4* bptr = Bp + (size_t)ct0 * 64 + lane;
       const size_t bstride = (size_t)NT * 64;  // float4 per k group
-      if (nrt == 2 && nct == 2) ch_mma<2, 2>(arow, bptr, bstride, G, acc);
-      else if (nrt == 2) ch_mma<2, 1>(arow, bptr, bstride, G, acc);
-      else if (nct == 2) ch_mma<1, 2>(arow, bptr, bstride, G, acc);
-      else ch_mma<1, 1>(arow, bptr, bstride, G, acc);
+      const bool pfx = (st.epi == NUDF_CH_MULSP || st.epi == NUDF_CH_TANGENT || st.epi == NUDF_CH_BWD);
+      ChPrefetch pf;
+      pf.X1 = st.X1;
+      pf.ldx1 = st.ldx1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = (ct0 + j) * 32 + ln;
+          pf.vo[i][j] = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx1 + (unsigned)((col < st.N) ? col : 0);
+        }
+      if (pfx) {
+        if (nrt == 2 && nct == 2) ch_mma<2, 2, true>(arow, bptr, bstride, G, acc, pf, px1);
+        else if (nrt == 2) ch_mma<2, 1, true>(arow, bptr, bstride, G, acc, pf, px1);
+        else if (nct == 2) ch_mma<1, 2, true>(arow, bptr, bstride, G, acc, pf, px1);
+        else ch_mma<1, 1, true>(arow, bptr, bstride, G, acc, pf, px1);
+      } else {
+        if (nrt == 2 && nct == 2) ch_mma<2, 2, false>(arow, bptr, bstride, G, acc, pf, px1);
+        else if (nrt == 2) ch_mma<2, 1, false>(arow, bptr, bstride, G, acc, pf, px1);
+        else if (nct == 2) ch_mma<1, 2, false>(arow, bptr, bstride, G, acc, pf, px1);
+        else ch_mma<1, 1, false>(arow, bptr, bstride, G, acc, pf, px1);
+      }
     }
     if (dbg && lane == 0) dbg[2 + 2 * si] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // every wave is done reading the activation tile
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
-        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
-        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
-        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
-        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
-        default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc); break;
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
       }
     }
     if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();

@@ -25,7 +25,7 @@ def run(P, chain, seed=0):
     grads = eng.backward(x, st, DA, d_udf, d_feat, 288, d_g)
     uo = eng.forward(x, need_grad_state=False, udf_only=True)["udf"]
     return dict(udf=st["udf"], sign=st["sign"], feat=st["feat"][:, :256], g=gr, uo=uo, X4=st["X"][4][:P], X8=st["X"][8][:P],
-                DA0=DA[0][:P], DA3=DA[3][:P], DA7=DA[7][:P], **{f"p{i}": t for i, t in enumerate(grads)})
+                DA0=DA[0][:P], DA3=DA[3][:P, :217], DA7=DA[7][:P], **{f"p{i}": t for i, t in enumerate(grads)})
 
 
 def rel(a, b):

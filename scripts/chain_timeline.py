@@ -32,6 +32,10 @@ print("wave_id histogram", collections.Counter(wave_id.tolist()))
 k0 = sorted(key)[0]
 for k in [k0]:
     print("SIMD", k)
-    for i in sorted(key[k], key=lambda i: d[i, 1])[:16]:
-        ts = (d[i, 1:22] - t0) / 100.0   # s_memtime ticks at 100 MHz? print raw deltas in ticks
-        print("blk", i // 4, "w", i % 4, "slot", int(wave_id[i]), " ".join(f"{int(v)}" for v in (d[i, 1:22] - t0)))
+    for i in sorted(key[k], key=lambda i: d[i, 1])[:8]:
+        st = d[i, 1:20]
+        mma = [int(st[1 + 2 * s] - (st[2 * s] if s == 0 else st[2 * s])) for s in range(9)]
+        epi = [int(st[2 + 2 * s] - st[1 + 2 * s]) for s in range(9)]
+        print("blk", i // 4, "w", i % 4, "slot", int(wave_id[i]), "start", int(st[0] - t0), "total", int(st[18] - st[0]))
+        print("    mma+wait", mma)
+        print("    epilogue", epi)
