@@ -375,6 +375,24 @@ typedef struct NudfUnpackMulti {
 } NudfUnpackMulti;
 int nudf_weightnorm_unpack_grad_multi(const NudfUnpackMulti* args, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * The three learnable scalars of the renderer in one launch (instead of ~15 one-element torch kernels):
+ *   inv_s = exp(10 variance).clip(1e-6, 1e6)                      fields.py:654-655, udf_renderer_blending.py:373
+ *   beta  = exp(10 beta).clip(0, beta_hi).clip(1e-6, 1e6)          fields.py:674-675, :376   (beta_hi = 1/beta_min)
+ *   gamma = exp(10 gamma).clip(1e-6, 1e6)                          fields.py:677-678, :377
+ * scal[3] = {inv_s, beta, gamma}; recip[2] = {1/inv_s, 1/beta} (the 'variance' / 'beta' entries of render()).
+ * bwd: d_param[3] = d_scal * d scal / d param (torch.clip passes the gradient on the closed interval).
+ * ---------------------------------------------------------------------------------- */
+int nudf_scalars_fwd(const float* variance, const float* beta, const float* gamma, float beta_hi, float* scal,
+                     float* recip, void* stream);
+int nudf_scalars_bwd(const float* variance, const float* beta, const float* gamma, float beta_hi, const float* d_scal,
+                     float* d_param, void* stream);
+
+/* sum_i |pred_i - gt_i| (the numerator of ColorPixelLoss, loss/loss.py:37-43) and its backward
+ * d_pred_i = d_out * sign(pred_i - gt_i).  out[0] += sum (caller zeroes). */
+int nudf_l1_sum_fwd(const float* pred, const float* gt, int n, float* out, void* stream);
+int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const float* d_out, float* d_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,7 @@ SYMBOLS = [
     "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch",
     "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
     "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
+    "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -194,6 +195,10 @@ _ARGTYPES = {
     "nudf_pack_frag": [_P, _I, _I, _I, _P, _P],
     "nudf_weightnorm_pack_multi": [C.POINTER(PackMulti), _P],
     "nudf_weightnorm_unpack_grad_multi": [C.POINTER(UnpackMulti), _P],
+    "nudf_scalars_fwd": [_P, _P, _P, _F, _P, _P, _P],
+    "nudf_scalars_bwd": [_P, _P, _P, _F, _P, _P, _P],
+    "nudf_l1_sum_fwd": [_P, _P, _I, _P, _P],
+    "nudf_l1_sum_bwd": [_P, _P, _I, _P, _P, _P],
 }
 
 _lib = None

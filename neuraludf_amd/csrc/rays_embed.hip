@@ -476,3 +476,75 @@ extern "C" int nudf_weightnorm_unpack_grad_multi(const NudfUnpackMulti* args, vo
   NUDF_CHECK_LAUNCH("nudf_weightnorm_unpack_grad_multi");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// renderer scalars (one thread each) and the L1 colour-loss numerator
+// ---------------------------------------------------------------------------------------
+__global__ void scalars_fwd_kernel(const float* variance, const float* beta, const float* gamma, float beta_hi,
+                                   float* scal, float* recip) {
+  if (threadIdx.x != 0) return;
+  const float s = fminf(fmaxf(expf(10.0f * variance[0]), 1e-6f), 1e6f);
+  const float b = fminf(fmaxf(fminf(fmaxf(expf(10.0f * beta[0]), 0.0f), beta_hi), 1e-6f), 1e6f);
+  const float g = fminf(fmaxf(expf(10.0f * gamma[0]), 1e-6f), 1e6f);
+  scal[0] = s; scal[1] = b; scal[2] = g;
+  if (recip) { recip[0] = 1.0f / s; recip[1] = 1.0f / b; }
+}
+extern "C" int nudf_scalars_fwd(const float* variance, const float* beta, const float* gamma, float beta_hi,
+                                float* scal, float* recip, void* stream) {
+  hipLaunchKernelGGL(scalars_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, variance, beta, gamma, beta_hi,
+                     scal, recip);
+  NUDF_CHECK_LAUNCH("nudf_scalars_fwd");
+  return 0;
+}
+__global__ void scalars_bwd_kernel(const float* variance, const float* beta, const float* gamma, float beta_hi,
+                                   const float* d_scal, float* d_param) {
+  if (threadIdx.x != 0) return;
+  const float s = expf(10.0f * variance[0]);
+  d_param[0] = (s >= 1e-6f && s <= 1e6f) ? d_scal[0] * 10.0f * s : 0.0f;
+  const float b = expf(10.0f * beta[0]);
+  const float b1 = fminf(fmaxf(b, 0.0f), beta_hi);
+  d_param[1] = (b >= 0.0f && b <= beta_hi && b1 >= 1e-6f && b1 <= 1e6f) ? d_scal[1] * 10.0f * b : 0.0f;
+  const float g = expf(10.0f * gamma[0]);
+  d_param[2] = (g >= 1e-6f && g <= 1e6f) ? d_scal[2] * 10.0f * g : 0.0f;
+}
+extern "C" int nudf_scalars_bwd(const float* variance, const float* beta, const float* gamma, float beta_hi,
+                                const float* d_scal, float* d_param, void* stream) {
+  hipLaunchKernelGGL(scalars_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, variance, beta, gamma, beta_hi,
+                     d_scal, d_param);
+  NUDF_CHECK_LAUNCH("nudf_scalars_bwd");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void l1_sum_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         int n, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += fabsf(pred[i] - gt[i]);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int nudf_l1_sum_fwd(const float* pred, const float* gt, int n, float* out, void* stream) {
+  if (n <= 0) return 0;
+  int nb = (n + 1023) / 1024;
+  if (nb > 64) nb = 64;     // <= 64 atomics on one address
+  hipLaunchKernelGGL(l1_sum_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, gt, n, out);
+  NUDF_CHECK_LAUNCH("nudf_l1_sum_fwd");
+  return 0;
+}
+__global__ void l1_sum_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int n,
+                                  const float* d_out, float* __restrict__ d_pred) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = pred[i] - gt[i];
+  d_pred[i] = d_out[0] * ((d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f));
+}
+extern "C" int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const float* d_out, float* d_pred,
+                               void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(l1_sum_bwd_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, d_out,
+                     d_pred);
+  NUDF_CHECK_LAUNCH("nudf_l1_sum_bwd");
+  return 0;
+}

@@ -11,6 +11,33 @@ from .. import dist as nudf_dist
 from .patch_metric import ssim_patch_error
 
 
+class _L1SumFn(torch.autograd.Function):
+    """sum |pred - gt| in one launch (and sign(pred - gt) * upstream in one launch back)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        from .._lib import call, ptr
+        p, g = pred.detach().contiguous(), gt.detach().contiguous()
+        out = torch.zeros(1, device=p.device)
+        call("nudf_l1_sum_fwd", ptr(p), ptr(g), p.numel(), ptr(out))
+        ctx.save_for_backward(p, g)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from .._lib import call, ptr
+        p, g = ctx.saved_tensors
+        d_pred = torch.empty_like(p)
+        call("nudf_l1_sum_bwd", ptr(p), ptr(g), p.numel(), ptr(d_out.reshape(1).contiguous()), ptr(d_pred))
+        return d_pred, None
+
+
+def _l1_sum(pred, gt):
+    if pred.is_cuda and pred.dtype == torch.float32 and gt.shape == pred.shape and gt.dtype == torch.float32:
+        return _L1SumFn.apply(pred, gt)
+    return (pred - gt).abs().sum()       # host tensors: only the world_size-2 CPU test of the sharding algebra
+
+
 class ColorPixelLoss(nn.Module):
     """loss/loss.py:21-44 -- the mask only enters the denominator, never the error."""
 
@@ -19,7 +46,7 @@ class ColorPixelLoss(nn.Module):
         self.data_parallel = False
 
     def forward(self, pred, gt, mask):
-        num = (pred - gt).abs().sum()
+        num = _l1_sum(pred, gt)
         if mask is not None:
             den = mask.sum().float()
             if self.data_parallel:

@@ -117,6 +117,29 @@ class _CompositeFn(torch.autograd.Function):
         return (None, None, None, None, None, None, o_udf, o_grad, o_col, o_cb, None, o_sig, o_bgc, o_scal)
 
 
+class _ScalarsFn(torch.autograd.Function):
+    """(variance, beta, gamma parameters) -> clipped [inv_s, beta, gamma] and [1/inv_s, 1/beta], one launch each way
+    (fields.py:654-655, 674-678 + the call-site clips of udf_renderer_blending.py:373-377)."""
+
+    @staticmethod
+    def forward(ctx, variance, beta, gamma, beta_hi):
+        v, b, g = variance.detach().contiguous(), beta.detach().contiguous(), gamma.detach().contiguous()
+        scal = torch.empty(3, device=v.device)
+        recip = torch.empty(2, device=v.device)
+        call("nudf_scalars_fwd", ptr(v), ptr(b), ptr(g), float(beta_hi), ptr(scal), ptr(recip))
+        ctx.save_for_backward(v, b, g)
+        ctx.beta_hi = float(beta_hi)
+        ctx.mark_non_differentiable(recip)
+        return scal, recip
+
+    @staticmethod
+    def backward(ctx, d_scal, _d_recip):
+        v, b, g = ctx.saved_tensors
+        d = torch.empty(3, device=v.device)
+        call("nudf_scalars_bwd", ptr(v), ptr(b), ptr(g), ctx.beta_hi, ptr(d_scal.contiguous()), ptr(d))
+        return d[0:1].reshape(v.shape), d[1:2].reshape(b.shape), d[2:3].reshape(g.shape), None
+
+
 def extract_fields(bound_min, bound_max, resolution, query_func, device='cuda'):
     """Dense-grid field query (models/udf_renderer_blending.py:16-31): chunks of 64^3 points."""
     n = 64
@@ -183,11 +206,19 @@ class UDFRendererBlending:
 
     # ------------------------------------------------------------------------------------
     def _scalars(self, dev):
-        """inv_s, beta, gamma: 1-element parameter transforms + call-site clips (:373-377)."""
-        inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6).reshape(1)
-        beta = self.beta_network.get_beta().clip(1e-6, 1e6).reshape(1)
-        gamma = self.beta_network.get_gamma().clip(1e-6, 1e6).reshape(1)
-        return inv_s, beta, gamma
+        """-> (scal [3] = clipped inv_s, beta, gamma ; recip [2] = 1/inv_s, 1/beta)  (:373-377).
+        One kernel when the scalar networks are the drop-in ones (1-element `variance`, `beta`, `gamma`
+        parameters); any other module goes through its own forward, as the reference does."""
+        dn, bn = self.deviation_network, self.beta_network
+        if (isinstance(getattr(dn, "variance", None), torch.Tensor) and dn.variance.numel() == 1 and dn.variance.is_cuda
+                and isinstance(getattr(bn, "beta", None), torch.Tensor) and hasattr(bn, "gamma")
+                and hasattr(bn, "beta_min")):
+            return _ScalarsFn.apply(dn.variance, bn.beta, bn.gamma, 1.0 / bn.beta_min)
+        inv_s = dn(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6).reshape(1)
+        beta = bn.get_beta().clip(1e-6, 1e6).reshape(1)
+        gamma = bn.get_gamma().clip(1e-6, 1e6).reshape(1)
+        scal = torch.cat([inv_s, beta, gamma])
+        return scal, torch.stack([1.0 / inv_s[0], 1.0 / beta[0]]).detach()
 
     def _quantiles(self, k, dev):
         key = (k, str(dev))
@@ -289,8 +320,7 @@ class UDFRendererBlending:
         ceng = self.color_network.engine()
         udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld)
         cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
-        inv_s, beta, gamma = self._scalars(dev)
-        scal = torch.cat([inv_s, beta, gamma])
+        scal, recip = self._scalars(dev)
         c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,
                  flip_saturation=flip_saturation, use_norm_grad=self.use_norm_grad_for_cosine,
                  sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics)
@@ -318,8 +348,8 @@ class UDFRendererBlending:
         g3 = grad.reshape(N, S, 3)
         ret = {
             'color_base': color_base, 'color': color, 'color_pixel': color_pixel, 'patch_colors': patch_colors,
-            'patch_mask': patch_mask, 'weights': weights, 's_val': 1.0 / inv_s.reshape(1, 1),
-            'beta': 1.0 / beta, 'gamma': gamma, 'depth': depth, 'gradient_error': gradient_error,
+            'patch_mask': patch_mask, 'weights': weights, 's_val': recip[0:1].reshape(1, 1),
+            'beta': recip[1:2], 'gamma': scal[2:3], 'depth': depth, 'gradient_error': gradient_error,
             'gradient_error_near_surface': gradient_error_ns, 'normals': normals, 'gradients': g3,
             'udf': udf.reshape(N, S), 'sparse_error': sparse_error, 'weight_sum': wsum, 'weight_sum_fg_bg': wsum_all,
         }
@@ -355,14 +385,16 @@ class UDFRendererBlending:
         t_rand = None
         lin = None
         if self.n_outside > 0:
-            lin = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside)
+            lin = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev)
         if perturb > 0:
-            t_rand = (torch.rand([N, 1]) - 0.5).to(dev).contiguous()            # (:618)
+            # drawn on the rays' device: the reference draws on its default device, which the runner makes the GPU
+            # (exp_runner_blending.py:872), so the draw order / shapes / generator are the same
+            t_rand = (torch.rand([N, 1], device=dev) - 0.5).contiguous()        # (:618)
             if self.n_outside > 0:                                               # (:621-627) stratified jitter
                 mids = .5 * (lin[..., 1:] + lin[..., :-1])
                 upper = torch.cat([mids, lin[..., -1:]], -1)
                 lower = torch.cat([lin[..., :1], mids], -1)
-                lin = lower + (upper - lower) * torch.rand(lin.shape).to(lin.device)
+                lin = lower + (upper - lower) * torch.rand(lin.shape, device=dev)
         z_vals = torch.empty(N, self.n_samples, device=dev)
         sample_dist = torch.empty(1, device=dev)
         call("nudf_coarse_z", ptr(near), ptr(far), nf_stride, ptr(t_rand), N, self.n_samples, ptr(z_vals),
@@ -370,7 +402,7 @@ class UDFRendererBlending:
         z_out = None
         if self.n_outside > 0:
             z_out = torch.empty(N, self.n_outside, device=dev)
-            call("nudf_outside_z", ptr(far), nf_stride, ptr(lin.to(dev).float().contiguous()), N, self.n_outside,
+            call("nudf_outside_z", ptr(far), nf_stride, ptr(lin.float().contiguous()), N, self.n_outside,
                  self.n_samples, ptr(z_out))
 
         n_samples = self.n_samples
@@ -395,10 +427,10 @@ class UDFRendererBlending:
 
         sparse_random_error = 0.0
         if True:
-            pts_random = torch.rand([1024, 3]).float().to(dev) * 2 - 1          # keeps the RNG stream aligned (:683)
+            pts_random = torch.rand([1024, 3], device=dev)                       # keeps the RNG stream aligned (:683)
             if self.compute_sparse_random:
                 with torch.no_grad():
-                    udf_random = self.udf_network.udf(pts_random)
+                    udf_random = self.udf_network.udf(pts_random * 2 - 1)
                 if (udf_random < 0.01).sum() > 10:
                     sparse_random_error = torch.exp(-self.sparse_scale_factor * udf_random[udf_random < 0.01]).mean()
         ret['variance'] = ret.pop('s_val')
