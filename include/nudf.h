@@ -367,6 +367,7 @@ typedef struct NudfUnpackLayer {
   const float* v; const float* g; const float* inv_norm;
   const int32_t* perm;
   float* dv; float* dg;            /* [out,in], [out] (dg NULL for a plain Linear)                              */
+  const float* db_in; float* db_out; /* optional [out] copy of the bias gradient out of the flat packed buffer  */
   int32_t out, in, ldw, row_start;
 } NudfUnpackLayer;
 typedef struct NudfUnpackMulti {
@@ -392,6 +393,12 @@ int nudf_scalars_bwd(const float* variance, const float* beta, const float* gamm
  * d_pred_i = d_out * sign(pred_i - gt_i).  out[0] += sum (caller zeroes). */
 int nudf_l1_sum_fwd(const float* pred, const float* gt, int n, float* out, void* stream);
 int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const float* d_out, float* d_pred, void* stream);
+
+/* batch-global regularisers from the composite kernel's partial sums (udf_renderer_blending.py:531-536, 553):
+ *   err[0] = sums[0] / (sums[1] + 1e-5), err[1] = sums[2] / (sums[3] + 1e-5), err[2] = sums[4] / n_rays
+ * bwd: d_sums[5] (entries 1 and 3, the mask counts, included for completeness). */
+int nudf_sums_errors_fwd(const float* sums, float n_rays, float* err, void* stream);
+int nudf_sums_errors_bwd(const float* sums, float n_rays, const float* d_err, float* d_sums, void* stream);
 
 #ifdef __cplusplus
 }

@@ -138,7 +138,7 @@ class PackMulti(C.Structure):
 
 class UnpackLayer(C.Structure):
     _fields_ = [("dW", c_fp), ("v", c_fp), ("g", c_fp), ("inv_norm", c_fp), ("perm", c_fp), ("dv", c_fp),
-                ("dg", c_fp), ("out", i32), ("in_", i32), ("ldw", i32), ("row_start", i32)]
+                ("dg", c_fp), ("db_in", c_fp), ("db_out", c_fp), ("out", i32), ("in_", i32), ("ldw", i32), ("row_start", i32)]
 
 
 class UnpackMulti(C.Structure):
@@ -160,6 +160,7 @@ SYMBOLS = [
     "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
     "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
     "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
+    "nudf_sums_errors_fwd", "nudf_sums_errors_bwd",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -199,6 +200,8 @@ _ARGTYPES = {
     "nudf_scalars_bwd": [_P, _P, _P, _F, _P, _P, _P],
     "nudf_l1_sum_fwd": [_P, _P, _I, _P, _P],
     "nudf_l1_sum_bwd": [_P, _P, _I, _P, _P, _P],
+    "nudf_sums_errors_fwd": [_P, _F, _P, _P],
+    "nudf_sums_errors_bwd": [_P, _F, _P, _P, _P],
 }
 
 _lib = None

@@ -271,30 +271,30 @@ extern "C" int nudf_signed_colsum(const float* sign, const float* R, int ldr, in
   return 0;
 }
 
-// backward of a sigmoid head: out[p,c] = (c < nsig) ? dy*y*(1-y) (+ extra) : draw   -> padded [P, ldo]
+// backward of a sigmoid head: out[p,c] = (c < nsig) ? dy*y*(1-y) (+ extra) : draw ; columns [nsig+nraw, ldo)
+// are written as zeros (out is the A operand of a GEMM whose K is padded to ldo)
 __global__ void sigmoid_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                         const float* __restrict__ dy_extra, int ldx, int nsig,
                                         const float* __restrict__ draw, int ldr, int nraw, int P,
                                         float* __restrict__ out, int ldo) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int C = nsig + nraw;
-  if (idx >= (long long)P * C) return;
-  int p = (int)(idx / C), c = (int)(idx - (long long)p * C);
-  float v;
+  if (idx >= (long long)P * ldo) return;
+  int p = (int)(idx / ldo), c = (int)(idx - (long long)p * ldo);
+  float v = 0.f;
   if (c < nsig) {
     float s = y[(size_t)p * nsig + c];
     float d = dy ? dy[(size_t)p * nsig + c] : 0.f;
     if (dy_extra) d += dy_extra[(size_t)p * ldx + c];
     v = d * s * (1.0f - s);
-  } else {
+  } else if (c < nsig + nraw) {
     v = draw ? draw[(size_t)p * ldr + (c - nsig)] : 0.f;
   }
-  out[(size_t)p * ldo + c] = v;
+  out[idx] = v;
 }
 extern "C" int nudf_sigmoid_head_bwd(const float* y, const float* dy, const float* dy_extra, int ldx, int nsig,
                                      const float* draw, int ldr, int nraw, int P, float* out, int ldo, void* stream) {
   if (P == 0) return 0;
-  hipLaunchKernelGGL(sigmoid_head_bwd_kernel, dim3(nblocks((long long)P * (nsig + nraw), 256)), dim3(256), 0,
+  hipLaunchKernelGGL(sigmoid_head_bwd_kernel, dim3(nblocks((long long)P * ldo, 256)), dim3(256), 0,
                      (hipStream_t)stream, y, dy, dy_extra, ldx, nsig, draw, ldr, nraw, P, out, ldo);
   NUDF_CHECK_LAUNCH("nudf_sigmoid_head_bwd");
   return 0;
@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void wn_unpack_multi_kernel(NudfUnpackMulti a)
   const NudfUnpackLayer& L = a.layer[li];
   const int row = grow - L.row_start;
   const int l = threadIdx.x & 63;
+  if (l == 0 && L.db_out) L.db_out[row] = L.db_in[row];
   if (!L.g) {
     for (int i = l; i < L.in; i += 64)
       L.dv[(size_t)row * L.in + i] = L.dW[(size_t)row * L.ldw + (L.perm ? L.perm[i] : i)];
@@ -546,5 +547,31 @@ extern "C" int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const 
   hipLaunchKernelGGL(l1_sum_bwd_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, d_out,
                      d_pred);
   NUDF_CHECK_LAUNCH("nudf_l1_sum_bwd");
+  return 0;
+}
+
+__global__ void sums_errors_fwd_kernel(const float* sums, float n_rays, float* err) {
+  if (threadIdx.x != 0) return;
+  err[0] = sums[0] / (sums[1] + 1e-5f);
+  err[1] = sums[2] / (sums[3] + 1e-5f);
+  err[2] = sums[4] / n_rays;
+}
+extern "C" int nudf_sums_errors_fwd(const float* sums, float n_rays, float* err, void* stream) {
+  hipLaunchKernelGGL(sums_errors_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, n_rays, err);
+  NUDF_CHECK_LAUNCH("nudf_sums_errors_fwd");
+  return 0;
+}
+__global__ void sums_errors_bwd_kernel(const float* sums, float n_rays, const float* d_err, float* d_sums) {
+  if (threadIdx.x != 0) return;
+  const float a = sums[1] + 1e-5f, b = sums[3] + 1e-5f;
+  d_sums[0] = d_err[0] / a;
+  d_sums[1] = -d_err[0] * sums[0] / (a * a);
+  d_sums[2] = d_err[1] / b;
+  d_sums[3] = -d_err[1] * sums[2] / (b * b);
+  d_sums[4] = d_err[2] / n_rays;
+}
+extern "C" int nudf_sums_errors_bwd(const float* sums, float n_rays, const float* d_err, float* d_sums, void* stream) {
+  hipLaunchKernelGGL(sums_errors_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, n_rays, d_err, d_sums);
+  NUDF_CHECK_LAUNCH("nudf_sums_errors_bwd");
   return 0;
 }

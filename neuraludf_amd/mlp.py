@@ -384,6 +384,10 @@ def unpack_group(layers, grads):
             L = a.layer[li]
             L.dW, L.v, L.perm, L.dv = ptr(dW), ptr(v), ptr(pl.perm), ptr(dv)
             L.out, L.in_, L.ldw, L.row_start = pl.out, pl.inp, pl.in_pad, rows
+            dbo = torch.empty(pl.out, device=v.device)      # fresh tensor: autograd takes it without a clone
+            L.db_in, L.db_out = ptr(db), ptr(dbo)
+            keep.append(db)
+            db = dbo
             if pl.weight_norm:
                 g = ps[1].detach().contiguous()
                 dg = torch.empty_like(g)
@@ -725,7 +729,7 @@ def relu_chain_bwd(layers, inputs, outs, D_last, P, first_needs_input_grad, add_
                 gemm_nn(D, pl.W, P, prev.out, pl.out_pad, "MULMASK", C1=Dn, X1=outs[i - 1], ldx1=outs[i - 1].shape[1])
             D = Dn
         elif first_needs_input_grad:
-            d_in0 = _buf(P, pl.inp, D.device)
+            d_in0 = _buf(P, pl.inp, D.device, zero=False)    # pad columns are never read
             gemm_nn(D, pl.W, P, pl.inp, pl.out_pad, "NONE", C1=d_in0)
     return grads, d_in0
 
@@ -803,12 +807,12 @@ class ColorEngine:
         dev = color.device
         plv = self.view[n - 1]
         nb = plv.out - self.dout
-        D = _buf(P, plv.out, dev, zero=True)
+        D = _buf(P, plv.out, dev, zero=False)           # nudf_sigmoid_head_bwd writes the pad columns
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, self.dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(D), D.shape[1])
         gv, dVIN = relu_chain_bwd(self.view, HV, HV[1:], D, P, True)
         # base head: d color_base = direct + through the view branch's input columns
-        Db = _buf(P, self.dout, dev, zero=True)
+        Db = _buf(P, self.dout, dev, zero=False)
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (self.H + self.npe), dVIN.shape[1],
              self.dout, None, 0, 0, P, ptr(Db), Db.shape[1])
         gb, dCIN = relu_chain_bwd(self.base, HB, HB[1:], Db, P, True, add_at={n - 2: (dVIN, dVIN.shape[1], 0)})
@@ -896,7 +900,7 @@ class NerfEngine:
         gemm_nn(Drgb, self.rgb.W, P, self.views.out, self.rgb.out_pad, "MULMASK", C1=Dv, X1=hv)
         g_views = self.views.new_grad_buffers()
         gemm_tn(Dv, self.views.out, VIN, g_views[0], self.views.out, self.views.in_pad, P, dbias=g_views[1])
-        dVIN = _buf(P, self.views.inp, dev)
+        dVIN = _buf(P, self.views.inp, dev, zero=False)  # only its first `feature.out` columns are read
         gemm_nn(Dv, self.views.W, P, self.views.inp, self.views.out_pad, "NONE", C1=dVIN)
         # feature / alpha heads share h = outs[-1]
         g_feat = self.feature.new_grad_buffers()

@@ -140,6 +140,27 @@ class _ScalarsFn(torch.autograd.Function):
         return d[0:1].reshape(v.shape), d[1:2].reshape(b.shape), d[2:3].reshape(g.shape), None
 
 
+class _ErrorsFn(torch.autograd.Function):
+    """[eik_num, eik_den, eikns_num, eikns_den, sparse_sum] -> [gradient_error, gradient_error_near_surface,
+    sparse_error] (:531-536, 553), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, sums, n_rays):
+        sums = sums.detach().contiguous()
+        err = torch.empty(3, device=sums.device)
+        call("nudf_sums_errors_fwd", ptr(sums), float(n_rays), ptr(err))
+        ctx.save_for_backward(sums)
+        ctx.n_rays = float(n_rays)
+        return err
+
+    @staticmethod
+    def backward(ctx, d_err):
+        (sums,) = ctx.saved_tensors
+        d = torch.empty(5, device=sums.device)
+        call("nudf_sums_errors_bwd", ptr(sums), ctx.n_rays, ptr(d_err.contiguous()), ptr(d))
+        return d, None
+
+
 def extract_fields(bound_min, bound_max, resolution, query_func, device='cuda'):
     """Dense-grid field query (models/udf_renderer_blending.py:16-31): chunks of 64^3 points."""
     n = 64
@@ -332,9 +353,8 @@ class UDFRendererBlending:
         if self.data_parallel:
             sums = nudf_dist.all_reduce_sum(sums)
         n_rays = float(N) * (nudf_dist.world_size() if self.data_parallel else 1)
-        gradient_error = sums[0] / (sums[1] + 1e-5)                       # (:533)
-        gradient_error_ns = sums[2] / (sums[3] + 1e-5)                    # (:536)
-        sparse_error = sums[4] / n_rays                                   # (:553)
+        err = _ErrorsFn.apply(sums, n_rays)
+        gradient_error, gradient_error_ns, sparse_error = err[0], err[1], err[2]       # (:533, :536, :553)
 
         color_pixel = patch_colors = patch_mask = None
         if color_maps is not None:
