@@ -84,6 +84,7 @@ def _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps
 class _PatchBlendFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps):
+        ctx.set_materialize_grads(False)
         pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs = map(_c, (pts, grad, rays_d, uv, logits, w, ref_cam,
                                                                             src_cam, imgs))
         N = pts.shape[0]
@@ -101,6 +102,8 @@ class _PatchBlendFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pc, _d_pm):
+        if d_pc is None:
+            return (None,) * 10
         pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs = ctx.saved_tensors
         N, S = pts.shape[0], pts.shape[1]
         a = PatchBlend()

@@ -37,6 +37,7 @@ class _UDFEvalFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, x, want_grad, feat_ld, *params):
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None, not as zero-filled tensors
         x = x.detach().contiguous()
         need_state = any(ctx.needs_input_grad)      # all False under no_grad (grad mode is off inside forward)
         st = engine.forward(x, need_grad_state=(need_state or want_grad), feat_ld=feat_ld)
@@ -50,6 +51,8 @@ class _UDFEvalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_udf, d_feat, d_g):
         engine, st = ctx.engine, ctx.st
+        if d_udf is None and d_feat is None and (d_g is None or d_g.numel() == 0):
+            return (None, None, None, None) + (None,) * len(engine.params())
         if st is None:
             raise RuntimeError("UDF evaluation was run without gradient state")
         if d_g is not None and d_g.numel() == 0:
@@ -158,6 +161,7 @@ class _ColorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, CIN, rays_d, S, *params):
+        ctx.set_materialize_grads(False)
         P = CIN.shape[0]
         need = any(ctx.needs_input_grad)
         cb, col, logits, st = engine.forward(CIN.detach(), rays_d.detach().contiguous(), S, P, keep_state=need)
@@ -235,6 +239,7 @@ RenderingNetwork = ResidualRenderingNetwork   # north-star name; the runner inst
 class _NerfFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, pts4, rays_d, S, *params):
+        ctx.set_materialize_grads(False)
         P = pts4.shape[0]
         need = any(ctx.needs_input_grad)
         sigma, rgb, st = engine.forward(pts4.detach().contiguous(), rays_d.detach().contiguous(), S, P, keep_state=need)

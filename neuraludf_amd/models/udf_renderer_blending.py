@@ -45,6 +45,7 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c, rays_o, rays_d, z, sample_dist, background_rgb, udf, grad, color, color_base, bg_z, bg_sigma,
                 bg_color, scal):
+        ctx.set_materialize_grads(False)     # unused outputs (depth, normals, diagnostics ...) arrive as None
         N, S = z.shape
         n_out = 0 if bg_z is None else bg_z.shape[1]
         dev = z.device
@@ -123,6 +124,7 @@ class _ScalarsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, variance, beta, gamma, beta_hi):
+        ctx.set_materialize_grads(False)
         v, b, g = variance.detach().contiguous(), beta.detach().contiguous(), gamma.detach().contiguous()
         scal = torch.empty(3, device=v.device)
         recip = torch.empty(2, device=v.device)
@@ -134,6 +136,8 @@ class _ScalarsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_scal, _d_recip):
+        if d_scal is None:
+            return None, None, None, None
         v, b, g = ctx.saved_tensors
         d = torch.empty(3, device=v.device)
         call("nudf_scalars_bwd", ptr(v), ptr(b), ptr(g), ctx.beta_hi, ptr(d_scal.contiguous()), ptr(d))
@@ -146,6 +150,7 @@ class _ErrorsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sums, n_rays):
+        ctx.set_materialize_grads(False)
         sums = sums.detach().contiguous()
         err = torch.empty(3, device=sums.device)
         call("nudf_sums_errors_fwd", ptr(sums), float(n_rays), ptr(err))
@@ -155,6 +160,8 @@ class _ErrorsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_err):
+        if d_err is None:
+            return None, None
         (sums,) = ctx.saved_tensors
         d = torch.empty(5, device=sums.device)
         call("nudf_sums_errors_bwd", ptr(sums), ctx.n_rays, ptr(d_err.contiguous()), ptr(d))
