@@ -76,6 +76,20 @@ typedef struct NudfGemmTN {
 /* C[NA,NB] += A1^T B1 (+ A2^T B2): weight gradients, reduction over the M points */
 int nudf_gemm_tn(const NudfGemmTN* args, void* stream);
 
+/* up to 12 single-pair problems over the same M points in one launch (all weight gradients of a ReLU chain) */
+#define NUDF_TN_MAX_PROBLEMS 12
+typedef struct NudfGemmTNProblem {
+  const float* A1; const float* B1;             /* [M, lda1], [M, ldb1]                   */
+  float* C; float* dbias;                       /* [NA, ldc] +=, [NA] += or NULL          */
+  int32_t lda1, ldb1, ldc, NA, NB;
+  int32_t tile_start;                           /* filled by the library                  */
+} NudfGemmTNProblem;
+typedef struct NudfGemmTNGroup {
+  int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
+  NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
+} NudfGemmTNGroup;
+int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);
+
 
 /* ------------------------------------------------------------------------------------
  * Fused UDF -> density -> alpha -> composite (forward / backward), one wavefront per ray.

@@ -36,6 +36,19 @@ class GemmTN(C.Structure):
                 ("rows_per_block", i32)]
 
 
+TN_MAX_PROBLEMS = 12
+
+
+class GemmTNProblem(C.Structure):
+    _fields_ = [("A1", c_fp), ("B1", c_fp), ("C", c_fp), ("dbias", c_fp), ("lda1", i32), ("ldb1", i32), ("ldc", i32),
+                ("NA", i32), ("NB", i32), ("tile_start", i32)]
+
+
+class GemmTNGroup(C.Structure):
+    _fields_ = [("n_problems", i32), ("M", i32), ("rows_per_block", i32), ("total_tiles", i32),
+                ("prob", GemmTNProblem * TN_MAX_PROBLEMS)]
+
+
 class Composite(C.Structure):
     _fields_ = [("rays_o", c_fp), ("rays_d", c_fp), ("z", c_fp), ("udf", c_fp), ("grad", c_fp),
                 ("color", c_fp), ("color_base", c_fp), ("bg_z", c_fp), ("bg_sigma", c_fp), ("bg_color", c_fp),
@@ -150,7 +163,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_composite_fwd",
+    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_composite_fwd",
     "nudf_composite_bwd", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
@@ -167,6 +180,7 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 _ARGTYPES = {
     "nudf_gemm_nn": [C.POINTER(GemmNN), _P],
     "nudf_gemm_tn": [C.POINTER(GemmTN), _P],
+    "nudf_gemm_tn_grouped": [C.POINTER(GemmTNGroup), _P],
     "nudf_composite_fwd": [C.POINTER(Composite), _P],
     "nudf_composite_bwd": [C.POINTER(Composite), C.POINTER(CompositeGrad), _P],
     "nudf_upsample": [C.POINTER(Upsample), _P],

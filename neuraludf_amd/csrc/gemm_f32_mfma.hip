@@ -278,8 +278,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nn_kernel(NudfGemmNN p) {
 // ---------------------------------------------------------------------------------------
 // weight-gradient GEMM: C[NA,NB] += sum_m A[m,:]^T B[m,:]   (two operand pairs, split over M)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
+__device__ __forceinline__ void gemm_tn_body(const NudfGemmTN& p, float* smem, int tile, int chunk) {
   float* As = smem;
   float* Bs = smem + 2 * T_TILE;
 
@@ -287,10 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_i = (p.NA + BM - 1) / BM;
   const int tiles_j = (p.NB + BN - 1) / BN;
-  const int tile = blockIdx.x % (tiles_i * tiles_j);
-  const int chunk = blockIdx.x / (tiles_i * tiles_j);
   const int i0 = (tile / tiles_j) * BM;
   const int j0 = (tile % tiles_j) * BN;
   const int mbeg = chunk * p.rows_per_block;
@@ -440,6 +436,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
   }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
+  const int tiles = ((p.NA + BM - 1) / BM) * ((p.NB + BN - 1) / BN);
+  gemm_tn_body(p, smem, blockIdx.x % tiles, blockIdx.x / tiles);
+}
+
+// several single-pair problems over the same M points in one launch (the weight gradients of a whole ReLU chain):
+// enough tiles to fill the chip with long row chunks, i.e. few atomics per output and one launch instead of 5-12
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(NudfGemmTNGroup g) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
+  const int gt = blockIdx.x % g.total_tiles;
+  const int chunk = blockIdx.x / g.total_tiles;
+  int pi = 0;
+  while (pi + 1 < g.n_problems && g.prob[pi + 1].tile_start <= gt) ++pi;
+  const NudfGemmTNProblem& q = g.prob[pi];
+  NudfGemmTN p;
+  p.A1 = q.A1; p.lda1 = q.lda1; p.na1 = q.NA;
+  p.B1 = q.B1; p.ldb1 = q.ldb1;
+  p.A2 = nullptr; p.lda2 = 0; p.na2 = 0; p.B2 = nullptr; p.ldb2 = 0;
+  p.C = q.C; p.ldc = q.ldc; p.dbias = q.dbias;
+  p.M = g.M; p.NA = q.NA; p.NB = q.NB; p.rows_per_block = g.rows_per_block;
+  gemm_tn_body(p, smem, gt - q.tile_start, chunk);
+}
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
@@ -530,5 +550,36 @@ extern "C" int nudf_gemm_tn(const NudfGemmTN* args, void* stream) {
   const int chunks = (p.M + p.rows_per_block - 1) / p.rows_per_block;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * chunks), dim3(256), 0, st, p);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn");
+  return 0;
+}
+
+extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
+  NudfGemmTNGroup g = *args;
+  if (g.n_problems <= 0 || g.M <= 0) return 0;
+  if (g.n_problems > NUDF_TN_MAX_PROBLEMS) {
+    nudf_set_error("nudf_gemm_tn_grouped: too many problems", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  int tiles = 0;
+  for (int i = 0; i < g.n_problems; ++i) {
+    NudfGemmTNProblem& q = g.prob[i];
+    if ((q.lda1 % 4) || (q.ldb1 % 4) || q.NA <= 0 || q.NB <= 0) {
+      nudf_set_error("nudf_gemm_tn_grouped: leading dimensions must be multiples of 4", hipErrorInvalidValue);
+      return (int)hipErrorInvalidValue;
+    }
+    q.tile_start = tiles;
+    tiles += ((q.NA + BM - 1) / BM) * ((q.NB + BN - 1) / BN);
+  }
+  g.total_tiles = tiles;
+  if (g.rows_per_block <= 0) {
+    int chunks = (640 + tiles - 1) / tiles;   // ~2.5 blocks per CU
+    int rpb = (g.M + chunks - 1) / chunks;
+    rpb = ((rpb + BK - 1) / BK) * BK;
+    if (rpb < 8 * BK) rpb = 8 * BK;
+    g.rows_per_block = rpb;
+  }
+  const int chunks = (g.M + g.rows_per_block - 1) / g.rows_per_block;
+  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles * chunks), dim3(256), 0, (hipStream_t)stream, g);
+  NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
   return 0;
 }

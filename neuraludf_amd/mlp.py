@@ -200,6 +200,24 @@ class ChainBuilder:
         self.keep = []
 
 
+def gemm_tn_grouped(jobs, M):
+    """jobs: [(A1 [M, lda], NA, B1 [M, ldb], NB, C [NA_pad, ldc], dbias | None)] -> one launch per <= 12 problems."""
+    for base in range(0, len(jobs), _lib.TN_MAX_PROBLEMS):
+        chunk = jobs[base:base + _lib.TN_MAX_PROBLEMS]
+        g = _lib.GemmTNGroup()
+        g.n_problems, g.M, g.rows_per_block = len(chunk), M, 0
+        flops = 0.0
+        for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
+            q = g.prob[i]
+            q.A1, q.B1, q.C, q.dbias = ptr(A1), ptr(B1), ptr(Cm), ptr(db)
+            q.lda1, q.ldb1, q.ldc, q.NA, q.NB = A1.shape[1], B1.shape[1], Cm.shape[1], NA, NB
+            flops += 2.0 * M * NA * NB
+        if PROFILE is not None:
+            _timed("gemm_tn", flops, lambda: call("nudf_gemm_tn_grouped", g))
+        else:
+            call("nudf_gemm_tn_grouped", g)
+
+
 class PackedLinear:
     """one (weight-normed or plain) nn.Linear packed for the GEMM kernels."""
 
@@ -715,9 +733,10 @@ def relu_chain_bwd(layers, inputs, outs, D_last, P, first_needs_input_grad, add_
     grads = alloc_grads(layers)
     D = D_last
     d_in0 = None
+    tn_jobs = []
     for i in range(n - 1, -1, -1):
         pl = layers[i]
-        gemm_tn(D, pl.out, inputs[i], grads[i][0], pl.out, pl.in_pad, P, dbias=grads[i][1])
+        tn_jobs.append((D, pl.out, inputs[i], pl.in_pad, grads[i][0], grads[i][1]))   # dW_i = D_i^T input_i, grouped below
         if i > 0:
             prev = layers[i - 1]
             Dn = _buf(P, prev.out, D.device)
@@ -731,6 +750,7 @@ def relu_chain_bwd(layers, inputs, outs, D_last, P, first_needs_input_grad, add_
         elif first_needs_input_grad:
             d_in0 = _buf(P, pl.inp, D.device, zero=False)    # pad columns are never read
             gemm_nn(D, pl.W, P, pl.inp, pl.out_pad, "NONE", C1=d_in0)
+    gemm_tn_grouped(tn_jobs, P)
     return grads, d_in0
 
 
