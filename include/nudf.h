@@ -297,7 +297,12 @@ enum {
   NUDF_CH_MULSP = 2,     /* out = acc * softplus'(X1) * scale ; cols >= iparam > 0: C2[col-iparam] = acc*scale */
   NUDF_CH_TANGENT = 3,   /* out = acc * s * scale ; C2 = acc * X2 * 100 (1 - s),  s = softplus'(X1) */
   NUDF_CH_BWD = 4,       /* out = acc * scale * softplus'(X1) + X2                                */
-  NUDF_CH_UDFHEAD = 5    /* col 0: C2[row] = |acc + bias| * scale, C1[row] = sign                 */
+  NUDF_CH_UDFHEAD = 5,   /* col 0: C2[row] = |acc + bias| * scale, C1[row] = sign                 */
+  NUDF_CH_RELU = 6,      /* out = relu(acc + bias) ; C2 (optional) mirrors it                     */
+  NUDF_CH_SIGMOIDN = 7,  /* cols < iparam: sigmoid -> C1 (and tile); cols >= iparam raw -> C2[col-iparam];
+                            N <= iparam: C2 mirrors the sigmoid columns instead                    */
+  NUDF_CH_MULMASK = 8,   /* out = (X1 > 0) ? acc * scale : 0            (ReLU backward)           */
+  NUDF_CH_ADDMASK = 9    /* out = (X1 > 0) ? (acc + X2) * scale : 0     (ReLU backward at a join) */
 };
 enum {
   NUDF_CH_INIT_LOAD = 0,   /* activation tile = A0[rows, 0:k0]                                    */
@@ -312,21 +317,24 @@ typedef struct NudfChainStep {
   float* C1; float* C2;            /* HBM copies of the outputs (NULL = keep in LDS only)            */
   const float* r1_row;             /* optional rank-1 term: acc += r1_row[row] * r1_col[col]         */
   const float* r1_col;
-  int32_t K, N;                    /* K % 16 == 0, K <= 256, N <= 256                                */
+  int32_t K, N;                    /* K % 16 == 0, K <= 288, N <= 256                                */
   int32_t epi;                     /* NUDF_CH_*                                                      */
   int32_t iparam;
   int32_t ldx1, ldx2, ldc1, ldc2;
   int32_t ldr1;                    /* element stride of r1_row                                       */
   int32_t act_write;               /* 1: the outputs become the next step's activation tile          */
   int32_t act_col0;                /* ... at tile columns [act_col0, act_col0 + N)                   */
-  int32_t pe_tail_col;             /* >= 0: afterwards write PE(x)*pe_tail_scale at these tile columns (and C1) */
+  int32_t pe_tail_col;             /* >= 0: afterwards write PE(x)*pe_tail_scale at these tile columns ...       */
+  int32_t ld_pe;
+  float* pe_dst;                   /* ... and at the same columns of pe_dst [P, ld_pe] (or NULL)                */
   float pe_tail_scale;
   float scale, xscale;
 } NudfChainStep;
 typedef struct NudfChain {
   int32_t P, n_steps;
   int32_t init;                    /* NUDF_CH_INIT_*                                                 */
-  int32_t k0;                      /* initial tile width (multiple of 4, <= 256)                     */
+  int32_t k0;                      /* initial tile width (multiple of 4, <= 288)                     */
+  int32_t x_div;                   /* x row of point p is p / x_div (samples per ray for per-ray directions; >= 1) */
   int32_t tile_rows;               /* 0 = choose, 32 or 64 points per workgroup                      */
   int32_t lda0, ldg0;
   int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */

@@ -113,7 +113,7 @@ class Adam(C.Structure):
 
 
 CH_MAX_STEPS = 12
-CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5)
+CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5, RELU=6, SIGMOIDN=7, MULMASK=8, ADDMASK=9)
 CH_INIT = dict(LOAD=0, POSENC=1, SEED=2)
 
 
@@ -121,11 +121,12 @@ class ChainStep(C.Structure):
     _fields_ = [("Bp", c_fp), ("bias", c_fp), ("X1", c_fp), ("X2", c_fp), ("C1", c_fp), ("C2", c_fp),
                 ("r1_row", c_fp), ("r1_col", c_fp), ("K", i32), ("N", i32), ("epi", i32), ("iparam", i32),
                 ("ldx1", i32), ("ldx2", i32), ("ldc1", i32), ("ldc2", i32), ("ldr1", i32), ("act_write", i32),
-                ("act_col0", i32), ("pe_tail_col", i32), ("pe_tail_scale", f32), ("scale", f32), ("xscale", f32)]
+                ("act_col0", i32), ("pe_tail_col", i32), ("ld_pe", i32), ("pe_dst", c_fp), ("pe_tail_scale", f32),
+                ("scale", f32), ("xscale", f32)]
 
 
 class Chain(C.Structure):
-    _fields_ = [("P", i32), ("n_steps", i32), ("init", i32), ("k0", i32), ("tile_rows", i32), ("lda0", i32),
+    _fields_ = [("P", i32), ("n_steps", i32), ("init", i32), ("k0", i32), ("x_div", i32), ("tile_rows", i32), ("lda0", i32),
                 ("ldg0", i32), ("pe_L", i32), ("pe_jvp", i32), ("pe_in_scale", f32), ("seed_scale", f32),
                 ("seed_xscale", f32), ("A0", c_fp), ("G0", c_fp), ("x", c_fp), ("v", c_fp), ("seed_sign", c_fp),
                 ("seed_wrow", c_fp), ("dbg", c_fp), ("step", ChainStep * CH_MAX_STEPS)]

@@ -20,7 +20,8 @@
 #include "nudf_common.h"
 #include "../../include/nudf.h"
 
-#define CH_LD 260          // activation row stride in floats: m*260 mod 64 = 4m -> conflict-free ds_read_b128
+#define CH_LD 292          // activation row stride in floats (K <= 288): m*292 mod 64 = 36m -> 16 consecutive rows hit
+                           // 16 distinct multiples of 4 -> conflict-free ds_read_b128
 #define CH_THREADS 256
 
 __device__ __forceinline__ f32x16 ch_mfma(float a, float b, f32x16 c) {
@@ -88,6 +89,9 @@ __device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& 
 // Stored-activation operand of the epilogue (X1), fetched for ALL tiles of the wave while the last two k groups
 // are still being multiplied: the HBM latency of the epilogue operands then hides under MFMAs instead of
 // sitting between the barrier and the first epilogue instruction.
+#define CH_USES_X1(e)                                                                                           \
+  ((e) == NUDF_CH_MULSP || (e) == NUDF_CH_TANGENT || (e) == NUDF_CH_BWD || (e) == NUDF_CH_MULMASK || (e) == NUDF_CH_ADDMASK)
+
 struct ChPrefetch {
   const float* X1;
   int ldx1;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     for (int r = 0; r < 16; ++r) v[r] += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo] * r1c;
   }
   float x2[16];   // x1 (the stored activation) was prefetched under the K loop
-  if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD) {
+  if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD || EPI == NUDF_CH_ADDMASK) {
     if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
 #pragma unroll
@@ -221,6 +225,17 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     } else if (EPI == NUDF_CH_UDFHEAD) {
       out[r] = fabsf(v[r]) * st.scale;
       out2[r] = (v[r] > 0.0f) ? 1.0f : ((v[r] < 0.0f) ? -1.0f : 0.0f);
+    } else if (EPI == NUDF_CH_RELU) {
+      out[r] = fmaxf(v[r], 0.0f);
+      out2[r] = out[r];                                       // optional mirror (hidden tap of the colour net)
+    } else if (EPI == NUDF_CH_SIGMOIDN) {
+      // columns < iparam through a sigmoid (torch.sigmoid accuracy: libm exp), the rest raw
+      out2[r] = v[r];
+      out[r] = (col < st.iparam) ? 1.0f / (1.0f + expf(-v[r])) : 0.0f;
+    } else if (EPI == NUDF_CH_MULMASK) {
+      out[r] = (x1[r] > 0.0f) ? v[r] * st.scale : 0.0f;      // ReLU backward
+    } else if (EPI == NUDF_CH_ADDMASK) {
+      out[r] = (x1[r] > 0.0f) ? (v[r] + x2[r]) * st.scale : 0.0f;   // ReLU backward at an adjoint join
     } else {
       // softplus'(a) = s and 1 - s recovered from the stored activation (see ch_sp_derivs)
       // stored h = softplus100(a) / xscale  ->  1 - s = exp(-100 h xscale), s = softplus'(a) = sigmoid(100 a)
@@ -250,7 +265,26 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     }
     return;
   }
-  if (col_ok) {
+  if (EPI == NUDF_CH_SIGMOIDN) {
+    if (col_ok) {
+      if (col < st.iparam) {
+        if (st.C1) {
+          const unsigned vo = grow0 * (unsigned)st.ldc1 + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+        }
+        if (st.C2 && st.N <= st.iparam) {   // no raw columns: C2 mirrors the sigmoid outputs (view-branch input)
+          const unsigned vo = grow0 * (unsigned)st.ldc2 + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out[r];
+        }
+      } else if (st.C2) {
+        const unsigned vo = grow0 * (unsigned)st.ldc2 + (col - st.iparam);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+      }
+    }
+  } else if (col_ok) {
     if (EPI == NUDF_CH_MULSP && st.iparam > 0 && col >= st.iparam) {
       if (st.C2) {
         const unsigned vo = grow0 * (unsigned)st.ldc2 + (col - st.iparam);
@@ -262,7 +296,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
       for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
     }
-    if (EPI == NUDF_CH_TANGENT) {
+    if (EPI == NUDF_CH_TANGENT || (EPI == NUDF_CH_RELU && st.C2)) {
       const unsigned vo = grow0 * (unsigned)st.ldc2 + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
@@ -280,7 +314,7 @@ template <int EPI>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
                                             const float (&px1)[2][2][16]) {
-  constexpr bool PF = (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD);
+  constexpr bool PF = CH_USES_X1(EPI);
   const int ntiles = nrt * nct;
 #pragma unroll 1
   for (int t = 0; t < ntiles; ++t) {
@@ -338,7 +372,7 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
     for (int e = tid; e < TM * 3; e += CH_THREADS) {
       int r = m0 + e / 3;
       if (r > p.P - 1) r = p.P - 1;
-      sm.xs[e] = p.x[(size_t)r * 3 + (e % 3)];
+      sm.xs[e] = p.x[(size_t)(r / p.x_div) * 3 + (e % 3)];   // x_div = samples per ray for per-ray directions
       sm.vs[e] = p.v ? p.v[(size_t)r * 3 + (e % 3)] : 0.0f;
     }
   }
@@ -421,7 +455,7 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
       const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
       const f32x4* bptr = Bp + (size_t)ct0 * 64 + lane;
       const size_t bstride = (size_t)NT * 64;  // float4 per k group
-      const bool pfx = (st.epi == NUDF_CH_MULSP || st.epi == NUDF_CH_TANGENT || st.epi == NUDF_CH_BWD);
+      const bool pfx = CH_USES_X1(st.epi);
       ChPrefetch pf;
       pf.X1 = st.X1;
       pf.ldx1 = st.ldx1;
@@ -454,13 +488,17 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
         case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
         case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
         case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
         default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
       }
     }
     if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();
     if (st.pe_tail_col >= 0) {
       __syncthreads();
-      ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.C1, st.ldc1, st.pe_tail_col, 0);
+      ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col, 0);
     }
     __syncthreads();
   }
@@ -469,14 +507,14 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
 extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   const NudfChain& p = *args;
   if (p.P <= 0 || p.n_steps <= 0) return 0;
-  bool bad = p.n_steps > NUDF_CH_MAX_STEPS || (p.k0 & 3) || p.k0 > 256;
+  bool bad = p.n_steps > NUDF_CH_MAX_STEPS || (p.k0 & 3) || p.k0 > 288 || p.x_div < 1;
   for (int i = 0; i < p.n_steps && !bad; ++i) {
     const NudfChainStep& s = p.step[i];
-    bad = (s.K & 15) || s.K <= 0 || s.K > 256 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
-          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 256);
+    bad = (s.K & 15) || s.K <= 0 || s.K > 288 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
+          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288);
   }
   if (bad) {
-    nudf_set_error("nudf_mlp_chain: K%16, K<=256, N<=256, 16-byte aligned packed weights required", hipErrorInvalidValue);
+    nudf_set_error("nudf_mlp_chain: K%16, K<=288, N<=256, x_div>=1, 16-byte aligned packed weights required", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
   hipStream_t st = (hipStream_t)stream;

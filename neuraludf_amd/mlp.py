@@ -144,6 +144,7 @@ class ChainBuilder:
     def __init__(self, P, init, k0, tile_rows=0):
         self.c = Chain()
         self.c.P, self.c.init, self.c.k0, self.c.tile_rows = P, CH_INIT[init], k0, (tile_rows or CHAIN_TILE)
+        self.c.x_div = 1
         self.n = 0
         self.flops = 0.0
         self.keep = []
@@ -154,9 +155,11 @@ class ChainBuilder:
         self.keep.append(t)
         return ptr(t) + 4 * off
 
-    def posenc(self, x, L, in_scale, tangent=None):
+    def posenc(self, x, L, in_scale, tangent=None, x_div=1):
+        """source of the positional encodings: x [P / x_div, 3] (x_div = samples per ray for per-ray directions)."""
         self.c.x, self.c.v = self._p(x), self._p(tangent)
         self.c.pe_L, self.c.pe_jvp, self.c.pe_in_scale = L, (1 if tangent is not None else 0), in_scale
+        self.c.x_div = x_div
 
     def init_store(self, G0):
         if G0 is not None:
@@ -171,13 +174,14 @@ class ChainBuilder:
         self.c.seed_scale, self.c.seed_xscale = scale, xscale
 
     def step(self, epi, Bp, K, N, bias=None, bias_off=0, X1=None, X2=None, C1=None, C2=None, ldc1=0, ldc2=0, r1_row=None,
-             ldr1=1, r1_col=None, iparam=0, act_write=1, act_col0=0, pe_tail_col=-1, pe_tail_scale=0.0, scale=1.0,
-             xscale=1.0):
+             ldr1=1, r1_col=None, iparam=0, act_write=1, act_col0=0, pe_tail_col=-1, pe_tail_scale=0.0, pe_dst=None,
+             scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x2_off=0):
         if self.n >= CH_MAX_STEPS:
             raise _lib.NudfError("too many chain steps")
         s = self.c.step[self.n]
         s.Bp, s.bias = self._p(Bp), self._p(bias, bias_off)
-        s.X1, s.X2, s.C1, s.C2 = self._p(X1), self._p(X2), self._p(C1), self._p(C2)
+        s.X1, s.X2, s.C1, s.C2 = self._p(X1), self._p(X2, x2_off), self._p(C1, c1_off), self._p(C2, c2_off)
+        s.pe_dst, s.ld_pe = self._p(pe_dst), (pe_dst.shape[1] if pe_dst is not None else 0)
         s.ldx1 = X1.shape[1] if X1 is not None else 0
         s.ldx2 = X2.shape[1] if X2 is not None else 0
         s.ldc1 = ldc1 or (C1.shape[1] if (C1 is not None and C1.dim() == 2) else 0)
@@ -510,7 +514,8 @@ class UDFEngine:
             cb.step("SOFTPLUS", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias,
                     C1=X[l + 1] if need_grad_state else None,
                     scale=self.inv_sqrt2 if nxt_skip else 1.0,
-                    pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2)
+                    pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
+                    pe_dst=X[l + 1] if (need_grad_state and nxt_skip) else None)
         pl = self.layers[L]
         Pp = pad_rows(P)
         udf = torch.empty(Pp, device=dev)
@@ -581,7 +586,8 @@ class UDFEngine:
                 nxt_skip = (l + 1) in self.skip
                 cb.step("TANGENT", pl.frag("fwd"), k8(pl.inp), pl.out, X1=X[l + 1], X2=DA[l], C1=R[l + 1], C2=EX[l],
                         scale=self.inv_sqrt2 if nxt_skip else 1.0, xscale=self._xs(l),
-                        pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2)
+                        pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
+                        pe_dst=R[l + 1] if nxt_skip else None)
             cb.launch()
             call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp,
                  1.0 / float(net.scale), ptr(grads[L][0]))
@@ -783,7 +789,114 @@ class ColorEngine:
     def cin_ld(self):
         return pad32(self.F + 3)
 
+    # -- dispatch: fused LDS-resident chains (default) or per-layer GEMM launches -------------------
+    def _chain_ok(self):
+        n = self.n
+        ok = USE_CHAIN and n >= 2 and 2 * n <= CH_MAX_STEPS and self.H <= 256 and self.net.embedview_fn is not None
+        ok = ok and k8(self.base[0].inp) <= 288 and k8(self.H + self.npe + self.dout) <= 288 and self.F % 4 == 0
+        ok = ok and self.view[n - 1].out <= 32 and self.dout <= 32
+        return ok
+
+    def _kinds(self):
+        """fragment copies per layer, in the order base + view (the pack_group order)."""
+        kinds = [("fwd", "bwd_hid:%d" % self.F)]        # d CIN: only the feature columns carry a gradient
+        kinds += [("fwd", "bwd")] * (self.n - 1)
+        kinds += [("fwd", "bwd")] * self.n
+        return kinds
+
     def forward(self, CIN, rays_d, S, P, keep_state=True):
+        if self._chain_ok():
+            return self._forward_chain(CIN, rays_d, S, P, keep_state)
+        return self._forward_layers(CIN, rays_d, S, P, keep_state)
+
+    def backward(self, st, color_base, color, d_cb, d_color, d_logits):
+        if "chain" in st:
+            return self._backward_chain(st, color_base, color, d_cb, d_color, d_logits)
+        return self._backward_layers(st, color_base, color, d_cb, d_color, d_logits)
+
+    def _forward_chain(self, CIN, rays_d, S, P, keep_state=True):
+        """one launch: base branch (ReLU x4, sigmoid head) -> [hidden | PE(dir) | color_base] assembled in the LDS
+        tile -> view branch (ReLU x4, sigmoid + logits head)   (fields.py:452-495)."""
+        dev, n = CIN.device, self.n
+        H, npe, dout = self.H, self.npe, self.dout
+        pack_group(self.base + self.view, self._kinds())
+        Pp = pad_rows(P)
+        VIN = torch.empty(Pp, pad32(H + npe + dout), device=dev) if keep_state else None
+        HB = [CIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
+        HV = [VIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
+        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp))
+        cb.init_load(CIN, CIN.shape[1])
+        cb.posenc(rays_d, self.net.multires_view, 1.0, x_div=S)
+        for l in range(n - 1):
+            pl = self.base[l]
+            tap = (l == n - 2)      # hidden tap (post-ReLU) also feeds the view branch, then PE(dir) joins the tile
+            cb.step("RELU", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=HB[l + 1] if keep_state else None,
+                    C2=VIN if (tap and keep_state) else None, pe_tail_col=H if tap else -1, pe_tail_scale=1.0,
+                    pe_dst=VIN if (tap and keep_state) else None)
+        color_base = torch.empty(Pp, dout, device=dev)
+        pl = self.base[n - 1]
+        cb.step("SIGMOIDN", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=color_base, C2=VIN if keep_state else None,
+                c2_off=H + npe, iparam=dout, act_write=1, act_col0=H + npe)
+        for l in range(n - 1):
+            pl = self.view[l]
+            cb.step("RELU", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=HV[l + 1] if keep_state else None)
+        pl = self.view[n - 1]
+        nb = pl.out - dout
+        color = torch.empty(Pp, dout, device=dev)
+        logits = torch.empty(Pp, max(nb, 1), device=dev)
+        cb.step("SIGMOIDN", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=color, C2=logits if nb > 0 else None,
+                iparam=dout, act_write=0)
+        cb.launch()
+        st = dict(HB=HB, HV=HV, P=P, chain=True) if keep_state else None
+        return color_base[:P], color[:P], (logits[:P] if nb > 0 else None), st
+
+    def _backward_chain(self, st, color_base, color, d_cb, d_color, d_logits):
+        """view-branch and base-branch reverse sweeps as one launch each; all 10 weight gradients in one grouped GEMM."""
+        P, n = st["P"], self.n
+        HB, HV = st["HB"], st["HV"]
+        dev = color.device
+        H, npe, dout = self.H, self.npe, self.dout
+        grads = alloc_grads(self.view + self.base)
+        plv = self.view[n - 1]
+        nb = plv.out - dout
+        Dv = [_buf(P, H, dev, zero=False) for _ in range(n - 1)] + [_buf(P, plv.out, dev, zero=False)]
+        call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
+             ptr(Dv[n - 1]), Dv[n - 1].shape[1])
+        dVIN = _buf(P, self.view[0].inp, dev, zero=False)
+        cb = ChainBuilder(P, "LOAD", k8(plv.out))
+        cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
+        for i in range(n - 1, 0, -1):
+            pl = self.view[i]
+            cb.step("MULMASK", pl.frag("bwd"), k8(pl.out), pl.inp, X1=HV[i], C1=Dv[i - 1])
+        pl0 = self.view[0]
+        cb.step("NONE", pl0.frag("bwd"), k8(pl0.out), pl0.inp, C1=dVIN, act_write=0)
+        cb.launch()
+        # base head: d color_base = direct + through the view branch's input columns
+        plb = self.base[n - 1]
+        Db = [_buf(P, H, dev, zero=False) for _ in range(n - 1)] + [_buf(P, plb.out, dev, zero=False)]
+        call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (H + npe), dVIN.shape[1],
+             dout, None, 0, 0, P, ptr(Db[n - 1]), Db[n - 1].shape[1])
+        dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)
+        cb = ChainBuilder(P, "LOAD", k8(plb.out))
+        cb.init_load(Db[n - 1], Db[n - 1].shape[1])
+        for i in range(n - 1, 0, -1):
+            pl = self.base[i]
+            if i == n - 1:   # the hidden tap's adjoint from the view branch joins before the ReLU mask
+                cb.step("ADDMASK", pl.frag("bwd"), k8(pl.out), pl.inp, X1=HB[i], X2=dVIN, C1=Db[i - 1])
+            else:
+                cb.step("MULMASK", pl.frag("bwd"), k8(pl.out), pl.inp, X1=HB[i], C1=Db[i - 1])
+        pb0 = self.base[0]
+        cb.step("NONE", pb0.frag("bwd_hid:%d" % self.F), k8(pb0.out), self.F, C1=dCIN, act_write=0)
+        cb.launch()
+        jobs = []
+        for i, pl in enumerate(self.view):
+            jobs.append((Dv[i], pl.out, HV[i], pl.in_pad, grads[i][0], grads[i][1]))
+        for i, pl in enumerate(self.base):
+            jobs.append((Db[i], pl.out, HB[i], pl.in_pad, grads[n + i][0], grads[n + i][1]))
+        gemm_tn_grouped(jobs, P)
+        return unpack_group(self.view + self.base, grads), dCIN[:P]
+
+    def _forward_layers(self, CIN, rays_d, S, P, keep_state=True):
         """CIN [P, pad(F+3)] = [feature F | pts 3 | 0] (written by the UDF head + nudf_copy_cols)."""
         dev = CIN.device
         n = self.n
@@ -820,7 +933,7 @@ class ColorEngine:
         st = dict(HB=HB, HV=HV, P=P) if keep_state else None
         return color_base, color, (logits if nb > 0 else None), st
 
-    def backward(self, st, color_base, color, d_cb, d_color, d_logits):
+    def _backward_layers(self, st, color_base, color, d_cb, d_color, d_logits):
         """-> (param grads in params() order, d_feat buffer [P, pad(F+3)] whose cols 0..F-1 are d feature)."""
         P, n = st["P"], self.n
         HB, HV = st["HB"], st["HV"]
