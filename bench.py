@@ -282,7 +282,7 @@ def composite_roofline(dev, N, S, reps=50):
             _fill_composite(a, c, n, s, 0)
             bufs = [torch.empty(n, s, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev),
                     torch.empty(n, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, device=dev),
-                    torch.empty(n, device=dev), torch.zeros(5, device=dev)]
+                    torch.empty(n, device=dev), torch.empty(5, device=dev)]
             (a.weights, a.out_color, a.out_color_base, a.out_depth, a.out_normals, a.out_wsum, a.out_wsum_all,
              a.sums) = [ptr(b) for b in bufs]
             ws = torch.empty(5 * ((n + 3) // 4), device=dev)

@@ -119,7 +119,8 @@ typedef struct NudfComposite {
   float* out_depth;                            /* [N]                                       */
   float* out_normals;                          /* [N,3]                                     */
   float* out_wsum; float* out_wsum_all;        /* [N]                                       */
-  float* sums;                                 /* [5] += {eik_num, eik_den, eikns_num, eikns_den, sparse_sum} (caller zeroes) */
+  float* sums;                                 /* [5] {eik_num, eik_den, eikns_num, eikns_den, sparse_sum}: assigned when ws is
+                                                  given, += (caller zeroes) on the atomic path */
   float* ws;                                   /* scratch [5 * ceil(N/4)] for per-block partial sums (two-stage,
                                                   deterministic; NULL = one atomic per block and sum, which serialises
                                                   at the memory side for large N) */
@@ -143,7 +144,7 @@ typedef struct NudfCompositeGrad {
   float* o_d_color; float* o_d_color_base;            /* [N,S,3] or NULL                    */
   float* o_d_bg_sigma;                                /* [N,n_out] or NULL                  */
   float* o_d_bg_color;                                /* [N,n_out,3] or NULL                */
-  float* o_d_scal;                                    /* [3] += d inv_s, d beta, d gamma (caller zeroes) */
+  float* o_d_scal;                                    /* [3] d inv_s, d beta, d gamma: assigned when ws is given, += otherwise */
   float* ws;                                          /* scratch [3 * ceil(N/4)] or NULL (see NudfComposite.ws) */
 } NudfCompositeGrad;
 
@@ -412,7 +413,7 @@ int nudf_scalars_bwd(const float* variance, const float* beta, const float* gamm
                      float* d_param, void* stream);
 
 /* sum_i |pred_i - gt_i| (the numerator of ColorPixelLoss, loss/loss.py:37-43) and its backward
- * d_pred_i = d_out * sign(pred_i - gt_i).  out[0] += sum (caller zeroes). */
+ * d_pred_i = d_out * sign(pred_i - gt_i).  out[0] = sum (one workgroup: these are [N,3] tensors). */
 int nudf_l1_sum_fwd(const float* pred, const float* gt, int n, float* out, void* stream);
 int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const float* d_out, float* d_pred, void* stream);
 

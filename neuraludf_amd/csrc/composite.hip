@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
   }
 }
 
-// out[k] += sum_b ws[b * K + k]  (one block; fixed order -> deterministic batch-global sums)
+// out[k] = sum_b ws[b * K + k]  (one block; fixed order -> deterministic batch-global sums; ASSIGNS)
 __global__ __launch_bounds__(256) void partial_sums_kernel(const float* __restrict__ ws, int nblk, int K,
                                                            float* __restrict__ out) {
   __shared__ float red[256];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void partial_sums_kernel(const float* __restri
       if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[k] += red[0];
+    if (threadIdx.x == 0) out[k] = red[0];
     __syncthreads();
   }
 }

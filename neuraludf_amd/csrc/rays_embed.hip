@@ -149,27 +149,37 @@ extern "C" int nudf_posenc(const float* x, int xld, int xdiv, const float* tange
 }
 
 // VJP of the encoding: g[p, j] = in_scale * sum_e dE[p,e] * dE_e/dx_j, dE gathered from up to two
-// sources (scaled).  One thread per point (D*(2L+1) reads, D writes).
-__global__ void posenc_vjp_kernel(const float* __restrict__ x, int xld, int D, int L, float in_scale, int P,
-                                  const float* __restrict__ s1, int ld1, float c1, const float* __restrict__ s2,
-                                  int ld2, float c2, float* __restrict__ g) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  for (int j = 0; j < D; ++j) {
-    float xv = x[(size_t)p * xld + j] * in_scale;
-    auto de = [&](int e) {
-      float t = 0.f;
-      if (s1) t += s1[(size_t)p * ld1 + e] * c1;
-      if (s2) t += s2[(size_t)p * ld2 + e] * c2;
-      return t;
-    };
-    float acc = de(j);
+// sources (scaled).  One block per 64 points: the dE rows are staged in LDS with coalesced reads (a thread
+// walking its own row touches 64 different cache lines per load), then one thread per (point, dimension).
+#define PV_PTS 64
+#define PV_MAXE 96
+__global__ __launch_bounds__(256) void posenc_vjp_kernel(const float* __restrict__ x, int xld, int D, int L,
+                                                         float in_scale, int P, const float* __restrict__ s1, int ld1,
+                                                         float c1, const float* __restrict__ s2, int ld2, float c2,
+                                                         float* __restrict__ g) {
+  __shared__ float de[PV_PTS][PV_MAXE + 1];
+  const int E = D * (2 * L + 1);
+  const int p0 = blockIdx.x * PV_PTS;
+  for (int idx = threadIdx.x; idx < PV_PTS * E; idx += 256) {
+    const int r = idx / E, e = idx - r * E;
+    const int p = min(p0 + r, P - 1);
+    float t = 0.f;
+    if (s1) t += s1[(size_t)p * ld1 + e] * c1;
+    if (s2) t += s2[(size_t)p * ld2 + e] * c2;
+    de[r][e] = t;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < PV_PTS * D; idx += 256) {
+    const int r = idx / D, j = idx - r * D;
+    const int p = p0 + r;
+    if (p >= P) continue;
+    const float xv = x[(size_t)p * xld + j] * in_scale;
+    float acc = de[r][j];
     for (int k = 0; k < L; ++k) {
-      float f = (float)(1 << k);
-      float a = xv * f;
+      const float f = (float)(1 << k);
       float sn, cs;
-      sincosf(a, &sn, &cs);
-      acc += f * (de(D * (1 + 2 * k) + j) * cs - de(D * (2 + 2 * k) + j) * sn);
+      sincosf(xv * f, &sn, &cs);
+      acc += f * (de[r][D * (1 + 2 * k) + j] * cs - de[r][D * (2 + 2 * k) + j] * sn);
     }
     g[(size_t)p * D + j] = acc * in_scale;
   }
@@ -177,7 +187,11 @@ __global__ void posenc_vjp_kernel(const float* __restrict__ x, int xld, int D, i
 extern "C" int nudf_posenc_vjp(const float* x, int xld, int D, int L, float in_scale, int P, const float* src1, int ld1,
                                float scale1, const float* src2, int ld2, float scale2, float* g, void* stream) {
   if (P == 0) return 0;
-  hipLaunchKernelGGL(posenc_vjp_kernel, dim3(nblocks(P, 256)), dim3(256), 0, (hipStream_t)stream, x, xld, D, L,
+  if (D * (2 * L + 1) > PV_MAXE) {
+    nudf_set_error("nudf_posenc_vjp: encoding wider than 96", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(posenc_vjp_kernel, dim3(nblocks(P, PV_PTS)), dim3(256), 0, (hipStream_t)stream, x, xld, D, L,
                      in_scale, P, src1, ld1, scale1, src2, ld2, scale2, g);
   NUDF_CHECK_LAUNCH("nudf_posenc_vjp");
   return 0;
@@ -250,23 +264,34 @@ extern "C" int nudf_udf_head_bwd(const float* sign, const float* dudf, const flo
 }
 
 // sign-weighted column sums: out[c] += sum_p sign[p] * R[p, c]  (gradient of row 0 of the last
-// UDF layer through the d udf/dx path).  Block = 256 rows x C columns.
-__global__ void signed_colsum_kernel(const float* __restrict__ sign, const float* __restrict__ R, int ldr, int P, int C,
-                                     float scale, float* __restrict__ out) {
-  int c = threadIdx.x;
-  int p0 = blockIdx.x * 256;
-  int p1 = min(p0 + 256, P);
-  for (; c < C; c += blockDim.x) {
-    float acc = 0.f;
-    for (int p = p0; p < p1; ++p) acc += sign[p] * R[(size_t)p * ldr + c];
-    atomicAdd(out + c, acc * scale);
+// UDF layer through the d udf/dx path).  Block = 64 rows x C columns, 4 row groups of 16 rows with the
+// loads of a group independent (the old 256-row serial walk per thread was latency-bound at 100 us).
+__global__ __launch_bounds__(256) void signed_colsum_kernel(const float* __restrict__ sign, const float* __restrict__ R,
+                                                            int ldr, int P, int C, float scale,
+                                                            float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c0 = blockIdx.y * 64;
+  const int c = c0 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  const int p0 = blockIdx.x * 256 + grp * 64;
+  float acc = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      const int p = p0 + i;
+      if (p < P) acc += sign[p] * R[(size_t)p * ldr + c];
+    }
   }
+  part[grp][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C)
+    atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * scale);
 }
 extern "C" int nudf_signed_colsum(const float* sign, const float* R, int ldr, int P, int C, float scale, float* out,
                                   void* stream) {
   if (P == 0) return 0;
-  hipLaunchKernelGGL(signed_colsum_kernel, dim3(nblocks(P, 256)), dim3(256), 0, (hipStream_t)stream, sign, R, ldr, P, C,
-                     scale, out);
+  hipLaunchKernelGGL(signed_colsum_kernel, dim3(nblocks(P, 256), (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     sign, R, ldr, P, C, scale, out);
   NUDF_CHECK_LAUNCH("nudf_signed_colsum");
   return 0;
 }
@@ -516,21 +541,23 @@ extern "C" int nudf_scalars_bwd(const float* variance, const float* beta, const 
   return 0;
 }
 
-__global__ __launch_bounds__(256) void l1_sum_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
-                                                         int n, float* out) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void l1_sum_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                          int n, float* out) {
+  __shared__ float red[16];
   float acc = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += fabsf(pred[i] - gt[i]);
+  for (int i = threadIdx.x; i < n; i += 1024) acc += fabsf(pred[i] - gt[i]);
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t;
+  }
 }
 extern "C" int nudf_l1_sum_fwd(const float* pred, const float* gt, int n, float* out, void* stream) {
   if (n <= 0) return 0;
-  int nb = (n + 1023) / 1024;
-  if (nb > 64) nb = 64;     // <= 64 atomics on one address
-  hipLaunchKernelGGL(l1_sum_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, gt, n, out);
+  hipLaunchKernelGGL(l1_sum_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, gt, n, out);
   NUDF_CHECK_LAUNCH("nudf_l1_sum_fwd");
   return 0;
 }

@@ -18,7 +18,7 @@ class _L1SumFn(torch.autograd.Function):
     def forward(ctx, pred, gt):
         from .._lib import call, ptr
         p, g = pred.detach().contiguous(), gt.detach().contiguous()
-        out = torch.zeros(1, device=p.device)
+        out = torch.empty(1, device=p.device)
         call("nudf_l1_sum_fwd", ptr(p), ptr(g), p.numel(), ptr(out))
         ctx.save_for_backward(p, g)
         return out[0]

@@ -65,8 +65,8 @@ class _CompositeFn(torch.autograd.Function):
         normals = torch.empty(N, 3, device=dev)
         wsum = torch.empty(N, 1, device=dev)
         wsum_all = torch.empty(N, 1, device=dev)
-        sums = torch.zeros(5, device=dev)
-        ws = torch.empty(5 * ((N + 3) // 4), device=dev)     # per-block partial sums (two-stage reduction)
+        sums = torch.empty(5, device=dev)                     # assigned by the two-stage reduction (ws given)
+        ws = torch.empty(5 * ((N + 3) // 4), device=dev)     # per-block partial sums
         a.ws = ptr(ws)
         a.weights, a.out_color, a.out_color_base = ptr(weights), ptr(out_color), ptr(out_cb)
         a.out_depth, a.out_normals, a.out_wsum, a.out_wsum_all, a.sums = (ptr(depth), ptr(normals), ptr(wsum),
@@ -109,7 +109,7 @@ class _CompositeFn(torch.autograd.Function):
         o_cb = torch.empty(N, S, 3, device=dev)
         o_sig = torch.empty(N, n_out, device=dev) if n_out else None
         o_bgc = torch.empty(N, n_out, 3, device=dev) if n_out else None
-        o_scal = torch.zeros(3, device=dev)
+        o_scal = torch.empty(3, device=dev)                   # assigned (ws given)
         ws = torch.empty(3 * ((N + 3) // 4), device=dev)
         g.ws = ptr(ws)
         g.o_d_udf, g.o_d_grad, g.o_d_color, g.o_d_color_base = ptr(o_udf), ptr(o_grad), ptr(o_col), ptr(o_cb)
@@ -145,8 +145,9 @@ class _ScalarsFn(torch.autograd.Function):
 
 
 class _ErrorsFn(torch.autograd.Function):
-    """[eik_num, eik_den, eikns_num, eikns_den, sparse_sum] -> [gradient_error, gradient_error_near_surface,
-    sparse_error] (:531-536, 553), one launch each way."""
+    """[eik_num, eik_den, eikns_num, eikns_den, sparse_sum] -> (gradient_error, gradient_error_near_surface,
+    sparse_error) (:531-536, 553), one launch each way.  Three separate 0-d outputs: indexing one [3] tensor would
+    cost a zero-fill + scatter per consumer in the backward."""
 
     @staticmethod
     def forward(ctx, sums, n_rays):
@@ -156,15 +157,17 @@ class _ErrorsFn(torch.autograd.Function):
         call("nudf_sums_errors_fwd", ptr(sums), float(n_rays), ptr(err))
         ctx.save_for_backward(sums)
         ctx.n_rays = float(n_rays)
-        return err
+        return err[0], err[1], err[2]
 
     @staticmethod
-    def backward(ctx, d_err):
-        if d_err is None:
+    def backward(ctx, d0, d1, d2):
+        if d0 is None and d1 is None and d2 is None:
             return None, None
         (sums,) = ctx.saved_tensors
+        z = sums.new_zeros(())
+        d_err = torch.stack([d if d is not None else z for d in (d0, d1, d2)])
         d = torch.empty(5, device=sums.device)
-        call("nudf_sums_errors_bwd", ptr(sums), ctx.n_rays, ptr(d_err.contiguous()), ptr(d))
+        call("nudf_sums_errors_bwd", ptr(sums), ctx.n_rays, ptr(d_err), ptr(d))
         return d, None
 
 
@@ -360,8 +363,7 @@ class UDFRendererBlending:
         if self.data_parallel:
             sums = nudf_dist.all_reduce_sum(sums)
         n_rays = float(N) * (nudf_dist.world_size() if self.data_parallel else 1)
-        err = _ErrorsFn.apply(sums, n_rays)
-        gradient_error, gradient_error_ns, sparse_error = err[0], err[1], err[2]       # (:533, :536, :553)
+        gradient_error, gradient_error_ns, sparse_error = _ErrorsFn.apply(sums, n_rays)   # (:533, :536, :553)
 
         color_pixel = patch_colors = patch_mask = None
         if color_maps is not None:
