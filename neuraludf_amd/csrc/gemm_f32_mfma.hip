@@ -11,6 +11,7 @@
 #include "nudf_common.h"
 #include "nudf_gemm.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -352,61 +353,46 @@ __device__ __forceinline__ void gemm_tn_body(const NudfGemmTN& p, float* smem, i
   }
   __syncthreads();
 
-  const bool full = acti && acti1 && actj0 && actj1;
+  // straight-line MFMA code for each of the four live-tile shapes of a wave (NI x NJ of its 2 x 2 tiles): a
+  // partially live wave (N ends inside its 64 x 64) does proportionally fewer MFMAs and has no branches inside
+  const int ni = acti ? (acti1 ? 2 : 1) : 0, nj = actj0 ? (actj1 ? 2 : 1) : 0;
+  auto mma_tile = [&](auto NI, auto NJ, int cur) {
+    constexpr int kNI = decltype(NI)::value, kNJ = decltype(NJ)::value;
+    const float* as = As + cur * T_TILE + (lane >> 5) * LDT_S + wm * 64 + (lane & 31);
+    const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT_S + wn * 64 + (lane & 31);
+    float av[2][4][2], bv[2][4][2];
+    auto rd = [&](int set, int c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kk = c * 4 + q;
+#pragma unroll
+        for (int i = 0; i < kNI; ++i) av[set][q][i] = as[(2 * kk) * LDT_S + 32 * i];
+#pragma unroll
+        for (int j = 0; j < kNJ; ++j) bv[set][q][j] = bs[(2 * kk) * LDT_S + 32 * j];
+      }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      if (c + 1 < BK / 8) rd((c + 1) & 1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+          for (int i = 0; i < kNI; ++i) acc[i][j] = mfma32(av[c & 1][q][i], bv[c & 1][q][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
     __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
-    if (full) {
-      // straight-line, software-pipelined in chunks of 4 k pairs: the 16 LDS reads of chunk c+1 are in flight
-      // under the 16 MFMAs of chunk c (two register sets)
-      const float* as = As + cur * T_TILE + (lane >> 5) * LDT_S + wm * 64 + (lane & 31);
-      const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT_S + wn * 64 + (lane & 31);
-      float av[2][4][2], bv[2][4][2];
-      auto rd = [&](int set, int c) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int kk = c * 4 + q;
-          av[set][q][0] = as[(2 * kk) * LDT_S];
-          av[set][q][1] = as[(2 * kk) * LDT_S + 32];
-          bv[set][q][0] = bs[(2 * kk) * LDT_S];
-          bv[set][q][1] = bs[(2 * kk) * LDT_S + 32];
-        }
-      };
-      rd(0, 0);
-#pragma unroll
-      for (int c = 0; c < BK / 8; ++c) {
-        if (c + 1 < BK / 8) rd((c + 1) & 1, c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0][0] = mfma32(av[c & 1][q][0], bv[c & 1][q][0], acc[0][0]);
-          acc[1][0] = mfma32(av[c & 1][q][1], bv[c & 1][q][0], acc[1][0]);
-          acc[0][1] = mfma32(av[c & 1][q][0], bv[c & 1][q][1], acc[0][1]);
-          acc[1][1] = mfma32(av[c & 1][q][1], bv[c & 1][q][1], acc[1][1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else if (acti && actj0) {
-      const float* as = As + cur * T_TILE + (lane >> 5) * LDT_S + wm * 64 + (lane & 31);
-      const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT_S + wn * 64 + (lane & 31);
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float a0 = as[(2 * kk) * LDT_S];
-        float b0 = bs[(2 * kk) * LDT_S];
-        acc[0][0] = mfma32(a0, b0, acc[0][0]);
-        float a1 = 0.f, b1 = 0.f;
-        if (acti1) {
-          a1 = as[(2 * kk) * LDT_S + 32];
-          acc[1][0] = mfma32(a1, b0, acc[1][0]);
-        }
-        if (actj1) {
-          b1 = bs[(2 * kk) * LDT_S + 32];
-          acc[0][1] = mfma32(a0, b1, acc[0][1]);
-          if (acti1) acc[1][1] = mfma32(a1, b1, acc[1][1]);
-        }
-      }
-    }
+    if (ni == 2 && nj == 2) mma_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, cur);
+    else if (ni == 2 && nj == 1) mma_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cur);
+    else if (ni == 1 && nj == 2) mma_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, cur);
+    else if (ni == 1 && nj == 1) mma_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cur);
     __builtin_amdgcn_sched_barrier(0);
     if (do_bias && kt < nk1) {  // column sums of the first pair's A (bias gradient)
       const float* as = As + cur * T_TILE + tid;
@@ -540,8 +526,9 @@ extern "C" int nudf_gemm_tn(const NudfGemmTN* args, void* stream) {
   }
   const int tiles = ((p.NA + BM - 1) / BM) * ((p.NB + BN - 1) / BN);
   if (p.rows_per_block <= 0) {
-    // aim for ~2 blocks per CU (512 blocks) but at least 8 k-steps per block
-    int chunks = (512 + tiles - 1) / tiles;
+    // one resident wave of workgroups (2 per CU = 512 blocks, never more), at least 8 k-steps per block
+    int chunks = 512 / tiles;
+    if (chunks < 1) chunks = 1;
     int rpb = (p.M + chunks - 1) / chunks;
     rpb = ((rpb + BK - 1) / BK) * BK;
     if (rpb < 8 * BK) rpb = 8 * BK;
@@ -572,7 +559,12 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   }
   g.total_tiles = tiles;
   if (g.rows_per_block <= 0) {
-    int chunks = (640 + tiles - 1) / tiles;   // ~2.5 blocks per CU
+    // exactly one resident wave of workgroups (2 per CU x 256 CUs): 640 blocks measured 348 us where 512 take
+    // 274 us -- a second, partial wave of blocks costs a whole extra pass (NUDF_TNG_BLOCKS: tuning hook)
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
+    int chunks = target / tiles;
+    if (chunks < 1) chunks = 1;
     int rpb = (g.M + chunks - 1) / chunks;
     rpb = ((rpb + BK - 1) / BK) * BK;
     if (rpb < 8 * BK) rpb = 8 * BK;
