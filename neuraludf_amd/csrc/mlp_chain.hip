@@ -408,8 +408,8 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
   // Workgroups that share a CU start in lock-step and would then always be in the same phase (K loop: both
   // want the MFMA pipe; epilogue: both want the VALU).  Delay the waves in odd hardware wave slots once, so
   // that one workgroup's epilogues run under the other's MFMA phases.  Speed only.
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
   if (gridDim.x > 256) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
     const unsigned k = (TM == 64) ? (slot & 1u) * 2u : (slot % 3u);
     for (unsigned d = 0; d < k; ++d) __builtin_amdgcn_s_sleep(127);
   }
@@ -423,6 +423,10 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
   // ---- the layer chain ---------------------------------------------------------------------------
   for (int si = 0; si < p.n_steps; ++si) {
     const NudfChainStep& st = p.step[si];
+    // The SIMD's issue arbiter prefers the OLDER of the two co-resident waves, so without help one workgroup of a
+    // CU runs every layer at full MFMA rate and its partner only in the gaps (the kernel then ends with half the
+    // wave slots idle for ~13 % of its time).  Alternate the priority layer by layer: speed only.
+    __builtin_amdgcn_s_setprio(((si + slot) & 1u) ? 1 : 0);
     const int G = st.K >> 3;                 // k groups of 8
     const int NT = (st.N + 31) >> 5;         // 32-column tiles
     const f32x4* __restrict__ Bp = reinterpret_cast<const f32x4*>(st.Bp);
