@@ -401,6 +401,8 @@ class UDFRendererBlending:
                rays_uv=None):
         dev = rays_o.device
         N = len(rays_o)
+        if N == 0:
+            return self._empty_result(dev, color_maps is not None, rays_uv is not None)
         rays_o = rays_o.detach().float().contiguous()
         rays_d = rays_d.detach().float().contiguous()
         if not isinstance(near, torch.Tensor):
@@ -465,6 +467,24 @@ class UDFRendererBlending:
         ret['variance'] = ret.pop('s_val')
         ret['z_vals'] = z_vals
         ret['sparse_random_error'] = sparse_random_error
+        return ret
+
+    def _empty_result(self, dev, pixel, patch):
+        """the result dict for an empty ray batch (validation chunks can be empty): empty per-ray tensors, zero sums."""
+        S = self.n_samples + (self.n_importance if self.n_importance > 0 else 0)
+        e = lambda *shape: torch.zeros(*shape, device=dev)
+        npx = (2 * self.h_patch_size + 1) ** 2
+        ret = {
+            'color_base': e(0, 3), 'color': e(0, 3), 'color_pixel': e(0, 3) if pixel else None,
+            'patch_colors': e(0, npx, 3) if patch else None, 'patch_mask': e(0) if patch else None,
+            'weights': e(0, S + self.n_outside), 'variance': e(1, 1), 'beta': e(1), 'gamma': e(1), 'depth': e(0, 1),
+            'gradient_error': e(()), 'gradient_error_near_surface': e(()), 'normals': e(0, 3), 'gradients': e(0, S, 3),
+            'udf': e(0, S), 'sparse_error': e(()), 'weight_sum': e(0, 1), 'weight_sum_fg_bg': e(0, 1),
+            'z_vals': e(0, S), 'sparse_random_error': 0.0,
+        }
+        for k in ['gradients_flip', 'inside_sphere', 'gradient_mag', 'true_cos', 'vis_prob', 'alpha', 'alpha_plus',
+                  'alpha_minus', 'mid_z_vals', 'dists', 'alpha_occ', 'raw_occ']:
+            ret[k] = e(0, S, 3) if k == 'gradients_flip' else e(0, S)
         return ret
 
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.01, device='cpu'):
