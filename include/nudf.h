@@ -323,6 +323,8 @@ typedef struct NudfChainStep {
   int32_t iparam;
   int32_t ldx1, ldx2, ldc1, ldc2;
   int32_t ldr1;                    /* element stride of r1_row                                       */
+  int32_t prec;                    /* MFMA operand precision: 0 = fp32 (exact), 1 = fp16, 2 = bf16 (fp32 accumulate;
+                                      Bp then holds the 16-bit fragment layout of nudf_weightnorm_pack_multi)     */
   int32_t act_write;               /* 1: the outputs become the next step's activation tile          */
   int32_t act_col0;                /* ... at tile columns [act_col0, act_col0 + N)                   */
   int32_t pe_tail_col;             /* >= 0: afterwards write PE(x)*pe_tail_scale at these tile columns ...       */
@@ -362,13 +364,15 @@ int nudf_pack_frag(const float* B, int ldb, int K, int N, float* out, void* stre
  * (torch.nn.utils.weight_norm at fields.py:175-176, 433-446).
  * ---------------------------------------------------------------------------------- */
 #define NUDF_PACK_MAX_LAYERS 16
-#define NUDF_PACK_MAX_FRAGS 3
+#define NUDF_PACK_MAX_FRAGS 4
 typedef struct NudfPackFrag {
   float* dst;                      /* fragment-ordered [K, N] operand (zero-initialised by the caller once)     */
   int32_t transpose;               /* 1: B[k][n] = W[o0 + n][i0 + k] (W^T, forward sweeps); 0: B[k][n] = W[o0 + k][i0 + n] */
   int32_t o0, i0;                  /* offsets into the packed [out, in] matrix                                  */
   int32_t K, N;
-  int32_t pad_;
+  int32_t dtype;                   /* 0: fp32 fragments (nudf_pack_frag layout); 1 / 2: fp16 / bf16 fragments for
+                                      v_mfma_f32_32x32x16_*: dst16[((g*NT + T)*64 + lane)*8 + j] =
+                                      B[16g + 8(lane>>5) + j][32T + (lane&31)], round-to-nearest-even             */
 } NudfPackFrag;
 typedef struct NudfPackLayer {
   const float* v; const float* g;  /* weight_v [out,in], weight_g [out] (NULL: plain Linear)                    */

@@ -120,7 +120,7 @@ CH_INIT = dict(LOAD=0, POSENC=1, SEED=2)
 class ChainStep(C.Structure):
     _fields_ = [("Bp", c_fp), ("bias", c_fp), ("X1", c_fp), ("X2", c_fp), ("C1", c_fp), ("C2", c_fp),
                 ("r1_row", c_fp), ("r1_col", c_fp), ("K", i32), ("N", i32), ("epi", i32), ("iparam", i32),
-                ("ldx1", i32), ("ldx2", i32), ("ldc1", i32), ("ldc2", i32), ("ldr1", i32), ("act_write", i32),
+                ("ldx1", i32), ("ldx2", i32), ("ldc1", i32), ("ldc2", i32), ("ldr1", i32), ("prec", i32), ("act_write", i32),
                 ("act_col0", i32), ("pe_tail_col", i32), ("ld_pe", i32), ("pe_dst", c_fp), ("pe_tail_scale", f32),
                 ("scale", f32), ("xscale", f32)]
 
@@ -133,11 +133,11 @@ class Chain(C.Structure):
 
 
 PACK_MAX_LAYERS = 16
-PACK_MAX_FRAGS = 3
+PACK_MAX_FRAGS = 4
 
 
 class PackFrag(C.Structure):
-    _fields_ = [("dst", c_fp), ("transpose", i32), ("o0", i32), ("i0", i32), ("K", i32), ("N", i32), ("pad_", i32)]
+    _fields_ = [("dst", c_fp), ("transpose", i32), ("o0", i32), ("i0", i32), ("K", i32), ("N", i32), ("dtype", i32)]
 
 
 class PackLayer(C.Structure):

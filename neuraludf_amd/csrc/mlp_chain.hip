@@ -24,6 +24,10 @@
                            // 16 distinct multiples of 4 -> conflict-free ds_read_b128
 #define CH_THREADS 256
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ f32x16 ch_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -173,6 +177,63 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// 16-bit-operand K loop (BASELINE config 5: fp16 / bf16 MFMA operands, fp32 accumulate, fp32 everywhere else):
+// v_mfma_f32_32x32x16_{f16,bf16}; lane (i, h) contracts k = 16g + 8h .. +7, i.e. two ds_read_b128 of the fp32
+// activation tile converted on the fly (v_cvt_pk_*_f32, round-to-nearest-even) and one 16-byte read of the
+// pre-converted weight fragments per 32-column tile.  16x the fp32 MFMA rate and a separate matrix pipe: the
+// sweep becomes epilogue / LDS bound.
+template <int NRT, int NCT, bool BF>
+__device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride,
+                                         int G16, f32x16 (&acc)[2][2]) {
+  f32x4 a0[NRT][2], a1[NRT][2];
+  uint4 b0[NCT], b1[NCT];
+  auto lda = [&](f32x4 (&a)[NRT][2], int g) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+      a[i][0] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16);
+      a[i][1] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16 + 4);
+    }
+  };
+  auto ldb = [&](uint4 (&b)[NCT], int g) {
+    const uint4* bq = bptr + (size_t)g * bstride;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) b[j] = bq[j * 64];
+  };
+  auto mma = [&](f32x4 (&a)[NRT][2], uint4 (&b)[NCT]) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+      const f32x8 av = {a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]};
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) {
+        if (BF)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_convertvector(av, bf16x8),
+                                                              __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_convertvector(av, f16x8),
+                                                             __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  lda(a0, 0);
+  ldb(b0, 0);
+  int g = 0;
+#pragma unroll 1
+  for (; g + 1 < G16; g += 2) {
+    lda(a1, g + 1);
+    ldb(b1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int gn = (g + 2 < G16) ? g + 2 : g + 1;
+    lda(a0, gn);
+    ldb(b0, gn);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (g < G16) mma(a0, b0);   // odd number of 16-wide k steps
+}
+
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
 // One 32x32 accumulator tile of a step's epilogue.  Branch-free per element: uniform options are tested once
 // around whole 16-element loops, the column predicate (N may end inside the tile) is one exec region, rows
@@ -180,7 +241,7 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
 // Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
 template <int EPI>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
-                                                 int h, int ln, f32x16 a, const float (&x1)[16]) {
+                                                 int h, int ln, f32x16 a, float (&x1)[16], bool load_x1) {
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -198,7 +259,12 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo] * r1c;
   }
-  float x2[16];   // x1 (the stored activation) was prefetched under the K loop
+  float x2[16];   // x1 (the stored activation) was prefetched under the fp32 K loop; the short 16-bit loops load it here
+  if (CH_USES_X1(EPI) && load_x1) {
+    const unsigned vo = grow0 * (unsigned)st.ldx1 + colc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
+  }
   if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD || EPI == NUDF_CH_ADDMASK) {
     if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
@@ -353,12 +419,12 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
         }
         break;
     }
-    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1);
+    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, st.prec != 0);
   }
 }
 
 template <int TM>
-__global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kernel(NudfChain p) {
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
   constexpr int WMT = TM / 32;  // row tiles per wave in the wide layout
   __shared__ __attribute__((aligned(16))) ChainSmem<TM> sm;
   const int tid = threadIdx.x;
@@ -426,7 +492,7 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
     // The SIMD's issue arbiter prefers the OLDER of the two co-resident waves, so without help one workgroup of a
     // CU runs every layer at full MFMA rate and its partner only in the gaps (the kernel then ends with half the
     // wave slots idle for ~13 % of its time).  Alternate the priority layer by layer: speed only.
-    __builtin_amdgcn_s_setprio(((si + slot) & 1u) ? 1 : 0);
+    if ((si + slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     const int G = st.K >> 3;                 // k groups of 8
     const int NT = (st.N + 31) >> 5;         // 32-column tiles
     const f32x4* __restrict__ Bp = reinterpret_cast<const f32x4*>(st.Bp);
@@ -470,7 +536,16 @@ __global__ __launch_bounds__(CH_THREADS, (TM == 64) ? 2 : 3) void mlp_chain_kern
           const int col = (ct0 + j) * 32 + ln;
           pf.vo[i][j] = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx1 + (unsigned)((col < st.N) ? col : 0);
         }
-      if (pfx) {
+      if (st.prec != 0) {
+        const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
+        const uint4* bp16 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 64 + lane;
+        const int G16 = st.K >> 4;
+        const bool bf = st.prec == 2;
+        if (nrt == 2 && nct == 2) { if (bf) ch_mma16<2, 2, true>(arow16, bp16, bstride, G16, acc); else ch_mma16<2, 2, false>(arow16, bp16, bstride, G16, acc); }
+        else if (nrt == 2) { if (bf) ch_mma16<2, 1, true>(arow16, bp16, bstride, G16, acc); else ch_mma16<2, 1, false>(arow16, bp16, bstride, G16, acc); }
+        else if (nct == 2) { if (bf) ch_mma16<1, 2, true>(arow16, bp16, bstride, G16, acc); else ch_mma16<1, 2, false>(arow16, bp16, bstride, G16, acc); }
+        else { if (bf) ch_mma16<1, 1, true>(arow16, bp16, bstride, G16, acc); else ch_mma16<1, 1, false>(arow16, bp16, bstride, G16, acc); }
+      } else if (pfx) {
         if (nrt == 2 && nct == 2) ch_mma<2, 2, true>(arow, bptr, bstride, G, acc, pf, px1);
         else if (nrt == 2) ch_mma<2, 1, true>(arow, bptr, bstride, G, acc, pf, px1);
         else if (nct == 2) ch_mma<1, 2, true>(arow, bptr, bstride, G, acc, pf, px1);
@@ -515,7 +590,7 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   for (int i = 0; i < p.n_steps && !bad; ++i) {
     const NudfChainStep& s = p.step[i];
     bad = (s.K & 15) || s.K <= 0 || s.K > 288 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
-          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288);
+          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 2;
   }
   if (bad) {
     nudf_set_error("nudf_mlp_chain: K%16, K<=288, N<=256, x_div>=1, 16-byte aligned packed weights required", hipErrorInvalidValue);

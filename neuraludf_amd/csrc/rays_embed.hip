@@ -422,9 +422,23 @@ __device__ __forceinline__ void frag_store(const NudfPackFrag& f, int o, int c, 
   const int n = f.transpose ? (o - f.o0) : (c - f.i0);
   if (k < 0 || n < 0 || k >= f.K || n >= f.N) return;
   const int NT = (f.N + 31) >> 5;
-  const int g = k >> 3, r = k & 7;
-  const int lane = 32 * (r >> 2) + (n & 31);
-  f.dst[((size_t)(g * NT + (n >> 5)) * 64 + lane) * 4 + (r & 3)] = w;
+  if (f.dtype == 0) {
+    const int g = k >> 3, r = k & 7;
+    const int lane = 32 * (r >> 2) + (n & 31);
+    f.dst[((size_t)(g * NT + (n >> 5)) * 64 + lane) * 4 + (r & 3)] = w;
+  } else {   // 16-bit fragments of v_mfma_f32_32x32x16_{f16,bf16}
+    const int g = k >> 4, r = k & 15;
+    const int lane = 32 * (r >> 3) + (n & 31);
+    unsigned short bits;
+    if (f.dtype == 1) {
+      const _Float16 hv = (_Float16)w;
+      bits = __builtin_bit_cast(unsigned short, hv);
+    } else {
+      const __bf16 bv = (__bf16)w;
+      bits = __builtin_bit_cast(unsigned short, bv);
+    }
+    reinterpret_cast<unsigned short*>(f.dst)[((size_t)(g * NT + (n >> 5)) * 64 + lane) * 8 + (r & 7)] = bits;
+  }
 }
 
 __global__ __launch_bounds__(256) void wn_pack_multi_kernel(NudfPackMulti a) {

@@ -188,6 +188,7 @@ class ChainBuilder:
         s.ldc2 = ldc2 or (C2.shape[1] if (C2 is not None and C2.dim() == 2) else 0)
         s.r1_row, s.ldr1, s.r1_col = self._p(r1_row), ldr1, self._p(r1_col)
         s.K, s.N, s.epi, s.iparam = K, N, CH[epi], iparam
+        s.prec = getattr(Bp, "prec", 0)
         s.act_write, s.act_col0, s.pe_tail_col, s.pe_tail_scale = act_write, act_col0, pe_tail_col, pe_tail_scale
         s.scale, s.xscale = scale, xscale
         self.n += 1
@@ -282,6 +283,8 @@ class PackedLinear:
         'bwd_feat'  rows 1.. of W"""
         f = self._frags.get(kind)
         if f is None:
+            if "@" in kind:
+                raise _lib.NudfError("16-bit fragment %r was not packed (pack_group packs them)" % kind)
             if kind == "fwd":
                 f = pack_frag(self.Wt, self.out_pad, self.inp, self.out)
             elif kind == "bwd":
@@ -323,8 +326,44 @@ class PackedLinear:
         return [dv, db]
 
 
+# MFMA operand precision of the fused chains.  "fp32" (default) is the parity path (exact fp32 MFMA).  "mixed16" is
+# BASELINE config 5 (16-bit MLP weights on the CDNA4 matrix cores): fp16 operands in the forward sweeps (value,
+# input gradient, colour), bf16 operands in the backward sweeps (tiny adjoints need fp32's exponent range), fp32
+# accumulation, fp32 activations / stored state / epilogues / weight gradients / optimizer.  The abs-head column
+# (the UDF value itself) stays in fp32.
+PRECISION = os.environ.get("NUDF_PRECISION", "fp32")
+_PREC = {"f32": 0, "f16": 1, "bf16": 2}
+
+
+def set_precision(name):
+    global PRECISION
+    if name not in ("fp32", "mixed16"):
+        raise ValueError("precision must be 'fp32' or 'mixed16'")
+    PRECISION = name
+
+
+def _sweep_dtype(sweep):
+    """operand dtype of a sweep: 'fwd' (value / input-gradient / colour forward) or 'bwd' (tangent / adjoint)."""
+    if PRECISION == "fp32":
+        return "f32"
+    return "f16" if sweep == "fwd" else "bf16"
+
+
+def _kind(base, sweep):
+    dt = _sweep_dtype(sweep)
+    return base if dt == "f32" else base + "@" + dt
+
+
 def _frag_spec(pl, kind):
-    """(transpose, o0, i0, K, N) of a fragment-ordered operand cut from the packed [out, in] matrix."""
+    """(transpose, o0, i0, K, N, dtype) of a fragment-ordered operand cut from the packed [out, in] matrix."""
+    dtype = 0
+    if "@" in kind:
+        kind, dt = kind.split("@")
+        dtype = _PREC[dt]
+    return _frag_spec32(pl, kind) + (dtype,)
+
+
+def _frag_spec32(pl, kind):
     if kind == "fwd":
         return (1, 0, 0, pl.inp, pl.out)
     if kind == "bwd":
@@ -374,14 +413,15 @@ def pack_group(layers, kinds=None):
             L.out, L.in_, L.ldw, L.ldwt = pl.out, pl.inp, pl.in_pad, pl.out_pad
             L.nfrag, L.row_start = len(ks), rows
             for fi, kind in enumerate(ks):
-                tr, o0, i0, K, N = _frag_spec(pl, kind)
+                tr, o0, i0, K, N, dtype = _frag_spec(pl, kind)
                 f = pl._frags.get(kind)
                 if f is None:
-                    f = torch.zeros(k8(K) // 8 * ((N + 31) // 32) * 256, device=dev, dtype=torch.float32)
-                    f.k_true, f.n_true = K, N
+                    nfl = k8(K) // 8 * ((N + 31) // 32) * 256          # fp32 fragments; 16-bit ones take half
+                    f = torch.zeros(nfl if dtype == 0 else nfl // 2, device=dev, dtype=torch.float32)
+                    f.k_true, f.n_true, f.prec = K, N, dtype
                     pl._frags[kind] = f
                 F = L.frag[fi]
-                F.dst, F.transpose, F.o0, F.i0, F.K, F.N = ptr(f), tr, o0, i0, K, N
+                F.dst, F.transpose, F.o0, F.i0, F.K, F.N, F.dtype = ptr(f), tr, o0, i0, K, N, dtype
             rows += pl.out
         a.n_layers, a.total_rows = len(chunk), rows
         call("nudf_weightnorm_pack_multi", a)
@@ -486,12 +526,18 @@ class UDFEngine:
         """fragment-ordered weight copies each layer needs for the four sweeps."""
         kinds = []
         for l, pl in enumerate(self.layers):
-            if l == self.L:
-                kinds.append(("fwd_head0", "fwd_feat", "bwd_feat"))
+            if l == self.L:      # the abs-head column (udf itself) always in fp32
+                ks = ["fwd_head0", _kind("fwd_feat", "fwd"), _kind("bwd_feat", "bwd")]
             elif l in self.skip:
-                kinds.append(("fwd", "bwd", "bwd_hid:%d" % self.layers[l - 1].out))
+                ks = [_kind("fwd", "fwd"), _kind("bwd", "fwd"), _kind("bwd_hid:%d" % self.layers[l - 1].out, "bwd")]
+                if PRECISION != "fp32":
+                    ks.append(_kind("fwd", "bwd"))
             else:
-                kinds.append(("fwd", "bwd"))
+                # forward value + tangent sweep use W^T ("fwd"), input-gradient + adjoint sweeps use W ("bwd")
+                ks = [_kind("fwd", "fwd"), _kind("bwd", "fwd")]
+                if PRECISION != "fp32":
+                    ks += [_kind("fwd", "bwd"), _kind("bwd", "bwd")]
+            kinds.append(tuple(ks))
         return kinds
 
     def _skip_col(self, l):
@@ -511,7 +557,7 @@ class UDFEngine:
         for l in range(L):
             pl = self.layers[l]
             nxt_skip = (l + 1) in self.skip
-            cb.step("SOFTPLUS", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias,
+            cb.step("SOFTPLUS", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias,
                     C1=X[l + 1] if need_grad_state else None,
                     scale=self.inv_sqrt2 if nxt_skip else 1.0,
                     pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
@@ -530,7 +576,8 @@ class UDFEngine:
                 _zero_cols(feat, F + 3)
             else:
                 _zero_cols(feat, F)
-            cb.step("NONE", pl.frag("fwd_feat"), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat, act_write=0)
+            cb.step("NONE", pl.frag(_kind("fwd_feat", "fwd")), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat,
+                    act_write=0)
         cb.step("UDFHEAD", pl.frag("fwd_head0"), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,
                 act_write=0, scale=1.0 / float(net.scale))
         cb.launch()
@@ -553,13 +600,14 @@ class UDFEngine:
             pl = self.layers[l]
             if l in self.skip:
                 demb_skip = torch.empty(pad_rows(P), Epad, device=dev)
-                cb.step("MULSP", pl.frag("bwd"), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], C2=demb_skip,
+                cb.step("MULSP", pl.frag(_kind("bwd", "fwd")), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], C2=demb_skip,
                         iparam=self.layers[l - 1].out, scale=self.inv_sqrt2, xscale=self._xs(l - 1))
             else:
-                cb.step("MULSP", pl.frag("bwd"), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], xscale=self._xs(l - 1))
+                cb.step("MULSP", pl.frag(_kind("bwd", "fwd")), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1],
+                        xscale=self._xs(l - 1))
         demb0 = torch.empty(pad_rows(P), Epad, device=dev)
         pl0 = self.layers[0]
-        cb.step("NONE", pl0.frag("bwd"), k8(pl0.out), pl0.inp, C1=demb0, act_write=0)
+        cb.step("NONE", pl0.frag(_kind("bwd", "fwd")), k8(pl0.out), pl0.inp, C1=demb0, act_write=0)
         cb.launch()
         g = torch.empty(P, 3, device=dev)
         call("nudf_posenc_vjp", ptr(x), 3, net.d_in, net.multires, float(net.scale), P,
@@ -584,7 +632,8 @@ class UDFEngine:
             for l in range(L):
                 pl = layers[l]
                 nxt_skip = (l + 1) in self.skip
-                cb.step("TANGENT", pl.frag("fwd"), k8(pl.inp), pl.out, X1=X[l + 1], X2=DA[l], C1=R[l + 1], C2=EX[l],
+                cb.step("TANGENT", pl.frag(_kind("fwd", "bwd")), k8(pl.inp), pl.out, X1=X[l + 1], X2=DA[l], C1=R[l + 1],
+                        C2=EX[l],
                         scale=self.inv_sqrt2 if nxt_skip else 1.0, xscale=self._xs(l),
                         pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
                         pe_dst=R[l + 1] if nxt_skip else None)
@@ -608,12 +657,14 @@ class UDFEngine:
             pl = layers[l]
             sc = self.inv_sqrt2 if l in self.skip else 1.0
             if l == L:
-                cb.step("BWD", pl.frag("bwd_feat"), k8(F), layers[l - 1].out, X1=X[l], X2=EX[l - 1] if second else None,
+                cb.step("BWD", pl.frag(_kind("bwd_feat", "bwd")), k8(F), layers[l - 1].out, X1=X[l],
+                        X2=EX[l - 1] if second else None,
                         C1=ABAR[l - 1], r1_row=ABAR[L], ldr1=ABAR[L].shape[1], r1_col=pl.W, scale=sc,
                         xscale=self._xs(l - 1))
             else:
                 n_hid = layers[l - 1].out           # the skip layer's embedding columns carry no parameter gradient
-                cb.step("BWD", pl.frag("bwd" if n_hid == pl.inp else "bwd_hid:%d" % n_hid), k8(pl.out), n_hid, X1=X[l],
+                cb.step("BWD", pl.frag(_kind("bwd" if n_hid == pl.inp else "bwd_hid:%d" % n_hid, "bwd")), k8(pl.out),
+                        n_hid, X1=X[l],
                         X2=EX[l - 1] if second else None, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
         cb.launch()
         for l, pl in enumerate(layers):
@@ -799,9 +850,10 @@ class ColorEngine:
 
     def _kinds(self):
         """fragment copies per layer, in the order base + view (the pack_group order)."""
-        kinds = [("fwd", "bwd_hid:%d" % self.F)]        # d CIN: only the feature columns carry a gradient
-        kinds += [("fwd", "bwd")] * (self.n - 1)
-        kinds += [("fwd", "bwd")] * self.n
+        fw, bw = _kind("fwd", "fwd"), _kind("bwd", "bwd")
+        kinds = [(fw, _kind("bwd_hid:%d" % self.F, "bwd"))]     # d CIN: only the feature columns carry a gradient
+        kinds += [(fw, bw)] * (self.n - 1)
+        kinds += [(fw, bw)] * self.n
         return kinds
 
     def forward(self, CIN, rays_d, S, P, keep_state=True):
@@ -830,21 +882,21 @@ class ColorEngine:
         for l in range(n - 1):
             pl = self.base[l]
             tap = (l == n - 2)      # hidden tap (post-ReLU) also feeds the view branch, then PE(dir) joins the tile
-            cb.step("RELU", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=HB[l + 1] if keep_state else None,
+            cb.step("RELU", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=HB[l + 1] if keep_state else None,
                     C2=VIN if (tap and keep_state) else None, pe_tail_col=H if tap else -1, pe_tail_scale=1.0,
                     pe_dst=VIN if (tap and keep_state) else None)
         color_base = torch.empty(Pp, dout, device=dev)
         pl = self.base[n - 1]
-        cb.step("SIGMOIDN", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=color_base, C2=VIN if keep_state else None,
+        cb.step("SIGMOIDN", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=color_base, C2=VIN if keep_state else None,
                 c2_off=H + npe, iparam=dout, act_write=1, act_col0=H + npe)
         for l in range(n - 1):
             pl = self.view[l]
-            cb.step("RELU", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=HV[l + 1] if keep_state else None)
+            cb.step("RELU", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=HV[l + 1] if keep_state else None)
         pl = self.view[n - 1]
         nb = pl.out - dout
         color = torch.empty(Pp, dout, device=dev)
         logits = torch.empty(Pp, max(nb, 1), device=dev)
-        cb.step("SIGMOIDN", pl.frag("fwd"), k8(pl.inp), pl.out, bias=pl.bias, C1=color, C2=logits if nb > 0 else None,
+        cb.step("SIGMOIDN", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=color, C2=logits if nb > 0 else None,
                 iparam=dout, act_write=0)
         cb.launch()
         st = dict(HB=HB, HV=HV, P=P, chain=True) if keep_state else None
@@ -867,9 +919,9 @@ class ColorEngine:
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
-            cb.step("MULMASK", pl.frag("bwd"), k8(pl.out), pl.inp, X1=HV[i], C1=Dv[i - 1])
+            cb.step("MULMASK", pl.frag(_kind("bwd", "bwd")), k8(pl.out), pl.inp, X1=HV[i], C1=Dv[i - 1])
         pl0 = self.view[0]
-        cb.step("NONE", pl0.frag("bwd"), k8(pl0.out), pl0.inp, C1=dVIN, act_write=0)
+        cb.step("NONE", pl0.frag(_kind("bwd", "bwd")), k8(pl0.out), pl0.inp, C1=dVIN, act_write=0)
         cb.launch()
         # base head: d color_base = direct + through the view branch's input columns
         plb = self.base[n - 1]
@@ -882,11 +934,11 @@ class ColorEngine:
         for i in range(n - 1, 0, -1):
             pl = self.base[i]
             if i == n - 1:   # the hidden tap's adjoint from the view branch joins before the ReLU mask
-                cb.step("ADDMASK", pl.frag("bwd"), k8(pl.out), pl.inp, X1=HB[i], X2=dVIN, C1=Db[i - 1])
+                cb.step("ADDMASK", pl.frag(_kind("bwd", "bwd")), k8(pl.out), pl.inp, X1=HB[i], X2=dVIN, C1=Db[i - 1])
             else:
-                cb.step("MULMASK", pl.frag("bwd"), k8(pl.out), pl.inp, X1=HB[i], C1=Db[i - 1])
+                cb.step("MULMASK", pl.frag(_kind("bwd", "bwd")), k8(pl.out), pl.inp, X1=HB[i], C1=Db[i - 1])
         pb0 = self.base[0]
-        cb.step("NONE", pb0.frag("bwd_hid:%d" % self.F), k8(pb0.out), self.F, C1=dCIN, act_write=0)
+        cb.step("NONE", pb0.frag(_kind("bwd_hid:%d" % self.F, "bwd")), k8(pb0.out), self.F, C1=dCIN, act_write=0)
         cb.launch()
         jobs = []
         for i, pl in enumerate(self.view):
