@@ -427,6 +427,15 @@ int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const float* d_ou
 int nudf_sums_errors_fwd(const float* sums, float n_rays, float* err, void* stream);
 int nudf_sums_errors_bwd(const float* sums, float n_rays, const float* d_err, float* d_sums, void* stream);
 
+/* ColorLoss in one launch when only the two L1 terms are active (loss/loss.py:105-133 with color_pixel = None,
+ * patch_colors = None):  den = mask ? sum(mask) + 1e-4 : n ;  Lb = sum|cb - gt| / den ;  Lc = sum|c - gt| / den ;
+ * out[3] = {(Lb w_b + Lc w_c) / (w_b + w_c + w_px), Lb, Lc}.
+ * bwd: d_cb / d_c from the upstream gradients d_out[3] (any of which may be zero). */
+int nudf_color_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
+                        float w_b, float w_c, float w_px, float* out, float* den_out, void* stream);
+int nudf_color_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, float w_b, float w_c,
+                        float w_px, const float* d_out, float* d_cb, float* d_c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,7 +174,7 @@ SYMBOLS = [
     "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
     "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
     "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
-    "nudf_sums_errors_fwd", "nudf_sums_errors_bwd",
+    "nudf_sums_errors_fwd", "nudf_sums_errors_bwd", "nudf_color_loss_fwd", "nudf_color_loss_bwd",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -217,6 +217,8 @@ _ARGTYPES = {
     "nudf_l1_sum_bwd": [_P, _P, _I, _P, _P, _P],
     "nudf_sums_errors_fwd": [_P, _F, _P, _P],
     "nudf_sums_errors_bwd": [_P, _F, _P, _P, _P],
+    "nudf_color_loss_fwd": [_P, _P, _P, _I, _P, _I, _F, _F, _F, _P, _P, _P],
+    "nudf_color_loss_bwd": [_P, _P, _P, _I, _P, _F, _F, _F, _P, _P, _P, _P],
 }
 
 _lib = None

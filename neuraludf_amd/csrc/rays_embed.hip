@@ -616,3 +616,62 @@ extern "C" int nudf_sums_errors_bwd(const float* sums, float n_rays, const float
   NUDF_CHECK_LAUNCH("nudf_sums_errors_bwd");
   return 0;
 }
+
+// ColorLoss (two L1 terms) in one workgroup: the inputs are [N,3] per-ray tensors
+__global__ __launch_bounds__(1024) void color_loss_fwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
+                                                              const float* __restrict__ gt, int n,
+                                                              const float* __restrict__ mask, int n_mask, float w_b,
+                                                              float w_c, float w_px, float* out, float* den_out) {
+  __shared__ float red[3][16];
+  float sb = 0.f, sc = 0.f, sm = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float g = gt[i];
+    sb += fabsf(cb[i] - g);
+    sc += fabsf(c[i] - g);
+  }
+  if (mask)
+    for (int i = threadIdx.x; i < n_mask; i += 1024) sm += mask[i];
+  sb = wave_sum(sb); sc = wave_sum(sc); sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sc; red[2][threadIdx.x >> 6] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tb = 0.f, tc = 0.f, tm = 0.f;
+    for (int w = 0; w < 16; ++w) { tb += red[0][w]; tc += red[1][w]; tm += red[2][w]; }
+    const float den = mask ? (tm + 1e-4f) : (float)n;
+    const float Lb = tb / den, Lc = tc / den;
+    out[0] = (Lb * w_b + Lc * w_c) / (w_b + w_c + w_px);
+    out[1] = Lb;
+    out[2] = Lc;
+    den_out[0] = den;
+  }
+}
+extern "C" int nudf_color_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
+                                   float w_b, float w_c, float w_px, float* out, float* den_out, void* stream) {
+  hipLaunchKernelGGL(color_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, w_b,
+                     w_c, w_px, out, den_out);
+  NUDF_CHECK_LAUNCH("nudf_color_loss_fwd");
+  return 0;
+}
+__global__ void color_loss_bwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
+                                      const float* __restrict__ gt, int n, const float* den, float w_b, float w_c,
+                                      float w_px, const float* d_out, float* __restrict__ d_cb, float* __restrict__ d_c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float W = w_b + w_c + w_px;
+  const float kb = (d_out[0] * w_b / W + d_out[1]) / den[0];
+  const float kc = (d_out[0] * w_c / W + d_out[2]) / den[0];
+  const float g = gt[i];
+  const float a = cb[i] - g, b = c[i] - g;
+  d_cb[i] = kb * ((a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f));
+  d_c[i] = kc * ((b > 0.f) ? 1.f : ((b < 0.f) ? -1.f : 0.f));
+}
+extern "C" int nudf_color_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, float w_b,
+                                   float w_c, float w_px, const float* d_out, float* d_cb, float* d_c, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(color_loss_bwd_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, cb, c, gt, n, den,
+                     w_b, w_c, w_px, d_out, d_cb, d_c);
+  NUDF_CHECK_LAUNCH("nudf_color_loss_bwd");
+  return 0;
+}

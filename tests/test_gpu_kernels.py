@@ -444,3 +444,22 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
             assert p.grad is not None, (net, nme)
             e_oracle32 = rel(g32, g64.float())
             assert rel(p.grad, g64.float()) < max(GTOL, 3.0 * e_oracle32), (net, nme, e_oracle32)
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_color_loss_two_term_kernel(dev, with_mask):
+    """ColorLoss with only the L1 terms active (one fused launch) against the oracle's loss/loss.py restatement."""
+    from neuraludf_amd.loss.loss import ColorLoss
+    g = torch.Generator().manual_seed(17)
+    n = 333
+    cb, c, gt = (torch.rand(n, 3, generator=g) for _ in range(3))
+    mask = (torch.rand(n, 1, generator=g) > 0.4).float() if with_mask else None
+    cbr, cr = cb.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    ref = O.color_loss(0.2, 1.0, 0.5, 0.0, 3, cbr, cr, gt, None, mask, None, None, None)
+    (ref["loss"] + 0.3 * ref["color_base_loss"] - 0.1 * ref["color_loss"]).backward()
+    cbd, cd = cb.to(dev).requires_grad_(True), c.to(dev).requires_grad_(True)
+    out = ColorLoss(0.2, 1.0, 0.5, 0.0)(cbd, cd, gt.to(dev), None, mask.to(dev) if with_mask else None, None, None, None)
+    for k in ("loss", "color_base_loss", "color_loss"):
+        assert abs(float(out[k].detach()) - float(ref[k].detach())) < 1e-6 * max(1.0, abs(float(ref[k].detach()))), k
+    (out["loss"] + 0.3 * out["color_base_loss"] - 0.1 * out["color_loss"]).backward()
+    assert rel(cbd.grad, cbr.grad) < 1e-5 and rel(cd.grad, cr.grad) < 1e-5
