@@ -436,6 +436,27 @@ int nudf_color_loss_fwd(const float* cb, const float* c, const float* gt, int n,
 int nudf_color_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, float w_b, float w_c,
                         float w_px, const float* d_out, float* d_cb, float* d_c, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * GPU-resident ray / patch batch generation: Dataset.gen_random_rays_patches_at (dataset/dataset.py:228-294) and
+ * Dataset.near_far_from_sphere (:329-335) in one call.  The pixel coordinates are drawn by the caller
+ * (torch.randint keeps the reference's RNG semantics).
+ * ---------------------------------------------------------------------------------- */
+typedef struct NudfRayBatch {
+  const float* image;              /* [H, W, 3] colours of the reference view (images[img_idx])                 */
+  const float* mask;               /* [H, W, 3]                                                                  */
+  const float* intrinsics_inv;     /* [4, 4] row-major                                                           */
+  const float* pose;               /* [4, 4] row-major camera-to-world                                           */
+  const int64_t* pixels_x; const int64_t* pixels_y;   /* [N]                                                     */
+  int32_t N, H, W, h_patch_size;
+  float* rays;                     /* [N, 10] = rays_o 3 | rays_v 3 | colour 3 | mask 1                          */
+  float* ndc_uv;                   /* [N, 2] or NULL                                                             */
+  float* xyz_cam;                  /* [N, 3] K^-1 (x, y, 1) or NULL                                              */
+  float* near; float* far;         /* [N] each, or both NULL                                                     */
+  float* patch_color;              /* [N, (2h+1)^2, 3] or NULL (crop_patch = False)                              */
+  uint8_t* patch_mask;             /* [N] or NULL                                                                */
+} NudfRayBatch;
+int nudf_gen_ray_batch(const NudfRayBatch* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

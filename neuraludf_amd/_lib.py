@@ -49,6 +49,13 @@ class GemmTNGroup(C.Structure):
                 ("prob", GemmTNProblem * TN_MAX_PROBLEMS)]
 
 
+class RayBatch(C.Structure):
+    _fields_ = [("image", c_fp), ("mask", c_fp), ("intrinsics_inv", c_fp), ("pose", c_fp), ("pixels_x", c_fp),
+                ("pixels_y", c_fp), ("N", i32), ("H", i32), ("W", i32), ("h_patch_size", i32), ("rays", c_fp),
+                ("ndc_uv", c_fp), ("xyz_cam", c_fp), ("near", c_fp), ("far", c_fp), ("patch_color", c_fp),
+                ("patch_mask", c_fp)]
+
+
 class Composite(C.Structure):
     _fields_ = [("rays_o", c_fp), ("rays_d", c_fp), ("z", c_fp), ("udf", c_fp), ("grad", c_fp),
                 ("color", c_fp), ("color_base", c_fp), ("bg_z", c_fp), ("bg_sigma", c_fp), ("bg_color", c_fp),
@@ -175,6 +182,7 @@ SYMBOLS = [
     "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
     "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
     "nudf_sums_errors_fwd", "nudf_sums_errors_bwd", "nudf_color_loss_fwd", "nudf_color_loss_bwd",
+    "nudf_gen_ray_batch",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -219,6 +227,7 @@ _ARGTYPES = {
     "nudf_sums_errors_bwd": [_P, _F, _P, _P, _P],
     "nudf_color_loss_fwd": [_P, _P, _P, _I, _P, _I, _F, _F, _F, _P, _P, _P],
     "nudf_color_loss_bwd": [_P, _P, _P, _I, _P, _F, _F, _F, _P, _P, _P, _P],
+    "nudf_gen_ray_batch": [C.POINTER(RayBatch), _P],
 }
 
 _lib = None

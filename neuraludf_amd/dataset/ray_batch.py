@@ -1,0 +1,128 @@
+"""GPU-resident training-batch generation: the per-iteration half of the reference's ``Dataset``
+(dataset/dataset.py), i.e. ``gen_random_rays_patches_at`` (:228-294), ``near_far_from_sphere`` (:329-335) and
+``get_ref_src_info`` (:141-149).  Image decoding / camera files (dataset.py:40-140, cv2 / glob) stay the caller's job:
+this class is constructed from the tensors that ``Dataset.__init__`` ends up with.
+
+MI355X-first difference: the reference keeps ``images`` / ``masks`` on the host and, every iteration, uploads the
+whole reference image for ``F.grid_sample`` (23 MB for a DTU view) plus the gathered colours; here the full image
+stack lives in HBM (49 DTU views = 1.1 GB of 288 GB) and one launch of ``nudf_gen_ray_batch`` writes the ray record,
+the ndc uv, the camera-space direction, near / far and the ground-truth patches.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+
+def build_patch_offset(h_patch_size: int, device=None) -> torch.Tensor:
+    """dataset.py:342-344: [1, (2h+1)^2, 2] integer (dx, dy) offsets, dx fastest."""
+    o = torch.arange(-h_patch_size, h_patch_size + 1, device=device)
+    dy, dx = torch.meshgrid(o, o, indexing="ij")
+    return torch.stack([dx, dy], dim=-1).view(1, -1, 2)
+
+
+class RayBatchSource:
+    """Holds ``images`` [n, H, W, 3], ``masks`` [n, H, W, 3], ``intrinsics_all`` [n, 4, 4], ``pose_all`` [n, 4, 4]
+    (same meaning as the reference attributes of those names, dataset.py:96-112) on the GPU."""
+
+    def __init__(self, images, masks, intrinsics_all, pose_all, device="cuda"):
+        dev = torch.device(device)
+        f = dict(device=dev, dtype=torch.float32)
+        self.device = dev
+        self.images = torch.as_tensor(images).to(**f).contiguous()
+        self.masks = None if masks is None else torch.as_tensor(masks).to(**f).contiguous()
+        self.intrinsics_all = torch.as_tensor(intrinsics_all).to(**f).contiguous()
+        self.intrinsics_all_inv = torch.inverse(self.intrinsics_all).contiguous()      # dataset.py:107
+        self.pose_all = torch.as_tensor(pose_all).to(**f).contiguous()
+        self.n_images, self.H, self.W = self.images.shape[0], self.images.shape[1], self.images.shape[2]
+        if self.masks is None:
+            self.masks = torch.ones_like(self.images)                                    # dataset.py:86-88
+        self._valid = {}
+
+    # -- pixel draws: torch's generator, same call order as dataset.py:235-252 -------------------------------------
+    def _valid_pixels(self, img_idx: int) -> torch.Tensor:
+        v = self._valid.get(img_idx)
+        if v is None:      # row-major list of pixels with mask > 0; the reference rebuilds it every call (:242-245)
+            v = torch.nonzero(self.masks[img_idx][:, :, 0] > 0)          # [num, 2] = (y, x)
+            self._valid[img_idx] = v
+        return v
+
+    def draw_pixels(self, img_idx: int, batch_size: int, importance_sample: bool = False, generator=None):
+        kw = dict(device=self.device, generator=generator)
+        if not importance_sample:
+            return (torch.randint(0, self.W, [batch_size], **kw), torch.randint(0, self.H, [batch_size], **kw))
+        x1 = torch.randint(0, self.W, [batch_size // 4], **kw)
+        y1 = torch.randint(0, self.H, [batch_size // 4], **kw)
+        valid = self._valid_pixels(img_idx)
+        sel = valid[torch.randint(0, valid.shape[0], [batch_size // 4 * 3], **kw)]
+        return torch.cat([x1, sel[:, 1]]), torch.cat([y1, sel[:, 0]])
+
+    # -- the batch -------------------------------------------------------------------------------------------------
+    def rays_at_pixels(self, img_idx: int, pixels_x, pixels_y, h_patch_size: int = 3, crop_patch: bool = False,
+                       with_near_far: bool = False):
+        if not (self.images.is_cuda):
+            raise RuntimeError("RayBatchSource needs a GPU (no CPU fallback)")
+        px = pixels_x.to(device=self.device, dtype=torch.int64).contiguous()
+        py = pixels_y.to(device=self.device, dtype=torch.int64).contiguous()
+        N = px.numel()
+        f = dict(device=self.device, dtype=torch.float32)
+        rays = torch.empty(N, 10, **f)
+        uv = torch.empty(N, 2, **f)
+        xyz = torch.empty(N, 3, **f)
+        near = far = None
+        if with_near_far:
+            near, far = torch.empty(N, 1, **f), torch.empty(N, 1, **f)
+        patch_color = patch_mask = None
+        if crop_patch:
+            npx = (2 * h_patch_size + 1) ** 2
+            patch_color = torch.empty(N, npx, 3, **f)
+            patch_mask = torch.empty(N, 1, device=self.device, dtype=torch.bool)
+        a = _lib.RayBatch()
+        a.image, a.mask = self.images[img_idx].data_ptr(), self.masks[img_idx].data_ptr()
+        a.intrinsics_inv, a.pose = self.intrinsics_all_inv[img_idx].data_ptr(), self.pose_all[img_idx].data_ptr()
+        a.pixels_x, a.pixels_y = px.data_ptr(), py.data_ptr()
+        a.N, a.H, a.W, a.h_patch_size = N, self.H, self.W, int(h_patch_size)
+        a.rays, a.ndc_uv, a.xyz_cam = rays.data_ptr(), uv.data_ptr(), xyz.data_ptr()
+        a.near = near.data_ptr() if with_near_far else None
+        a.far = far.data_ptr() if with_near_far else None
+        a.patch_color = patch_color.data_ptr() if crop_patch else None
+        a.patch_mask = patch_mask.data_ptr() if crop_patch else None
+        _lib.call("nudf_gen_ray_batch", a)
+        sample = {"rays": rays, "rays_ndc_uv": uv, "rays_norm_XYZ_cam": xyz, "rays_patch_color": patch_color,
+                  "rays_patch_mask": patch_mask}
+        if with_near_far:
+            sample["near"], sample["far"] = near, far
+        return sample
+
+    def gen_random_rays_patches_at(self, img_idx, batch_size, importance_sample=False, h_patch_size=3,
+                                   crop_patch=False, generator=None, with_near_far=False):
+        """Same arguments and sample dict as dataset.py:228-294 (+ optional near / far from the same launch)."""
+        px, py = self.draw_pixels(int(img_idx), batch_size, importance_sample, generator)
+        return self.rays_at_pixels(int(img_idx), px, py, h_patch_size, crop_patch, with_near_far)
+
+    def near_far_from_sphere(self, rays_o, rays_d):
+        """dataset.py:329-335 on already generated rays (the fused path is ``with_near_far=True``)."""
+        a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+        b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+        mid = 0.5 * (-b) / a
+        return mid - 1.0, mid + 1.0
+
+    def prepare_ref_src_pairs(self):
+        """dataset.py:129-139: for every view the 9 nearest other cameras (by camera-centre distance)."""
+        cam_loc = self.pose_all[:, :3, 3]
+        pair_dist = torch.cdist(cam_loc[None], cam_loc[None], p=2.0)
+        _, indices = torch.sort(pair_dist, descending=False, dim=2)
+        self.ref_src_pair = {i: indices[0, i][1:10] for i in range(self.n_images)}
+        return self.ref_src_pair
+
+    def get_ref_src_info(self, img_idx, num=8):
+        """dataset.py:141-149: (ref c2w, src c2ws, src intrinsics [n,4,4], src images [n,3,H,W], [W, H]);
+        everything is already resident, so the `.cuda()` uploads of the reference are index selects."""
+        if isinstance(img_idx, torch.Tensor):
+            img_idx = int(img_idx.item())
+        if not hasattr(self, "ref_src_pair"):
+            self.prepare_ref_src_pairs()
+        src_idx = self.ref_src_pair[img_idx][:num]
+        return (self.pose_all[img_idx], self.pose_all[src_idx], self.intrinsics_all[src_idx],
+                self.images[src_idx].permute(0, 3, 1, 2), [self.W, self.H])

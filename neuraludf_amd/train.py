@@ -102,3 +102,28 @@ class Trainer:
             self.bucket.all_reduce()
         self.optimizer.step()
         return loss.detach(), out
+
+    def iteration(self, source, iter_step, schedules, image_perm=None, batch_size=512, num_src=8):
+        """one pass of the reference training loop body (exp_runner_blending.py:262-375) with every per-iteration
+        input produced on the GPU: schedules -> ray / patch batch (one launch) -> render -> loss -> backward -> Adam.
+        ``source`` is a ``dataset.RayBatchSource``; -> (loss, render_out, sample)."""
+        schedules.apply_learning_rates(self.optimizer, iter_step)
+        a = schedules.at(iter_step)
+        self.color_loss.set_color_weights(a["color_base_weight"], a["color_weight"], a["color_pixel_weight"],
+                                          a["color_patch_weight"])
+        self.lc.update(color_pixel_weight=a["color_pixel_weight"], color_patch_weight=a["color_patch_weight"])
+        self.tc.update(igr_ns_weight=a["igr_ns_weight"], sparse_weight=a["sparse_weight"])
+        n = source.n_images
+        img_idx = int(image_perm[iter_step % len(image_perm)]) if image_perm is not None else iter_step % n
+        s = source.gen_random_rays_patches_at(img_idx, batch_size, crop_patch=a["color_patch_weight"] > 0.0,
+                                              h_patch_size=self.color_loss.h_patch_size, with_near_far=True)
+        data = s["rays"]
+        batch = dict(rays_o=data[:, :3], rays_d=data[:, 3:6], true_rgb=data[:, 6:9], mask=(data[:, 9:10] > 0.5).float(),
+                     near=s["near"], far=s["far"], rays_uv=s["rays_ndc_uv"], gt_patch_colors=s["rays_patch_color"])
+        blend = None
+        if a["color_pixel_weight"] > 0.0 or a["color_patch_weight"] > 0.0:
+            ref_c2w, src_c2ws, src_intr, src_images, _ = source.get_ref_src_info(img_idx, num_src)
+            blend = dict(color_maps=src_images, w2cs=torch.inverse(src_c2ws), intrinsics=src_intr, query_c2w=ref_c2w)
+        loss, out = self.step(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
+                              blend=blend)
+        return loss, out, s

@@ -1,0 +1,60 @@
+"""CPU: the batch-generation oracle (oracle/rays_oracle.py) against the reference's own output
+(tests/golden/ref_raybatch.npz, made by tests/golden/make_golden_rays.py from Dataset.gen_random_rays_patches_at)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rays_oracle as ro
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_raybatch.npz")
+CASES = ["plain", "importance", "nopatch"]
+
+
+def load_gold():
+    g = dict(np.load(GOLD))
+    g["images"] = g["images_u8"].astype(np.float32) / np.float32(256.0)
+    g["masks"] = np.repeat(g["masks_u8"].astype(np.float32) / np.float32(256.0), 3, axis=-1)
+    g["intrinsics_all_inv"] = np.linalg.inv(g["intrinsics_all"].astype(np.float64)).astype(np.float32)
+    return g
+
+
+def check_sample(g, name, s, near, far, atol=2e-6):
+    """integer / gather outputs bit-exact; float arithmetic within a few ulp of the reference's fp32."""
+    ref = lambda k: g[f"{name}.{k}"]  # noqa: E731
+    np.testing.assert_array_equal(s["rays"][:, 6:10], ref("rays")[:, 6:10])          # colour gather, mask
+    np.testing.assert_array_equal(s["rays"][:, 0:3], ref("rays")[:, 0:3])            # origin
+    np.testing.assert_allclose(s["rays"][:, 3:6], ref("rays")[:, 3:6], rtol=0, atol=atol)
+    np.testing.assert_allclose(s["rays_ndc_uv"], ref("rays_ndc_uv"), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(s["rays_norm_XYZ_cam"], ref("rays_norm_XYZ_cam"), rtol=0, atol=atol)
+    np.testing.assert_allclose(near, ref("near"), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(far, ref("far"), rtol=0, atol=1e-5)
+    if f"{name}.rays_patch_color" in g:
+        np.testing.assert_array_equal(np.asarray(s["rays_patch_mask"]).astype(bool), ref("rays_patch_mask"))
+        np.testing.assert_allclose(s["rays_patch_color"], ref("rays_patch_color"), rtol=0, atol=2e-5)
+    else:
+        assert s["rays_patch_color"] is None and s["rays_patch_mask"] is None
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference(name):
+    g = load_gold()
+    i = int(g[f"{name}.img_idx"])
+    crop = f"{name}.rays_patch_color" in g
+    s = ro.gen_rays_patches(g["images"][i], g["masks"][i], g["intrinsics_all_inv"][i], g["pose_all"][i],
+                            g[f"{name}.px"], g[f"{name}.py"], int(g[f"{name}.h"]), crop)
+    near, far = ro.near_far_from_sphere(s["rays"][:, :3], s["rays"][:, 3:6])
+    check_sample(g, name, s, near, far)
+
+
+def test_patch_offsets_and_border():
+    off = ro.build_patch_offset(1)[0]
+    assert off.tolist() == [[-1, -1], [0, -1], [1, -1], [-1, 0], [0, 0], [1, 0], [-1, 1], [0, 1], [1, 1]]
+    # a patch hanging over the image corner: out-of-image taps contribute zero (padding_mode='zeros')
+    img = np.ones((8, 10, 3), np.float32)
+    s = ro.gen_rays_patches(img, img, np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32),
+                            np.array([0, 9]), np.array([0, 7]), 2, True)
+    assert not s["rays_patch_mask"].any()
+    assert s["rays_patch_color"][0, 0].max() == 0.0 and s["rays_patch_color"][1, -1].max() == 0.0
+    # centre tap of the corner pixel: align_corners=False puts it at (-0.5, -0.5) -> one quarter of the 2x2 footprint
+    assert abs(s["rays_patch_color"][0, 12, 0] - 0.25) < 1e-6
