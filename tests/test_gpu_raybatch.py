@@ -55,7 +55,11 @@ def test_ref_src_pairs_match_reference():
     src = source(g)
     pairs = src.prepare_ref_src_pairs()
     got = np.stack([pairs[i].cpu().numpy() for i in range(src.n_images)])
-    np.testing.assert_array_equal(got, g["ref_src_pairs"])
+    # the ring scene has equidistant neighbours, so tied entries may come in either order: compare the distances
+    loc = g["pose_all"][:, :3, 3]
+    dist = np.linalg.norm(loc[:, None] - loc[None], axis=-1)
+    np.testing.assert_allclose(np.take_along_axis(dist, got, 1), np.take_along_axis(dist, g["ref_src_pairs"], 1), atol=1e-5)
+    assert all(i not in got[i] for i in range(src.n_images))
     ref_c2w, c2ws, intr, imgs, wh = src.get_ref_src_info(1, num=2)
     assert c2ws.shape == (2, 4, 4) and intr.shape == (2, 4, 4) and imgs.shape == (2, 3, src.H, src.W) and wh == [src.W, src.H]
     assert torch.equal(imgs[0].permute(1, 2, 0), src.images[pairs[1][0]])
@@ -112,7 +116,7 @@ def test_training_iterations_from_generated_batches():
         tr = Trainer(torch.device("cuda"), conf, color_loss_conf=dict(color_pixel_weight=0.1, color_patch_weight=0.1),
                      fused_adam=True, seed=0)
         sched = Schedules(is_finetune=ft, **base)
-        w0 = tr.color.state_dict()["lin0.weight_v"].clone()
+        w0 = tr.color.state_dict()["lin_base0.weight_v"].clone()
         for it in (600, 601):
             loss, out, s = tr.iteration(src, it, sched, batch_size=64)
             assert torch.isfinite(loss)
@@ -120,4 +124,4 @@ def test_training_iterations_from_generated_batches():
         assert (out["color_pixel"] is not None) == ft and (s["rays_patch_color"] is not None) == ft
         lrs = [g_["lr"] for g_ in tr.optimizer.param_groups]
         assert lrs[1] == pytest.approx(5e-4 * 601 / 5000) and lrs[0] == pytest.approx(1e-4 * 601 / 10000)
-        assert not torch.equal(w0, tr.color.state_dict()["lin0.weight_v"])
+        assert not torch.equal(w0, tr.color.state_dict()["lin_base0.weight_v"])
