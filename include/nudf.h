@@ -303,14 +303,16 @@ enum {
   NUDF_CH_SIGMOIDN = 7,  /* cols < iparam: sigmoid -> C1 (and tile); cols >= iparam raw -> C2[col-iparam];
                             N <= iparam: C2 mirrors the sigmoid columns instead                    */
   NUDF_CH_MULMASK = 8,   /* out = (X1 > 0) ? acc * scale : 0            (ReLU backward)           */
-  NUDF_CH_ADDMASK = 9    /* out = (X1 > 0) ? (acc + X2) * scale : 0     (ReLU backward at a join) */
+  NUDF_CH_ADDMASK = 9,   /* out = (X1 > 0) ? (acc + X2) * scale : 0     (ReLU backward at a join) */
+  NUDF_CH_RELUADD = 10   /* out = relu(acc + bias + X2)   (skip layer whose second input part was multiplied
+                            by an earlier step: NeRF's cat([input_pts, h]) is wider than the LDS tile)  */
 };
 enum {
   NUDF_CH_INIT_LOAD = 0,   /* activation tile = A0[rows, 0:k0]                                    */
   NUDF_CH_INIT_POSENC = 1, /* activation tile = PE(x) (or its JVP with tangent v), zero-padded to k0 */
   NUDF_CH_INIT_SEED = 2    /* tile[r,c] = seed_sign[r] * seed_wrow[c] * seed_scale * softplus'(A0[r,c]) */
 };
-#define NUDF_CH_MAX_STEPS 12
+#define NUDF_CH_MAX_STEPS 14
 typedef struct NudfChainStep {
   const float* Bp;                 /* packed weights (nudf_pack_frag) of the [K, N] operand          */
   const float* bias;               /* [N] or NULL                                                    */

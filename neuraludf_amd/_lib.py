@@ -119,8 +119,8 @@ class Adam(C.Structure):
                 ("block_start", i32 * (ADAM_MAX_TENSORS + 1)), ("pad2_", i32), ("group", AdamGroup * ADAM_MAX_GROUPS)]
 
 
-CH_MAX_STEPS = 12
-CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5, RELU=6, SIGMOIDN=7, MULMASK=8, ADDMASK=9)
+CH_MAX_STEPS = 14
+CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5, RELU=6, SIGMOIDN=7, MULMASK=8, ADDMASK=9, RELUADD=10)
 CH_INIT = dict(LOAD=0, POSENC=1, SEED=2)
 
 

@@ -265,7 +265,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
   }
-  if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD || EPI == NUDF_CH_ADDMASK) {
+  if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD || EPI == NUDF_CH_ADDMASK || EPI == NUDF_CH_RELUADD) {
     if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
 #pragma unroll
@@ -294,6 +294,8 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     } else if (EPI == NUDF_CH_RELU) {
       out[r] = fmaxf(v[r], 0.0f);
       out2[r] = out[r];                                       // optional mirror (hidden tap of the colour net)
+    } else if (EPI == NUDF_CH_RELUADD) {
+      out[r] = fmaxf(v[r] + x2[r], 0.0f);                     // skip layer: X2 = (other input part) x (its weight rows)
     } else if (EPI == NUDF_CH_SIGMOIDN) {
       // columns < iparam through a sigmoid (torch.sigmoid accuracy: libm exp), the rest raw
       out2[r] = v[r];
@@ -571,13 +573,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
         case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
         case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
         case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
         default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
       }
     }
     if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();
     if (st.pe_tail_col >= 0) {
       __syncthreads();
-      ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col, 0);
+      // zero up to the next multiple of 16 columns: the K padding of the step that consumes [.. | PE] must multiply
+      // finite zeros (columns never written before hold arbitrary LDS contents)
+      const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
+      ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col,
+                      min((pe_end + 15) & ~15, 288));
     }
     __syncthreads();
   }

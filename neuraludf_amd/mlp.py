@@ -297,6 +297,9 @@ class PackedLinear:
                 f = pack_frag(self.W, self.in_pad, self.out - 1, self.inp, off=self.in_pad)
             elif kind.startswith("bwd_hid:"):
                 f = pack_frag(self.W, self.in_pad, self.out, int(kind.split(":")[1]))
+            elif kind.startswith("fwd_in:"):
+                _, i0, K = kind.split(":")
+                f = pack_frag(self.Wt, self.out_pad, int(K), self.out, off=int(i0) * self.out_pad)
             else:
                 raise KeyError(kind)
             self._frags[kind] = f
@@ -376,6 +379,9 @@ def _frag_spec32(pl, kind):
         return (0, 1, 0, pl.out - 1, pl.inp)
     if kind.startswith("bwd_hid:"):
         return (0, 0, 0, pl.out, int(kind.split(":")[1]))
+    if kind.startswith("fwd_in:"):       # W^T restricted to the (packed-order) input columns [i0, i0 + K)
+        _, i0, K = kind.split(":")
+        return (1, 0, int(i0), int(K), pl.out)
     raise KeyError(kind)
 
 
@@ -1039,7 +1045,130 @@ class NerfEngine:
             out += pl.params()
         return out
 
+    # -- dispatch: fused LDS-resident chains (default) or per-layer GEMM launches -------------------
+    def _skip_layer(self):
+        """index of the pts layer whose input is cat([input_pts, h]) (fields.py:607-609), or -1."""
+        sk = [i + 1 for i in sorted(self.skips) if i + 1 < self.D]
+        return sk[0] if sk else -1
+
+    def _chain_ok(self):
+        net = self.net
+        sk = [i for i in self.skips if 0 <= i < self.D]
+        ok = USE_CHAIN and self.W <= 256 and self.W % 32 == 0 and self.D + 5 <= CH_MAX_STEPS and len(sk) <= 1
+        ok = ok and (not sk or sk[0] < self.D - 1) and k8(self.e) <= 288 and k8(self.W + self.ev) <= 288
+        ok = ok and net.d_in_view == 3 and self.ev == 3 * (2 * net.multires_view + 1) and self.views.out <= 256
+        return ok
+
+    def _kinds(self):
+        """fragment copies per layer in _all() order (pts, views, feature, alpha, rgb)."""
+        fw, bw = _kind("fwd", "fwd"), _kind("bwd", "bwd")
+        W, e, j = self.W, self.e, self._skip_layer()
+        kinds = []
+        for i in range(self.D):
+            if i == j:
+                kinds.append((_kind("fwd_in:0:%d" % W, "fwd"), _kind("fwd_in:%d:%d" % (W, e), "fwd"),
+                              _kind("bwd_hid:%d" % W, "bwd")))
+            else:
+                kinds.append((fw,) if i == 0 else (fw, bw))
+        kinds += [(fw, _kind("bwd_hid:%d" % W, "bwd")), (fw, bw), (fw,), (fw, bw)]
+        return kinds
+
     def forward(self, pts4, rays_d, S, P, keep_state=True):
+        if self._chain_ok():
+            return self._forward_chain(pts4, rays_d, S, P, keep_state)
+        return self._forward_layers(pts4, rays_d, S, P, keep_state)
+
+    def backward(self, st, d_sigma, d_rgb):
+        if "chain" in st:
+            return self._backward_chain(st, d_sigma, d_rgb)
+        return self._backward_layers(st, d_sigma, d_rgb)
+
+    def _forward_chain(self, pts4, rays_d, S, P, keep_state=True):
+        """the whole background network (fields.py:599-628) as one launch: PE(pts) tile -> 8 ReLU layers (the skip
+        layer's cat([input_pts, h]) is 340 wide, more than the 288-column LDS tile, so its PE part is multiplied by
+        an extra step while the tile still holds PE(pts) and joins through the RELUADD epilogue) -> density head,
+        feature layer + PE(dir) assembled in the tile -> view layer -> colour head."""
+        dev, D, W, e, ev = pts4.device, self.D, self.W, self.e, self.ev
+        net = self.net
+        fw = _kind("fwd", "fwd")
+        j = self._skip_layer()
+        pack_group(self._all(), self._kinds())
+        Hin = [_buf(P, self.pts[0].inp, dev)]
+        if keep_state:
+            Hin += [_buf(P, pl.inp, dev, zero=(i + 1 == j)) for i, pl in enumerate(self.pts[1:])]
+        d2 = Hin[j] if (j >= 0 and keep_state) else None
+        call("nudf_posenc", ptr(pts4), net.d_in, 1, None, net.d_in, net.multires, 1.0, P,
+             ptr(Hin[0]), Hin[0].shape[1], 1.0,
+             (ptr(d2) + 4 * W) if d2 is not None else None, d2.shape[1] if d2 is not None else 0, 1.0)
+        Pp = pad_rows(P)
+        h_last = _buf(P, W, dev, zero=False) if keep_state else None
+        VIN = _zero_cols(torch.empty(Pp, pad32(W + ev), device=dev), W + ev) if keep_state else None
+        hv = _buf(P, self.views.out, dev, zero=False) if keep_state else None
+        sigma = torch.empty(Pp, 1, device=dev)
+        rgb = torch.empty(Pp, 3, device=dev)
+        cb = ChainBuilder(P, "LOAD", k8(e))
+        cb.init_load(Hin[0], Hin[0].shape[1])
+        cb.posenc(rays_d, net.multires_view, 1.0, x_div=S)
+        SK = None
+        if j >= 0:
+            SK = _buf(P, W, dev, zero=False)
+            cb.step("NONE", self.pts[j].frag(_kind("fwd_in:%d:%d" % (W, e), "fwd")), k8(e), W, C1=SK, act_write=0)
+        for i in range(D):
+            pl = self.pts[i]
+            dst = None
+            if keep_state:
+                dst = Hin[i + 1] if i + 1 < D else h_last
+            if i == j:
+                cb.step("RELUADD", pl.frag(_kind("fwd_in:0:%d" % W, "fwd")), k8(W), W, bias=pl.bias, X2=SK, C1=dst)
+            else:
+                cb.step("RELU", pl.frag(fw), k8(pl.inp), pl.out, bias=pl.bias, C1=dst)
+        cb.step("NONE", self.alpha.frag(fw), k8(W), 1, bias=self.alpha.bias, C1=sigma, act_write=0)
+        cb.step("NONE", self.feature.frag(fw), k8(W), W, bias=self.feature.bias, C1=VIN, pe_tail_col=W, pe_tail_scale=1.0,
+                pe_dst=VIN)
+        cb.step("RELU", self.views.frag(fw), k8(W + ev), self.views.out, bias=self.views.bias, C1=hv)
+        cb.step("NONE", self.rgb.frag(fw), k8(self.views.out), 3, bias=self.rgb.bias, C1=rgb, act_write=0)
+        cb.launch()
+        st = dict(Hin=Hin, h_last=h_last, VIN=VIN, hv=hv, P=P, chain=True) if keep_state else None
+        return sigma[:P], rgb[:P], st
+
+    def _backward_chain(self, st, d_sigma, d_rgb):
+        """one reverse sweep (colour head -> view layer -> feature layer joined with the density head's rank-1 adjoint
+        -> pts layers 7..1) and one grouped GEMM for all 12 weight gradients."""
+        P, D, W = st["P"], self.D, self.W
+        Hin, h_last, VIN, hv = st["Hin"], st["h_last"], st["VIN"], st["hv"]
+        dev = VIN.device
+        bw = _kind("bwd", "bwd")
+        j = self._skip_layer()
+        layers = self._all()
+        grads = alloc_grads(layers)
+        Pp = pad_rows(P)
+        Drgb = torch.zeros(Pp, 32, device=dev)
+        call("nudf_copy_cols", ptr(d_rgb), 3, 1, ptr(Drgb), 32, 3, P, 1.0)
+        Dsig = torch.zeros(Pp, 32, device=dev)
+        call("nudf_copy_cols", ptr(d_sigma), 1, 1, ptr(Dsig), 32, 1, P, 1.0)
+        Dv = _buf(P, self.views.out, dev, zero=False)
+        dF = _buf(P, W, dev, zero=False)
+        Dp = [_buf(P, W, dev, zero=False) for _ in range(D)]
+        cb = ChainBuilder(P, "LOAD", k8(3))
+        cb.init_load(Drgb, Drgb.shape[1])
+        cb.step("MULMASK", self.rgb.frag(bw), k8(3), self.views.out, X1=hv, C1=Dv)
+        cb.step("NONE", self.views.frag(_kind("bwd_hid:%d" % W, "bwd")), k8(self.views.out), W, C1=dF)
+        cb.step("MULMASK", self.feature.frag(bw), k8(W), W, X1=h_last, r1_row=Dsig, ldr1=Dsig.shape[1],
+                r1_col=self.alpha.W, C1=Dp[D - 1])
+        for i in range(D - 1, 0, -1):
+            pl = self.pts[i]
+            kind = _kind("bwd_hid:%d" % W, "bwd") if i == j else bw
+            cb.step("MULMASK", pl.frag(kind), k8(pl.out), W, X1=Hin[i], C1=Dp[i - 1], act_write=1 if i > 1 else 0)
+        cb.launch()
+        jobs = [(Dp[i], pl.out, Hin[i], pl.in_pad, grads[i][0], grads[i][1]) for i, pl in enumerate(self.pts)]
+        jobs.append((Dv, self.views.out, VIN, self.views.in_pad, grads[D][0], grads[D][1]))
+        jobs.append((dF, self.feature.out, h_last, self.feature.in_pad, grads[D + 1][0], grads[D + 1][1]))
+        jobs.append((Dsig, 1, h_last, self.alpha.in_pad, grads[D + 2][0], grads[D + 2][1]))
+        jobs.append((Drgb, 3, hv, self.rgb.in_pad, grads[D + 3][0], grads[D + 3][1]))
+        gemm_tn_grouped(jobs, P)
+        return unpack_group(layers, grads)
+
+    def _forward_layers(self, pts4, rays_d, S, P, keep_state=True):
         dev = pts4.device
         pack_group(self._all())
         Hin = [_buf(P, pl.inp, dev) for pl in self.pts]
@@ -1072,7 +1201,7 @@ class NerfEngine:
         st = dict(Hin=Hin, outs=outs, VIN=VIN, hv=hv, P=P) if keep_state else None
         return sigma, rgb, st
 
-    def backward(self, st, d_sigma, d_rgb):
+    def _backward_layers(self, st, d_sigma, d_rgb):
         P = st["P"]
         Hin, outs, VIN, hv = st["Hin"], st["outs"], st["VIN"], st["hv"]
         dev = VIN.device

@@ -171,39 +171,39 @@ class _ErrorsFn(torch.autograd.Function):
         return d, None
 
 
+GRID_CHUNK_POINTS = 1 << 21      # points per field query: large launches (>= 32768 row tiles) instead of 64^3 blocks
+
+
+def _grid_query(bound_min, bound_max, resolution, query_func, device, channels):
+    """Dense-grid evaluation of a field, GPU-resident.  Same grid as the reference (per-axis
+    ``linspace(bound_min, bound_max, resolution)``, x-major ordering) but the points are generated on the device in
+    slabs of whole x-planes (up to GRID_CHUNK_POINTS each) and the values land in one device volume that is copied to
+    the host once; the reference walks 64^3 blocks with a host meshgrid, an upload and a download per block
+    (models/udf_renderer_blending.py:16-49)."""
+    dev = torch.device(device)
+    R = int(resolution)
+    axes = [torch.linspace(float(bound_min[k]), float(bound_max[k]), R, device=dev) for k in range(3)]
+    shape = (R, R, R) if channels == 1 else (R, R, R, channels)
+    vol = torch.empty(shape, dtype=torch.float32, device=dev)
+    planes = max(1, (GRID_CHUNK_POINTS // (1 if channels == 1 else 4)) // (R * R))   # gradient queries keep activations
+    yz = torch.stack([axes[1][:, None].expand(R, R), axes[2][None, :].expand(R, R)], -1).reshape(1, R * R, 2)
+    for x0 in range(0, R, planes):
+        xs = axes[0][x0:x0 + planes]
+        pts = torch.cat([xs[:, None, None].expand(len(xs), R * R, 1), yz.expand(len(xs), R * R, 2)], -1).reshape(-1, 3)
+        val = query_func(pts).detach()
+        vol[x0:x0 + len(xs)] = val.reshape((len(xs),) + shape[1:])
+    return vol.cpu().numpy()
+
+
 def extract_fields(bound_min, bound_max, resolution, query_func, device='cuda'):
-    """Dense-grid field query (models/udf_renderer_blending.py:16-31): chunks of 64^3 points."""
-    n = 64
-    X = torch.linspace(bound_min[0], bound_max[0], resolution).split(n)
-    Y = torch.linspace(bound_min[1], bound_max[1], resolution).split(n)
-    Z = torch.linspace(bound_min[2], bound_max[2], resolution).split(n)
-    u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+    """[R, R, R] float32 numpy volume of ``query_func(pts [P, 3]) -> [P]`` (reference signature, :16)."""
     with torch.no_grad():
-        for xi, xs in enumerate(X):
-            for yi, ys in enumerate(Y):
-                for zi, zs in enumerate(Z):
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(device)
-                    val = query_func(pts).reshape(len(xs), len(ys), len(zs)).detach().cpu().numpy()
-                    u[xi * n: xi * n + len(xs), yi * n: yi * n + len(ys), zi * n: zi * n + len(zs)] = val
-    return u
+        return _grid_query(bound_min, bound_max, resolution, query_func, device, 1)
 
 
 def extract_gradient_fields(bound_min, bound_max, resolution, query_func, device='cuda'):
-    """(:33-49) same chunking, [R,R,R,3] output."""
-    n = 64
-    X = torch.linspace(bound_min[0], bound_max[0], resolution).split(n)
-    Y = torch.linspace(bound_min[1], bound_max[1], resolution).split(n)
-    Z = torch.linspace(bound_min[2], bound_max[2], resolution).split(n)
-    u = np.zeros([resolution, resolution, resolution, 3], dtype=np.float32)
-    for xi, xs in enumerate(X):
-        for yi, ys in enumerate(Y):
-            for zi, zs in enumerate(Z):
-                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1).to(device)
-                val = query_func(pts).reshape(len(xs), len(ys), len(zs), 3).detach().cpu().numpy()
-                u[xi * n: xi * n + len(xs), yi * n: yi * n + len(ys), zi * n: zi * n + len(zs)] = val
-    return u
+    """[R, R, R, 3] volume of a vector field, e.g. ``lambda p: udf_network.gradient(p).squeeze()`` (:33)."""
+    return _grid_query(bound_min, bound_max, resolution, query_func, device, 3)
 
 
 class UDFRendererBlending:

@@ -169,6 +169,39 @@ def test_udf_other_paths_match_the_default(dev, nets, mode):
         assert rel(a, b) < 2e-5
 
 
+@pytest.mark.parametrize("mode", ["chain64", "layers"])
+def test_nerf_paths_agree(dev, nets, mode):
+    """the fused background-NeRF chain (32-point tiles) against its 64-point-tile variant and the per-layer GEMM
+    path: values and all 24 parameter gradients, per-ray view directions (x_div = samples per ray)."""
+    from neuraludf_amd import mlp
+    mods, _ = nets
+    net = mods["nerf"]
+    g = torch.Generator().manual_seed(9)
+    S, R = 6, 83
+    P = S * R
+    p3 = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    pts4 = torch.cat([p3, torch.rand(P, 1, generator=g)], -1).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    w1, w2 = torch.randn(P, 1, generator=g).to(dev), torch.randn(P, 3, generator=g).to(dev)
+
+    def run():
+        net.zero_grad()
+        s, rgb = net.evaluate(pts4, dirs, S)
+        ((s * w1).sum() + (rgb * w2).sum()).backward()
+        return [s.detach(), rgb.detach()] + [p.grad.clone() for p in net.parameters()]
+    ref = run()
+    try:
+        if mode == "chain64":
+            mlp.CHAIN_TILE = 64
+        else:
+            mlp.USE_CHAIN = False
+        got = run()
+    finally:
+        mlp.CHAIN_TILE, mlp.USE_CHAIN = 0, True
+    for a, b in zip(got, ref):
+        assert rel(a, b) < 2e-5
+
+
 def test_color_network(dev, nets):
     mods, sds = nets
     g = torch.Generator().manual_seed(4)
