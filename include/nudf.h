@@ -437,6 +437,13 @@ int nudf_color_loss_fwd(const float* cb, const float* c, const float* gt, int n,
                         float w_b, float w_c, float w_px, float* out, float* den_out, void* stream);
 int nudf_color_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, float w_b, float w_c,
                         float w_px, const float* d_out, float* d_cb, float* d_c, void* stream);
+/* the same loss split at the ray-sharding exchange step (one process per GPU): local sums[3] = {sum|cb - gt|,
+ * sum|c - gt|, sum(mask) or n} -> the caller all-reduces them (RCCL) -> finish forms out[3] / den exactly as above;
+ * nudf_color_loss_bwd then runs on the local rays with the GLOBAL den. */
+int nudf_color_loss_sums(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
+                         float* sums, void* stream);
+int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px, float* out, float* den_out,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * GPU-resident ray / patch batch generation: Dataset.gen_random_rays_patches_at (dataset/dataset.py:228-294) and

@@ -654,6 +654,53 @@ extern "C" int nudf_color_loss_fwd(const float* cb, const float* c, const float*
   NUDF_CHECK_LAUNCH("nudf_color_loss_fwd");
   return 0;
 }
+// ray-sharded variant: local sums -> (caller all-reduces the 3 floats) -> finish.  sums = [sum|cb-gt|, sum|c-gt|, D]
+// with D = sum(mask) or the element count; the same arithmetic as color_loss_fwd_kernel split at the exchange step.
+__global__ __launch_bounds__(1024) void color_loss_sums_kernel(const float* __restrict__ cb, const float* __restrict__ c,
+                                                               const float* __restrict__ gt, int n,
+                                                               const float* __restrict__ mask, int n_mask, float* sums) {
+  __shared__ float red[3][16];
+  float sb = 0.f, sc = 0.f, sm = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float g = gt[i];
+    sb += fabsf(cb[i] - g);
+    sc += fabsf(c[i] - g);
+  }
+  if (mask)
+    for (int i = threadIdx.x; i < n_mask; i += 1024) sm += mask[i];
+  sb = wave_sum(sb); sc = wave_sum(sc); sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sc; red[2][threadIdx.x >> 6] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tb = 0.f, tc = 0.f, tm = 0.f;
+    for (int w = 0; w < 16; ++w) { tb += red[0][w]; tc += red[1][w]; tm += red[2][w]; }
+    sums[0] = tb; sums[1] = tc; sums[2] = mask ? tm : (float)n;
+  }
+}
+extern "C" int nudf_color_loss_sums(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
+                                    float* sums, void* stream) {
+  hipLaunchKernelGGL(color_loss_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, sums);
+  NUDF_CHECK_LAUNCH("nudf_color_loss_sums");
+  return 0;
+}
+__global__ void color_loss_finish_kernel(const float* __restrict__ sums, int has_mask, float w_b, float w_c, float w_px,
+                                         float* out, float* den_out) {
+  const float den = has_mask ? (sums[2] + 1e-4f) : sums[2];
+  const float Lb = sums[0] / den, Lc = sums[1] / den;
+  out[0] = (Lb * w_b + Lc * w_c) / (w_b + w_c + w_px);
+  out[1] = Lb;
+  out[2] = Lc;
+  den_out[0] = den;
+}
+extern "C" int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px, float* out,
+                                      float* den_out, void* stream) {
+  hipLaunchKernelGGL(color_loss_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, has_mask, w_b, w_c, w_px,
+                     out, den_out);
+  NUDF_CHECK_LAUNCH("nudf_color_loss_finish");
+  return 0;
+}
 __global__ void color_loss_bwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
                                       const float* __restrict__ gt, int n, const float* den, float w_b, float w_c,
                                       float w_px, const float* d_out, float* __restrict__ d_cb, float* __restrict__ d_c) {

@@ -37,15 +37,26 @@ class _ColorLossFn(torch.autograd.Function):
     weighting in one launch each way (the generic path costs ~12 + ~15 one-element launches)."""
 
     @staticmethod
-    def forward(ctx, cb, c, gt, mask, w_b, w_c, w_px):
+    def forward(ctx, cb, c, gt, mask, w_b, w_c, w_px, data_parallel=False):
         from .._lib import call, ptr
         ctx.set_materialize_grads(False)
         cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
         m_ = mask.detach().float().contiguous() if mask is not None else None
         out = torch.empty(3, device=cb_.device)
         den = torch.empty(1, device=cb_.device)
-        call("nudf_color_loss_fwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_), m_.numel() if m_ is not None else 0,
-             float(w_b), float(w_c), float(w_px), ptr(out), ptr(den))
+        if data_parallel and nudf_dist.world_size() > 1:
+            # ray-sharded: local sums -> ONE all-reduce of 3 floats -> the same final arithmetic on every rank; the
+            # backward below then differentiates the global loss w.r.t. the local rays (global denominator)
+            import torch.distributed as dist
+            sums = torch.empty(3, device=cb_.device)
+            call("nudf_color_loss_sums", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_),
+                 m_.numel() if m_ is not None else 0, ptr(sums))
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            call("nudf_color_loss_finish", ptr(sums), 1 if m_ is not None else 0, float(w_b), float(w_c), float(w_px),
+                 ptr(out), ptr(den))
+        else:
+            call("nudf_color_loss_fwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_),
+                 m_.numel() if m_ is not None else 0, float(w_b), float(w_c), float(w_px), ptr(out), ptr(den))
         ctx.save_for_backward(cb_, c_, gt_, den)
         ctx.w = (float(w_b), float(w_c), float(w_px))
         return out[0], out[1], out[2]
@@ -55,13 +66,13 @@ class _ColorLossFn(torch.autograd.Function):
         from .._lib import call, ptr
         cb_, c_, gt_, den = ctx.saved_tensors
         if d0 is None and d1 is None and d2 is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         z = den.new_zeros(())
         d_out = torch.stack([d if d is not None else z for d in (d0, d1, d2)])
         d_cb, d_c = torch.empty_like(cb_), torch.empty_like(c_)
         call("nudf_color_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), *ctx.w, ptr(d_out), ptr(d_cb),
              ptr(d_c))
-        return d_cb, d_c, None, None, None, None, None
+        return d_cb, d_c, None, None, None, None, None, None
 
 
 def _l1_sum(pred, gt):
@@ -156,10 +167,11 @@ class ColorLoss(nn.Module):
 
     def forward(self, color_base, color, gt_color, color_pixel, pixel_mask, patch_colors, gt_patch_colors, patch_mask):
         if (color_base is not None and color is not None and color_pixel is None and patch_colors is None
-                and not self.pixel_func.data_parallel and color.is_cuda and color.dtype == torch.float32
+                and color.is_cuda and color.dtype == torch.float32
                 and color.shape == gt_color.shape == color_base.shape):
             total, lb, lc = _ColorLossFn.apply(color_base, color, gt_color, pixel_mask, self.color_base_weight,
-                                               self.color_weight, self.color_pixel_weight)
+                                               self.color_weight, self.color_pixel_weight,
+                                               self.pixel_func.data_parallel)
             return {'loss': total, 'color_base_loss': lb, 'color_loss': lc, 'color_pixel_loss': 0.0,
                     'color_patch_loss': 0.0}
         color_base_loss = color_loss = color_pixel_loss = color_patch_loss = 0.0

@@ -496,3 +496,38 @@ def test_color_loss_two_term_kernel(dev, with_mask):
         assert abs(float(out[k].detach()) - float(ref[k].detach())) < 1e-6 * max(1.0, abs(float(ref[k].detach()))), k
     (out["loss"] + 0.3 * out["color_base_loss"] - 0.1 * out["color_loss"]).backward()
     assert rel(cbd.grad, cbr.grad) < 1e-5 and rel(cd.grad, cr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_color_loss_sharded_split_matches_fused(dev, with_mask):
+    """the ray-sharded form (local sums -> all-reduce -> finish) of the fused ColorLoss: one shard reproduces the fused
+    launch bit for bit, two shards summed (what the all-reduce does) agree to fp32 rounding."""
+    from neuraludf_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(23)
+    n = 512
+    cb, c, gt = (torch.rand(n, 3, generator=g).to(dev) for _ in range(3))
+    mask = (torch.rand(n, 1, generator=g) > 0.4).float().to(dev) if with_mask else None
+    w = (0.2, 1.0, 0.5)
+
+    def fused():
+        out, den = torch.empty(3, device=dev), torch.empty(1, device=dev)
+        call("nudf_color_loss_fwd", ptr(cb), ptr(c), ptr(gt), cb.numel(), ptr(mask), mask.numel() if with_mask else 0, *w,
+             ptr(out), ptr(den))
+        return out, den
+
+    def sums_of(lo, hi):
+        s = torch.empty(3, device=dev)
+        m = mask[lo:hi].contiguous() if with_mask else None
+        call("nudf_color_loss_sums", ptr(cb[lo:hi].contiguous()), ptr(c[lo:hi].contiguous()), ptr(gt[lo:hi].contiguous()),
+             (hi - lo) * 3, ptr(m), (hi - lo) if with_mask else 0, ptr(s))
+        return s
+
+    def finish(s):
+        out, den = torch.empty(3, device=dev), torch.empty(1, device=dev)
+        call("nudf_color_loss_finish", ptr(s), 1 if with_mask else 0, *w, ptr(out), ptr(den))
+        return out, den
+    o0, d0 = fused()
+    o1, d1 = finish(sums_of(0, n))
+    assert torch.equal(o0, o1) and torch.equal(d0, d1)
+    o2, d2 = finish(sums_of(0, n // 2) + sums_of(n // 2, n))
+    assert rel(o2, o0) < 1e-6 and rel(d2, d0) < 1e-6
