@@ -131,12 +131,19 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible: bench.py measures the HIP path only"}))
         sys.exit(1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  NUDF_DIST_BACKEND=gloo lets the 2-rank flow be exercised on a ONE-GPU box (both ranks on
+    # cuda:0, collectives staged through the host) -- tests only; the measured configuration is nccl (= RCCL).
+    backend = os.environ.get("NUDF_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from neuraludf_amd import mlp, synth
     from neuraludf_amd import dist as nd
@@ -195,12 +202,15 @@ def main():
                    "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam"},
     }
 
-    if rank == 0 and not args.no_roofline:
-        # ---- one instrumented step: HIP events around every GEMM launch on the launch stream ----
-        mlp.PROFILE = []
+    if not args.no_roofline:
+        # ---- one instrumented step: HIP events around every GEMM launch on the launch stream.  EVERY rank takes
+        # the step (it contains the data-parallel collectives); only rank 0 records and reports. ----
+        mlp.PROFILE = [] if rank == 0 else None
         tr.step(batch)
         torch.cuda.synchronize()
+        barrier()
         prof, mlp.PROFILE = mlp.PROFILE, None
+    if rank == 0 and not args.no_roofline:
         agg = {}
         for name, flops, s, e in prof:
             a = agg.setdefault(name, [0, 0.0, 0.0])

@@ -1054,7 +1054,8 @@ class NerfEngine:
     def _chain_ok(self):
         net = self.net
         sk = [i for i in self.skips if 0 <= i < self.D]
-        ok = USE_CHAIN and self.W <= 256 and self.W % 32 == 0 and self.D + 5 <= CH_MAX_STEPS and len(sk) <= 1
+        ok = USE_CHAIN and os.environ.get("NUDF_NERF_CHAIN", "1") != "0"      # A/B switch for profiling
+        ok = ok and self.W <= 256 and self.W % 32 == 0 and self.D + 5 <= CH_MAX_STEPS and len(sk) <= 1
         ok = ok and (not sk or sk[0] < self.D - 1) and k8(self.e) <= 288 and k8(self.W + self.ev) <= 288
         ok = ok and net.d_in_view == 3 and self.ev == 3 * (2 * net.multires_view + 1) and self.views.out <= 256
         return ok
