@@ -43,7 +43,12 @@ WORKLOADS = {
                            "dtu"),
     "dtu_shipped_512x114+32": (512, dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5,
                                          perturb=1.0), "dtu"),
+    # BASELINE config 3: garment scene, mix schedule, pixel + patch blending over 8 source views (7x7 patches)
+    "garment_blend_1024x128": (1024, dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0,
+                                          upsampling_type="mix", use_norm_grad_for_cosine=True, h_patch_size=3),
+                               "garment"),
 }
+BLEND_WORKLOADS = {"garment_blend_1024x128": dict(color_pixel_weight=0.5, color_patch_weight=0.1)}
 
 
 def cpu_baseline(workload, seconds_budget=25.0):
@@ -158,11 +163,17 @@ def main():
         import neuraludf_amd.optim  # noqa: F401
     except Exception:
         fused = False
-    tr = Trainer(dev, rconf, seed=0, data_parallel=(world > 1), fused_adam=fused)
+    lconf = BLEND_WORKLOADS.get(args.workload)
+    tr = Trainer(dev, rconf, color_loss_conf=lconf, seed=0, data_parallel=(world > 1), fused_adam=fused)
     tr.renderer.diagnostics = False
     scene = synth.make_scene(scene_kind)
-    rays = synth.make_rays(scene, 0, rays_per_gpu * world, seed=1234)
+    rays = synth.make_rays(scene, 0, rays_per_gpu * world, seed=1234, margin=8 if lconf else 0)
     batch = {k: nd.shard(v, rank, world).contiguous().to(dev) for k, v in rays.items()}
+    step_kw = {}
+    if lconf:      # source views resident in HBM, ground-truth patches as the batch generator would crop them
+        step_kw["blend"] = {k: v.to(dev) for k, v in synth.make_source_views(scene, 0, 8, hwc=True).items()}
+        npx = (2 * rconf["h_patch_size"] + 1) ** 2
+        batch["gt_patch_colors"] = torch.rand(batch["rays_o"].shape[0], npx, 3, device=dev)
     s_core = rconf["n_samples"] + rconf["n_importance"]
 
     def barrier():
@@ -171,13 +182,13 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        tr.step(batch)
+        tr.step(batch, **step_kw)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.step(batch)
+        tr.step(batch, **step_kw)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -206,7 +217,7 @@ def main():
         # ---- one instrumented step: HIP events around every GEMM launch on the launch stream.  EVERY rank takes
         # the step (it contains the data-parallel collectives); only rank 0 records and reports. ----
         mlp.PROFILE = [] if rank == 0 else None
-        tr.step(batch)
+        tr.step(batch, **step_kw)
         torch.cuda.synchronize()
         barrier()
         prof, mlp.PROFILE = mlp.PROFILE, None

@@ -180,9 +180,12 @@ typedef struct NudfPixelBlend {   /* patch_projector.py:21-43, projector_utils.p
   const float* pts;               /* [P,3] sample points                                    */
   const float* logits; int32_t nl;/* [P,nl] blending logits (first V columns used)          */
   const float* proj;              /* [V,12] row-major 3x4 = K_v[:3,:3] @ w2c_v[:3,:]        */
-  const float* imgs;              /* [V,3,H,W] source images                                */
+  const float* imgs;              /* [V,3,H,W] source images (img_layout 0) or [V,H,W,3] (img_layout 1) */
   int32_t P, V, H, W;
   float* pix;                     /* [P,3] blended pixel colour per sample                  */
+  int32_t img_layout;             /* 1: channel-interleaved texels = the memory behind the reference's
+                                     images[src_idx].permute(0,3,1,2) view (dataset.py:147-149); one 12-byte load
+                                     per texel instead of three plane loads                              */
 } NudfPixelBlend;
 int nudf_pixel_blend_fwd(const NudfPixelBlend* a, void* stream);
 int nudf_pixel_blend_bwd(const NudfPixelBlend* a, const float* d_pix, float* d_logits, void* stream);
@@ -209,10 +212,11 @@ typedef struct NudfPatchBlend {   /* patch_projector.py:45-164, fields.py:521-53
   const float* w; int32_t ldw;    /* [N,ldw] compositing weights (first S used)             */
   const float* ref_cam;           /* [24] K_ref^-1 | R_ref | t_ref | cam centre             */
   const float* src_cam;           /* [V,24] K_src | R_rel | t_rel | -R_rel^T t_rel          */
-  const float* imgs;              /* [V,3,H,W]                                              */
+  const float* imgs;              /* [V,3,H,W] (img_layout 0) or [V,H,W,3] (img_layout 1)     */
   int32_t N, S, V, H, W, hps;
   float* patch_colors;            /* [N,(2h+1)^2,3]                                         */
   float* patch_mask;              /* [N] = sum_s w_s [any view sees the whole patch]        */
+  int32_t img_layout;             /* as in NudfPixelBlend                                   */
 } NudfPatchBlend;
 int nudf_patch_blend_fwd(const NudfPatchBlend* a, void* stream);
 int nudf_patch_blend_bwd(const NudfPatchBlend* a, const float* d_patch, float* d_logits, float* d_w, void* stream);

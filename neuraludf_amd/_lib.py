@@ -87,7 +87,7 @@ class Upsample(C.Structure):
 
 class PixelBlend(C.Structure):
     _fields_ = [("pts", c_fp), ("logits", c_fp), ("nl", i32), ("proj", c_fp), ("imgs", c_fp),
-                ("P", i32), ("V", i32), ("H", i32), ("W", i32), ("pix", c_fp)]
+                ("P", i32), ("V", i32), ("H", i32), ("W", i32), ("pix", c_fp), ("img_layout", i32)]
 
 
 class PixelComposite(C.Structure):
@@ -99,7 +99,7 @@ class PatchBlend(C.Structure):
     _fields_ = [("pts", c_fp), ("grad", c_fp), ("rays_d", c_fp), ("uv", c_fp), ("logits", c_fp), ("nl", i32),
                 ("w", c_fp), ("ldw", i32), ("ref_cam", c_fp), ("src_cam", c_fp), ("imgs", c_fp),
                 ("N", i32), ("S", i32), ("V", i32), ("H", i32), ("W", i32), ("hps", i32),
-                ("patch_colors", c_fp), ("patch_mask", c_fp)]
+                ("patch_colors", c_fp), ("patch_mask", c_fp), ("img_layout", i32)]
 
 
 ADAM_MAX_TENSORS = 64

@@ -21,24 +21,49 @@
 // fully unrolled loop over the views so that per-view arrays stay in registers
 #define FORV(v) _Pragma("unroll") for (int v = 0; v < MAXV; ++v) if (v < V)
 
+struct __attribute__((packed, aligned(4))) Texel3 { float r, g, b; };
+
+// F.grid_sample(bilinear, padding_mode='zeros', align_corners=True) on pixel coordinates.  HWC = channel-interleaved
+// image (one 12-byte load per texel); otherwise three planes.  Loads are clamped and unconditional, the validity of
+// each tap goes into its weight (no divergent load groups); same products and summation order in both layouts.
+template <bool HWC>
 __device__ __forceinline__ void bilinear3(const float* __restrict__ img, int H, int W, float ix, float iy, float out[3]) {
-  // F.grid_sample(bilinear, padding_mode='zeros', align_corners=True) on pixel coordinates
   const float x0f = floorf(ix), y0f = floorf(iy);
   const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
   const float wx1 = ix - x0f, wx0 = (x0f + 1.0f) - ix;
   const float wy1 = iy - y0f, wy0 = (y0f + 1.0f) - iy;
   const bool vx0 = (x0 >= 0) && (x0 <= W - 1), vx1 = (x1 >= 0) && (x1 <= W - 1);
   const bool vy0 = (y0 >= 0) && (y0 <= H - 1), vy1 = (y1 >= 0) && (y1 <= H - 1);
-  const size_t plane = (size_t)H * W;
+  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+  const bool v00 = vx0 && vy0, v10 = vx1 && vy0, v01 = vx0 && vy1, v11 = vx1 && vy1;
+  const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+  const unsigned o00 = (unsigned)cy0 * W + cx0, o10 = (unsigned)cy0 * W + cx1;
+  const unsigned o01 = (unsigned)cy1 * W + cx0, o11 = (unsigned)cy1 * W + cx1;
+  float t[4][3];
+  if (HWC) {
+    const Texel3* q = reinterpret_cast<const Texel3*>(img);
+    const Texel3 a = q[o00], b = q[o10], c = q[o01], d = q[o11];
+    t[0][0] = a.r; t[0][1] = a.g; t[0][2] = a.b;
+    t[1][0] = b.r; t[1][1] = b.g; t[1][2] = b.b;
+    t[2][0] = c.r; t[2][1] = c.g; t[2][2] = c.b;
+    t[3][0] = d.r; t[3][1] = d.g; t[3][2] = d.b;
+  } else {
+    const size_t plane = (size_t)H * W;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float* p = img + c * plane;
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* pl = img + ch * plane;
+      t[0][ch] = pl[o00]; t[1][ch] = pl[o10]; t[2][ch] = pl[o01]; t[3][ch] = pl[o11];
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
     float v = 0.0f;
-    if (vx0 && vy0) v += p[(size_t)y0 * W + x0] * (wx0 * wy0);
-    if (vx1 && vy0) v += p[(size_t)y0 * W + x1] * (wx1 * wy0);
-    if (vx0 && vy1) v += p[(size_t)y1 * W + x0] * (wx0 * wy1);
-    if (vx1 && vy1) v += p[(size_t)y1 * W + x1] * (wx1 * wy1);
-    out[c] = v;
+    if (v00) v += t[0][ch] * w00;
+    if (v10) v += t[1][ch] * w10;
+    if (v01) v += t[2][ch] * w01;
+    if (v11) v += t[3][ch] * w11;
+    out[ch] = v;
   }
 }
 
@@ -98,7 +123,8 @@ __global__ void pixel_blend_kernel(NudfPixelBlend p, const float* __restrict__ d
     m[v] = (fabsf(xn) < 1.0f) && (fabsf(yn) < 1.0f);
     const float ix = (xn + 1.0f) * 0.5f * (float)(W - 1);
     const float iy = (yn + 1.0f) * 0.5f * (float)(H - 1);
-    bilinear3(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col[v]);
+    if (p.img_layout) bilinear3<true>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col[v]);
+    else bilinear3<false>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col[v]);
     lg[v] = p.logits[(size_t)i * p.nl + v];
   }
   float Te;
@@ -221,12 +247,18 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
     for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
 
-template <bool BWD, int PC>
-__global__ __launch_bounds__(256) void patch_blend_kernel(NudfPatchBlend p, const float* __restrict__ d_patch,
-                                                          float* __restrict__ d_logits, float* __restrict__ d_w) {
+// One WORKGROUP per ray; its PB_WAVES waves take the samples round-robin (the per-sample work -- V homographies,
+// V x Npx bilinear gathers, the view softmax -- is independent across samples; only the forward's sum over samples
+// is shared and is reduced through LDS in a fixed order at the end).  One wave per ray left a single wave per SIMD
+// walking S x V dependent gather rounds: latency bound at ~0.7 TB/s of texel traffic.
+// PB_WAVES = 4 for >= 1024 rays (4 waves/SIMD resident across the chip in one round), 8 below.
+template <bool BWD, int PC, int PB_WAVES>
+__global__ __launch_bounds__(64 * PB_WAVES) void patch_blend_kernel(NudfPatchBlend p, const float* __restrict__ d_patch,
+                                                                    float* __restrict__ d_logits,
+                                                                    float* __restrict__ d_w) {
+  __shared__ float red[BWD ? 1 : PB_WAVES][BWD ? 1 : (PC * 64 * 3 + 1)];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + wave;
-  if (ray >= p.N) return;
+  const int ray = blockIdx.x;
   const int S = p.S, V = p.V, H = p.H, W = p.W, h = p.hps, ws = 2 * p.hps + 1, Npx = ws * ws;
   const float* ref = p.ref_cam;
   const float dxr = p.rays_d[ray * 3], dyr = p.rays_d[ray * 3 + 1], dzr = p.rays_d[ray * 3 + 2];
@@ -251,7 +283,7 @@ __global__ __launch_bounds__(256) void patch_blend_kernel(NudfPatchBlend p, cons
   }
   float pmask_acc = 0.f;
 
-  for (int s = 0; s < S; ++s) {
+  for (int s = wave; s < S; s += PB_WAVES) {
     const size_t sb = (size_t)ray * S + s;
     const float px = p.pts[sb * 3], py = p.pts[sb * 3 + 1], pz = p.pts[sb * 3 + 2];
     float gx = p.grad[sb * 3], gy = p.grad[sb * 3 + 1], gz = p.grad[sb * 3 + 2];
@@ -306,7 +338,10 @@ __global__ __launch_bounds__(256) void patch_blend_kernel(NudfPatchBlend p, cons
         float xn = fminf(fmaxf(2.0f * gxp / (float)(W - 1) - 1.0f, -10.0f), 10.0f);
         float yn = fminf(fmaxf(2.0f * gyp / (float)(H - 1) - 1.0f, -10.0f), 10.0f);
         const float ix = (xn + 1.0f) * 0.5f * (float)(W - 1), iy = (yn + 1.0f) * 0.5f * (float)(H - 1);
-        if (act[c]) bilinear3(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col[c][v]);
+        if (act[c]) {
+          if (p.img_layout) bilinear3<true>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col[c][v]);
+          else bilinear3<false>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col[c][v]);
+        }
         else { col[c][v][0] = col[c][v][1] = col[c][v][2] = 0.f; mk = true; }
         allv = allv && mk;
       }
@@ -352,13 +387,31 @@ __global__ __launch_bounds__(256) void patch_blend_kernel(NudfPatchBlend p, cons
   if (!BWD) {
 #pragma unroll
     for (int c = 0; c < PC; ++c) {
-      const int pi = c * 64 + l;
-      if (pi < Npx) {
-        const size_t b = ((size_t)ray * Npx + pi) * 3;
-        p.patch_colors[b] = accp[c][0]; p.patch_colors[b + 1] = accp[c][1]; p.patch_colors[b + 2] = accp[c][2];
+      red[wave][(c * 64 + l) * 3 + 0] = accp[c][0];
+      red[wave][(c * 64 + l) * 3 + 1] = accp[c][1];
+      red[wave][(c * 64 + l) * 3 + 2] = accp[c][2];
+    }
+    if (l == 0) red[wave][PC * 64 * 3] = pmask_acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < PC; ++c) {
+        const int pi = c * 64 + l;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int w8 = 0; w8 < PB_WAVES; ++w8) {
+          t0 += red[w8][pi * 3]; t1 += red[w8][pi * 3 + 1]; t2 += red[w8][pi * 3 + 2];
+        }
+        if (pi < Npx) {
+          const size_t b = ((size_t)ray * Npx + pi) * 3;
+          p.patch_colors[b] = t0; p.patch_colors[b + 1] = t1; p.patch_colors[b + 2] = t2;
+        }
+      }
+      if (l == 0) {
+        float t = 0.f;
+        for (int w8 = 0; w8 < PB_WAVES; ++w8) t += red[w8][PC * 64 * 3];
+        p.patch_mask[ray] = t;
       }
     }
-    if (l == 0) p.patch_mask[ray] = pmask_acc;
   }
 }
 
@@ -369,9 +422,16 @@ extern "C" int nudf_patch_blend_fwd(const NudfPatchBlend* a, void* stream) {
     nudf_set_error("nudf_patch_blend: V <= 16 and h_patch_size <= 5 required", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
-  dim3 grid((a->N + 3) / 4), block(256);
-  if (npx <= 64) hipLaunchKernelGGL((patch_blend_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, *a, nullptr, nullptr, nullptr);
-  else hipLaunchKernelGGL((patch_blend_kernel<false, 2>), grid, block, 0, (hipStream_t)stream, *a, nullptr, nullptr, nullptr);
+  const bool w8 = a->N < 1024;
+  dim3 grid(a->N), block(w8 ? 512 : 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (npx <= 64) {
+    if (w8) hipLaunchKernelGGL((patch_blend_kernel<false, 1, 8>), grid, block, 0, st, *a, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((patch_blend_kernel<false, 1, 4>), grid, block, 0, st, *a, nullptr, nullptr, nullptr);
+  } else {
+    if (w8) hipLaunchKernelGGL((patch_blend_kernel<false, 2, 8>), grid, block, 0, st, *a, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((patch_blend_kernel<false, 2, 4>), grid, block, 0, st, *a, nullptr, nullptr, nullptr);
+  }
   NUDF_CHECK_LAUNCH("nudf_patch_blend_fwd");
   return 0;
 }
@@ -379,9 +439,16 @@ extern "C" int nudf_patch_blend_bwd(const NudfPatchBlend* a, const float* d_patc
                                     void* stream) {
   if (a->N <= 0) return 0;
   const int npx = (2 * a->hps + 1) * (2 * a->hps + 1);
-  dim3 grid((a->N + 3) / 4), block(256);
-  if (npx <= 64) hipLaunchKernelGGL((patch_blend_kernel<true, 1>), grid, block, 0, (hipStream_t)stream, *a, d_patch, d_logits, d_w);
-  else hipLaunchKernelGGL((patch_blend_kernel<true, 2>), grid, block, 0, (hipStream_t)stream, *a, d_patch, d_logits, d_w);
+  const bool w8 = a->N < 1024;
+  dim3 grid(a->N), block(w8 ? 512 : 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (npx <= 64) {
+    if (w8) hipLaunchKernelGGL((patch_blend_kernel<true, 1, 8>), grid, block, 0, st, *a, d_patch, d_logits, d_w);
+    else hipLaunchKernelGGL((patch_blend_kernel<true, 1, 4>), grid, block, 0, st, *a, d_patch, d_logits, d_w);
+  } else {
+    if (w8) hipLaunchKernelGGL((patch_blend_kernel<true, 2, 8>), grid, block, 0, st, *a, d_patch, d_logits, d_w);
+    else hipLaunchKernelGGL((patch_blend_kernel<true, 2, 4>), grid, block, 0, st, *a, d_patch, d_logits, d_w);
+  }
   NUDF_CHECK_LAUNCH("nudf_patch_blend_bwd");
   return 0;
 }

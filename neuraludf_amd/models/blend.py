@@ -14,29 +14,44 @@ def _c(t):
     return None if t is None else t.detach().float().contiguous()
 
 
+def _img(t):
+    """source images [V,3,H,W] -> (tensor whose memory the kernel reads, its [V,3,H,W] shape, layout flag).
+    The reference hands over `images[src_idx].permute(0, 3, 1, 2)` (dataset.py:147-149), i.e. channel-interleaved
+    memory behind an NCHW view: the kernels read that layout directly (one 12-byte load per texel, no 100 MB
+    re-layout copy per iteration); a contiguous NCHW tensor is read as three planes."""
+    t = t.detach().float()
+    if not t.is_contiguous():
+        hwc = t.permute(0, 2, 3, 1)
+        if hwc.is_contiguous():
+            return hwc, tuple(t.shape), 1
+        t = t.contiguous()
+    return t, tuple(t.shape), 0
+
+
 class _PixelBlendFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, logits, proj, imgs):
-        pts, logits, proj, imgs = _c(pts), _c(logits), _c(proj), _c(imgs)
+        pts, logits, proj = _c(pts), _c(logits), _c(proj)
+        imgs, (V, _, H, W), layout = _img(imgs)
         P = pts.shape[0]
-        V, _, H, W = imgs.shape
         a = PixelBlend()
         a.pts, a.logits, a.nl, a.proj, a.imgs = ptr(pts), ptr(logits), logits.shape[1], ptr(proj), ptr(imgs)
-        a.P, a.V, a.H, a.W = P, V, H, W
+        a.P, a.V, a.H, a.W, a.img_layout = P, V, H, W, layout
         pix = torch.empty(P, 3, device=pts.device)
         a.pix = ptr(pix)
         call("nudf_pixel_blend_fwd", a)
         ctx.save_for_backward(pts, logits, proj, imgs)
+        ctx.img = (V, H, W, layout)
         return pix
 
     @staticmethod
     def backward(ctx, d_pix):
         pts, logits, proj, imgs = ctx.saved_tensors
         P = pts.shape[0]
-        V, _, H, W = imgs.shape
+        V, H, W, layout = ctx.img
         a = PixelBlend()
         a.pts, a.logits, a.nl, a.proj, a.imgs = ptr(pts), ptr(logits), logits.shape[1], ptr(proj), ptr(imgs)
-        a.P, a.V, a.H, a.W = P, V, H, W
+        a.P, a.V, a.H, a.W, a.img_layout = P, V, H, W, layout
         d_logits = torch.empty_like(logits)
         call("nudf_pixel_blend_bwd", a, ptr(d_pix.contiguous()), ptr(d_logits))
         return None, d_logits, None, None
@@ -72,9 +87,9 @@ class _PixelCompositeFn(torch.autograd.Function):
         return d_w, d_pix, None, d_in, d_tail
 
 
-def _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps):
+def _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps, img):
     N, S = pts.shape[0], pts.shape[1]
-    V, _, H, W = imgs.shape
+    V, H, W, a.img_layout = img
     a.pts, a.grad, a.rays_d, a.uv = ptr(pts), ptr(grad), ptr(rays_d), ptr(uv)
     a.logits, a.nl, a.w, a.ldw = ptr(logits), logits.shape[-1], ptr(w), w.shape[1]
     a.ref_cam, a.src_cam, a.imgs = ptr(ref_cam), ptr(src_cam), ptr(imgs)
@@ -85,12 +100,13 @@ class _PatchBlendFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps):
         ctx.set_materialize_grads(False)
-        pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs = map(_c, (pts, grad, rays_d, uv, logits, w, ref_cam,
-                                                                            src_cam, imgs))
+        pts, grad, rays_d, uv, logits, w, ref_cam, src_cam = map(_c, (pts, grad, rays_d, uv, logits, w, ref_cam, src_cam))
+        imgs, (V, _, H, W), layout = _img(imgs)
+        ctx.img = (V, H, W, layout)
         N = pts.shape[0]
         npx = (2 * hps + 1) ** 2
         a = PatchBlend()
-        _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps)
+        _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, hps, ctx.img)
         pc = torch.empty(N, npx, 3, device=pts.device)
         pm = torch.empty(N, device=pts.device)
         a.patch_colors, a.patch_mask = ptr(pc), ptr(pm)
@@ -107,7 +123,7 @@ class _PatchBlendFn(torch.autograd.Function):
         pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs = ctx.saved_tensors
         N, S = pts.shape[0], pts.shape[1]
         a = PatchBlend()
-        _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, ctx.hps)
+        _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, ctx.hps, ctx.img)
         d_logits = torch.empty_like(logits)
         d_ws = torch.empty(N, S, device=pts.device)
         call("nudf_patch_blend_bwd", a, ptr(d_pc.contiguous()), ptr(d_logits), ptr(d_ws))

@@ -85,13 +85,16 @@ def make_rays(scene: Scene, img_idx: int, n_rays: int, seed: int = 1234, margin:
                 mask=torch.ones(n_rays, 1), rays_uv=uv, pixels=torch.stack([px, py], -1))
 
 
-def make_source_views(scene: Scene, img_idx: int, n_src: int = 8, seed: int = 77):
-    """8 nearest cameras + random source images (dataset/dataset.py:129-149 picks by distance)."""
+def make_source_views(scene: Scene, img_idx: int, n_src: int = 8, seed: int = 77, hwc: bool = False):
+    """8 nearest cameras + random source images (dataset/dataset.py:129-149 picks by distance).  hwc=True returns
+    `color_maps` the way the reference's dataset does: an NCHW view of channel-interleaved memory (:147-149)."""
     g = torch.Generator().manual_seed(seed)
     c = scene.c2w[:, :3, 3]
     d = (c - c[img_idx]).norm(dim=-1)
     order = torch.argsort(d)[1:n_src + 1]
     imgs = torch.rand(n_src, 3, scene.H, scene.W, generator=g)
+    if hwc:
+        imgs = imgs.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     return dict(color_maps=imgs, intrinsics=scene.intrinsics[order].contiguous(),
                 src_c2ws=scene.c2w[order].contiguous(), w2cs=torch.inverse(scene.c2w[order]).contiguous(),
                 query_c2w=scene.c2w[img_idx].contiguous())

@@ -96,6 +96,38 @@ def test_blend_stagewise(dev, with_bg):
         assert rel(bgd.grad, bgr.grad) < 1e-3
 
 
+def test_blend_image_layouts_agree(dev):
+    """channel-interleaved source images behind an NCHW view (what the reference's dataset hands over,
+    dataset.py:147-149) are read in place and give bit-identical pixel / patch colours and gradients as the planar
+    NCHW copy; ray counts on both sides of the 4- / 8-waves-per-ray switch."""
+    from neuraludf_amd.models import blend
+    g = torch.Generator().manual_seed(11)
+    scene = synth.make_scene("tiny")
+    S, hps = 19, 2
+    src = synth.make_source_views(scene, 0, 8)
+    planar = _smooth_images(8, scene.H, scene.W).to(dev)
+    inter = planar.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert not inter.is_contiguous() and torch.equal(inter, planar)
+    for N in (9, 1030):
+        r = synth.make_rays(scene, 0, N, seed=8, margin=6)
+        z = torch.sort(r["near"] + (r["far"] - r["near"]) * torch.rand(N, S, generator=g), -1)[0]
+        pts = (r["rays_o"][:, None] + r["rays_d"][:, None] * z[..., None]).to(dev)
+        grad = torch.randn(N, S, 3, generator=g).to(dev)
+        logits, w = torch.randn(N, S, 10, generator=g).to(dev), (torch.rand(N, S, generator=g) * 0.05).to(dev)
+        k1, k2 = torch.randn(N, 3, generator=g).to(dev), torch.randn(N, 25, 3, generator=g).to(dev)
+        res = []
+        for imgs in (planar, inter):
+            lg, wd = logits.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            cp, pc, pmk = blend.blend_and_composite(hps, pts, lg, wd, grad, r["rays_d"].to(dev), imgs, src["w2cs"].to(dev),
+                                                    src["intrinsics"].to(dev), src["query_c2w"].to(dev),
+                                                    r["rays_uv"].clone().to(dev))
+            ((cp * k1).sum() + (pc * k2).sum()).backward()
+            res.append((cp.detach(), pc.detach(), pmk.detach(), lg.grad, wd.grad))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        assert float(res[0][1].abs().max()) > 0
+
+
 def test_ssim_patch_loss(dev):
     from neuraludf_amd.loss.loss import ColorLoss
     g = torch.Generator().manual_seed(6)
