@@ -38,3 +38,30 @@ def test_grid_queries_match_oracle(monkeypatch):
     np.testing.assert_allclose(u.reshape(-1), -ou.numpy(), atol=1e-4)
     gm = float(og.abs().max())
     np.testing.assert_allclose(g.reshape(-1, 3), og.numpy(), atol=2e-4 * max(1.0, gm))
+
+
+def test_extract_geometry_with_stub_marching_cubes(monkeypatch):
+    """renderer.extract_geometry = GPU grid query + the caller's marching cubes (PyMCubes, stubbed here): the grid
+    handed to it is the UDF volume and the vertices are mapped back to the bounding box."""
+    import sys
+    import types
+    from neuraludf_amd.models import fields
+    from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending, extract_fields
+    dev = torch.device("cuda:0")
+    mods = perturb_(build_modules(fields, seed=0))
+    for m in mods.values():
+        m.to(dev)
+    seen = {}
+
+    def fake_mc(u, thr):
+        seen["u"], seen["thr"] = u, thr
+        return np.array([[0.0, 0.0, 0.0], [15.0, 15.0, 15.0], [7.5, 0.0, 15.0]]), np.array([[0, 1, 2]])
+    monkeypatch.setitem(sys.modules, "mcubes", types.SimpleNamespace(marching_cubes=fake_mc))
+    r = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], n_samples=16,
+                            n_importance=0, n_outside=0, up_sample_steps=1, perturb=0.0)
+    bmin, bmax = torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 0.5, 2.0])
+    v, t = r.extract_geometry(bmin, bmax, 16, threshold=0.02)
+    np.testing.assert_allclose(v, [[-1, -1, -1], [1, 0.5, 2], [0, -1, 2]], atol=1e-12)
+    assert t.tolist() == [[0, 1, 2]] and seen["thr"] == 0.02 and seen["u"].shape == (16, 16, 16)
+    np.testing.assert_array_equal(seen["u"], extract_fields(bmin, bmax, 16, lambda p: mods["udf"].udf(p)[:, 0], dev))
+    assert float(seen["u"].min()) >= 0.0
