@@ -58,18 +58,28 @@ __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 
 struct RawSample {
   float z, zn, u, gx, gy, gz;
 };
-__device__ __forceinline__ void load_raw(const NudfComposite& p, int ray, int i, RawSample& r) {
+// Row pointers of one ray.  The ray index is wave-uniform (made scalar with readfirstlane), so every address is
+// <SGPR base> + <32-bit lane offset>: no 64-bit VALU address arithmetic (it was 9 % of the instructions).
+struct RayRows {
+  const float* z; const float* udf; const float* grad; const float* color; const float* color_base;
+};
+__device__ __forceinline__ RayRows ray_rows(const NudfComposite& p, int ray) {
+  const size_t b = (size_t)ray * p.S;
+  RayRows r;
+  r.z = p.z + b; r.udf = p.udf + b; r.grad = p.grad + b * 3; r.color = p.color + b * 3; r.color_base = p.color_base + b * 3;
+  return r;
+}
+__device__ __forceinline__ void load_raw(const RayRows& rr, int S, int i, RawSample& r) {
   // branch-free: the index is clamped into the ray (a divergent branch around a load makes the compiler wait
   // for all outstanding loads at the join); lanes past S load a valid duplicate that is never used
-  const int S = p.S;
-  const int ic = min(i, S - 1);
-  const size_t b = (size_t)ray * S + ic;
-  r.z = p.z[b];
-  r.zn = p.z[b + ((ic < S - 1) ? 1 : 0)];
-  r.u = p.udf[b];
-  r.gx = p.grad[b * 3 + 0];
-  r.gy = p.grad[b * 3 + 1];
-  r.gz = p.grad[b * 3 + 2];
+  // unsigned offsets: <SGPR base> + zero-extended 32-bit lane offset is the saddr addressing mode
+  const unsigned ic = min((unsigned)i, (unsigned)(S - 1));
+  r.z = rr.z[ic];
+  r.zn = rr.z[min(ic + 1u, (unsigned)(S - 1))];
+  r.u = rr.udf[ic];
+  r.gx = rr.grad[ic * 3u + 0u];
+  r.gy = rr.grad[ic * 3u + 1u];
+  r.gz = rr.grad[ic * 3u + 2u];
 }
 
 // shared per-sample evaluation (phase A)
@@ -98,10 +108,12 @@ __device__ __forceinline__ void eval_sample(const NudfComposite& p, const RayCon
   s.aocc = 1.0f - s.E_occ;
 }
 
-template <int NC>
+// FULL: S == 64 * NC, no outside samples, s_nominal >= S -- every lane of every chunk holds a live inside sample, so
+// none of the liveness selects / compares exist in that instantiation (cfg 2 and cfg 5 shapes).
+template <int NC, bool DIAG, bool FULL>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + wave;
+  const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   __shared__ float red[4][5];
   float s_relax_n = 0.f, s_relax_d = 0.f, s_near_n = 0.f, s_near_d = 0.f, s_sparse = 0.f;
 
@@ -118,26 +130,30 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     // ---- phase 0: every load of this ray, branch-free --------------------------------------
     RawSample raw[NC];
     float bgz[NC], bgzn[NC], bgs[NC];
+    const RayRows rr = ray_rows(p, ray);
+    float* __restrict__ wrow = p.weights + (size_t)ray * ST;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      load_raw(p, ray, i, raw[c]);
-      const size_t b = (size_t)ray * S + min(i, S - 1);
-      cr[c] = p.color[b * 3 + 0]; cg[c] = p.color[b * 3 + 1]; cb[c] = p.color[b * 3 + 2];
-      br[c] = p.color_base[b * 3 + 0]; bg[c] = p.color_base[b * 3 + 1]; bb[c] = p.color_base[b * 3 + 2];
+      load_raw(rr, S, i, raw[c]);
+      const unsigned b = min((unsigned)i, (unsigned)(S - 1));
+      cr[c] = rr.color[b * 3u + 0u]; cg[c] = rr.color[b * 3u + 1u]; cb[c] = rr.color[b * 3u + 2u];
+      br[c] = rr.color_base[b * 3u + 0u]; bg[c] = rr.color_base[b * 3u + 1u]; bb[c] = rr.color_base[b * 3u + 2u];
       bgz[c] = bgzn[c] = bgs[c] = 0.f;
     }
-    if (NO > 0) {  // uniform
+    if (!FULL && NO > 0) {  // uniform
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int i = c * 64 + l;
         if ((c + 1) * 64 <= S) continue;  // uniform: this chunk holds no outside sample
-        const int j = min(max(i - S, 0), NO - 1);
-        const size_t b = (size_t)ray * NO + j;
-        bgz[c] = p.bg_z[b];
-        bgzn[c] = p.bg_z[b + ((j < NO - 1) ? 1 : 0)];
-        bgs[c] = p.bg_sigma[b];
-        const float q0 = p.bg_color[b * 3 + 0], q1 = p.bg_color[b * 3 + 1], q2 = p.bg_color[b * 3 + 2];
+        const unsigned j = (unsigned)min(max(i - S, 0), NO - 1);
+        const float* bz = p.bg_z + (size_t)ray * NO;
+        const float* bs = p.bg_sigma + (size_t)ray * NO;
+        const float* bc = p.bg_color + (size_t)ray * NO * 3;
+        bgz[c] = bz[j];
+        bgzn[c] = bz[min(j + 1u, (unsigned)(NO - 1))];
+        bgs[c] = bs[j];
+        const float q0 = bc[j * 3u + 0u], q1 = bc[j * 3u + 1u], q2 = bc[j * 3u + 2u];
         const bool out = i >= S;
         cr[c] = out ? q0 : cr[c]; cg[c] = out ? q1 : cg[c]; cb[c] = out ? q2 : cb[c];
         br[c] = out ? q0 : br[c]; bg[c] = out ? q1 : bg[c]; bb[c] = out ? q2 : bb[c];
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const bool live = (c * 64 + l) < ST;
+      const bool live = FULL || (c * 64 + l) < ST;
       cr[c] = live ? cr[c] : 0.f; cg[c] = live ? cg[c] : 0.f; cb[c] = live ? cb[c] : 0.f;
       br[c] = live ? br[c] : 0.f; bg[c] = live ? bg[c] : 0.f; bb[c] = live ? bb[c] : 0.f;
     }
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
       const int i = c * 64 + l;
       tcv[c] = 0.f; aocc[c] = 0.f; alpha[c] = 0.f; apv[c] = 0.f; amv[c] = 0.f; flipv[c] = 1.f; midv[c] = 0.f;
       nx[c] = ny[c] = nz[c] = 0.f;
-      if (i < S) {
+      if (FULL || i < S) {
         PerSample s;
         eval_sample(p, rc, i, raw[c], s);
         tcv[c] = s.tc; aocc[c] = s.aocc; flipv[c] = s.flip; midv[c] = s.mid;
@@ -172,15 +188,17 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
         if (pn < 1.2f) { s_relax_n += ge; s_relax_d += 1.0f; }
         if (s.u < 0.05f) { s_near_n += ge; s_near_d += 1.0f; }
         s_sparse += CEXP(-p.sparse_scale * s.u);
-        if (p.o_alpha_occ) p.o_alpha_occ[b] = s.aocc;
-        if (p.o_raw_occ) p.o_raw_occ[b] = s.raw;
-        if (p.o_true_cos) p.o_true_cos[b] = s.tc;
-        if (p.o_grad_mag) p.o_grad_mag[b] = s.gm;
-        if (p.o_mid_z) p.o_mid_z[b] = s.mid;
-        if (p.o_dists) p.o_dists[b] = s.dist;
-        if (p.o_inside) p.o_inside[b] = (pn < 1.0f) ? 1.0f : 0.0f;
-        if (p.o_flip) p.o_flip[b] = s.flip;
-      } else if (i < ST) {
+        if (DIAG) {
+          if (p.o_alpha_occ) p.o_alpha_occ[b] = s.aocc;
+          if (p.o_raw_occ) p.o_raw_occ[b] = s.raw;
+          if (p.o_true_cos) p.o_true_cos[b] = s.tc;
+          if (p.o_grad_mag) p.o_grad_mag[b] = s.gm;
+          if (p.o_mid_z) p.o_mid_z[b] = s.mid;
+          if (p.o_dists) p.o_dists[b] = s.dist;
+          if (p.o_inside) p.o_inside[b] = (pn < 1.0f) ? 1.0f : 0.0f;
+          if (p.o_flip) p.o_flip[b] = s.flip;
+        }
+      } else if (!FULL && i < ST) {
         const float dist = (i < ST - 1) ? (bgzn[c] - bgz[c]) : rc.sdist;
         alpha[c] = 1.0f - CEXP(-fmaxf(bgs[c], 0.0f) * dist);  // :181
       }
@@ -195,18 +213,20 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
       const float tn_other = (c + 1 < NC) ? wave_bcast(tcv[(c + 1 < NC) ? c + 1 : c], 0) : 0.f;
       const float tnext = wave_shift_down1(tcv[c], tn_other);
       float vm = (i < S - 1) ? ((tnext < 0.01f) ? 1.0f : 0.0f) : 1.0f;
-      float q = (i < S) ? (clip01(1.0f - aocc[c] + p.flip_saturation * vm) + 1e-7f) : 1.0f;
+      float q = (FULL || i < S) ? (clip01(1.0f - aocc[c] + p.flip_saturation * vm) + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(q) * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
-      if (i < S) {
+      if (FULL || i < S) {
         const float vis = clip01(exc);
         alpha[c] = apv[c] * vis + amv[c] * (1.0f - vis);
-        const size_t b = (size_t)ray * S + i;
-        if (p.o_vis_prob) p.o_vis_prob[b] = vis;
-        if (p.o_alpha) p.o_alpha[b] = alpha[c];
-        if (p.o_alpha_plus) p.o_alpha_plus[b] = apv[c];
-        if (p.o_alpha_minus) p.o_alpha_minus[b] = amv[c];
+        if (DIAG) {
+          const size_t b = (size_t)ray * S + i;
+          if (p.o_vis_prob) p.o_vis_prob[b] = vis;
+          if (p.o_alpha) p.o_alpha[b] = alpha[c];
+          if (p.o_alpha_plus) p.o_alpha_plus[b] = apv[c];
+          if (p.o_alpha_minus) p.o_alpha_minus[b] = amv[c];
+        }
       }
     }
 
@@ -217,17 +237,17 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      const float f = (i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
+      const float f = (FULL || i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(f) * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
-      const float w = (i < ST) ? alpha[c] * exc : 0.0f;
-      if (i < ST) p.weights[(size_t)ray * ST + i] = w;
+      const float w = (FULL || i < ST) ? alpha[c] * exc : 0.0f;
+      if (FULL || i < ST) wrow[i] = w;
       a_cr += w * cr[c]; a_cg += w * cg[c]; a_cb += w * cb[c];
       a_br += w * br[c]; a_bg += w * bg[c]; a_bb += w * bb[c];
       a_wall += w;
-      if (i < p.s_nominal) a_ws += w;
-      if (i < S) {
+      if (FULL || i < p.s_nominal) a_ws += w;
+      if (FULL || i < S) {
         a_depth += w * midv[c];
         a_nx += w * nx[c]; a_ny += w * ny[c]; a_nz += w * nz[c];
       }
@@ -267,31 +287,45 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
   }
 }
 
-// out[k] = sum_b ws[b * K + k]  (one block; fixed order -> deterministic batch-global sums; ASSIGNS)
-__global__ __launch_bounds__(256) void partial_sums_kernel(const float* __restrict__ ws, int nblk, int K,
-                                                           float* __restrict__ out) {
-  __shared__ float red[256];
-  for (int k = 0; k < K; ++k) {
-    float acc = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) acc += ws[(size_t)b * K + k];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-      if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
-      __syncthreads();
+// out[k] = sum_b ws[b * K + k]  (one block of 1024 threads; fixed order -> deterministic batch-global sums; ASSIGNS).
+// Thread t owns the block rows t, t + 1024, ... and keeps all K (<= 8) running sums, so the partials are read once,
+// coalesced; then one DPP wave reduction per k and a 16-entry LDS pass.  (The first version reduced one k at a time
+// with an LDS tree per k: 27 us for 8192 blocks, a quarter of the whole composite forward at 32768 rays.)
+__global__ __launch_bounds__(1024) void partial_sums_kernel(const float* __restrict__ ws, int nblk, int K,
+                                                            float* __restrict__ out) {
+  __shared__ float red[8][16];
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 1024) {
+    const float* row = ws + (size_t)b * K;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < K) acc[k] += row[k];
+  }
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < K) {
+      const float t = wave_sum(acc[k]);
+      if (l == 0) red[k][wave] = t;
     }
-    if (threadIdx.x == 0) out[k] = red[0];
-    __syncthreads();
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
+    out[threadIdx.x] = t;
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // backward: recompute the forward per ray, then two reverse (suffix) scans
 // ------------------------------------------------------------------------------------------
-template <int NC>
+template <int NC, bool FULL>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, NudfCompositeGrad g) {
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + wave;
+  const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   __shared__ float red[4][3];
   float d_invs = 0.f, d_beta = 0.f, d_gamma = 0.f;
 
@@ -325,18 +359,20 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     // ---- phase 0: every load of this ray, branch-free (see load_raw) ------------------------------
     RawSample raw[NC];
     float cdot[NC], dwup[NC], bgz[NC], bgzn[NC], bgs[NC];
+    const RayRows rr = ray_rows(p, ray);
+    const float* dwrow = g.d_weights ? g.d_weights + (size_t)ray * ST : nullptr;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      load_raw(p, ray, i, raw[c]);
-      const size_t b = (size_t)ray * S + min(i, S - 1);
+      load_raw(rr, S, i, raw[c]);
+      const unsigned b = min((unsigned)i, (unsigned)(S - 1));
       // the colours only enter the backward through <upstream, colour>
-      cdot[c] = dCr * p.color[b * 3 + 0] + dCg * p.color[b * 3 + 1] + dCb * p.color[b * 3 + 2] +
-                dBr * p.color_base[b * 3 + 0] + dBg * p.color_base[b * 3 + 1] + dBb * p.color_base[b * 3 + 2];
-      dwup[c] = g.d_weights ? g.d_weights[(size_t)ray * ST + min(i, ST - 1)] : 0.f;
+      cdot[c] = dCr * rr.color[b * 3u + 0u] + dCg * rr.color[b * 3u + 1u] + dCb * rr.color[b * 3u + 2u] +
+                dBr * rr.color_base[b * 3u + 0u] + dBg * rr.color_base[b * 3u + 1u] + dBb * rr.color_base[b * 3u + 2u];
+      dwup[c] = dwrow ? dwrow[min((unsigned)i, (unsigned)(ST - 1))] : 0.f;
       bgz[c] = bgzn[c] = bgs[c] = 0.f;
     }
-    if (NO > 0) {  // uniform
+    if (!FULL && NO > 0) {  // uniform
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int i = c * 64 + l;
@@ -353,7 +389,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const bool live = (c * 64 + l) < ST;
+      const bool live = FULL || (c * 64 + l) < ST;
       cdot[c] = live ? cdot[c] : 0.f;
       dwup[c] = live ? dwup[c] : 0.f;
     }
@@ -364,10 +400,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       const int i = c * 64 + l;
       ps[c].tc = 0.f; ps[c].aocc = 0.f; alpha[c] = 0.f; bg_dist[c] = 0.f; bg_E[c] = 1.f; icv[c] = 0.f;
       ap_raw[c] = am_raw[c] = 0.f;
-      if (i < S) {
+      if (FULL || i < S) {
         eval_sample(p, rc, i, raw[c], ps[c]);
         icv[c] = iter_cos_of(-fabsf(ps[c].tc), p.has_anneal, p.cos_anneal);
-      } else if (i < ST) {
+      } else if (!FULL && i < ST) {
         bg_dist[c] = (i < ST - 1) ? (bgzn[c] - bgz[c]) : rc.sdist;
         bg_E[c] = CEXP(-fmaxf(bgs[c], 0.0f) * bg_dist[c]);
         alpha[c] = 1.0f - bg_E[c];
@@ -382,13 +418,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       const float tnext = wave_shift_down1(ps[c].tc, tn_other);
       float vm = (i < S - 1) ? ((tnext < 0.01f) ? 1.0f : 0.0f) : 1.0f;
       inner[c] = 1.0f - ps[c].aocc + p.flip_saturation * vm;
-      q[c] = (i < S) ? (clip01(inner[c]) + 1e-7f) : 1.0f;
+      q[c] = (FULL || i < S) ? (clip01(inner[c]) + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(q[c]) * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
       Vraw[c] = exc;
       vis[c] = clip01(exc);
-      if (i < S) {
+      if (FULL || i < S) {
         ap_raw[c] = sdf2alpha_f(ps[c].u, icv[c], ps[c].dist, rc.inv_s).a;
         am_raw[c] = sdf2alpha_f(-ps[c].u, icv[c], ps[c].dist, rc.inv_s).a;
         alpha[c] = clip01(ap_raw[c]) * vis[c] + clip01(am_raw[c]) * (1.0f - vis[c]);
@@ -399,29 +435,30 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      f[c] = (i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
+      f[c] = (FULL || i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
       float inc = wave_incl_scan_mul(f[c]) * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
       T[c] = exc;
-      w[c] = (i < ST) ? alpha[c] * exc : 0.0f;
+      w[c] = (FULL || i < ST) ? alpha[c] * exc : 0.0f;
       float d = 0.f;
-      if (i < ST) {
+      if (FULL || i < ST) {
         d = dWall + dwup[c] + cdot[c];
-        if (i < p.s_nominal) d += dWs;
+        if (FULL || i < p.s_nominal) d += dWs;
       }
-      if (i < S) {
-        const size_t b = (size_t)ray * S + i;
+      if (FULL || i < S) {
+        const unsigned b = (unsigned)i;
         d += dDepth * ps[c].mid + ps[c].flip * (dNx * ps[c].gx + dNy * ps[c].gy + dNz * ps[c].gz);
         // colours receive w * upstream
         if (g.o_d_color) {
-          g.o_d_color[b * 3 + 0] = w[c] * dCr; g.o_d_color[b * 3 + 1] = w[c] * dCg; g.o_d_color[b * 3 + 2] = w[c] * dCb;
+          float* o = g.o_d_color + (size_t)ray * S * 3;
+          o[b * 3u + 0u] = w[c] * dCr; o[b * 3u + 1u] = w[c] * dCg; o[b * 3u + 2u] = w[c] * dCb;
         }
         if (g.o_d_color_base) {
-          g.o_d_color_base[b * 3 + 0] = w[c] * dBr; g.o_d_color_base[b * 3 + 1] = w[c] * dBg;
-          g.o_d_color_base[b * 3 + 2] = w[c] * dBb;
+          float* o = g.o_d_color_base + (size_t)ray * S * 3;
+          o[b * 3u + 0u] = w[c] * dBr; o[b * 3u + 1u] = w[c] * dBg; o[b * 3u + 2u] = w[c] * dBb;
         }
-      } else if (i < ST) {
+      } else if (!FULL && i < ST) {
         const size_t b = (size_t)ray * NO + (i - S);
         if (g.o_d_bg_color) {
           g.o_d_bg_color[b * 3 + 0] = w[c] * (dCr + dBr); g.o_d_bg_color[b * 3 + 1] = w[c] * (dCg + dBg);
@@ -450,11 +487,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
       dV_V[c] = 0.f;
-      if (i < S) {
+      if (FULL || i < S) {
         const float dvis = dalpha[c] * (clip01(ap_raw[c]) - clip01(am_raw[c]));
         const float dV = (Vraw[c] >= 0.0f && Vraw[c] <= 1.0f) ? dvis : 0.0f;
         dV_V[c] = dV * Vraw[c];
-      } else if (i < ST) {
+      } else if (!FULL && i < ST) {
         // background alpha = 1 - exp(-relu(sigma) dist)
         const size_t b = (size_t)ray * NO + (i - S);
         if (g.o_d_bg_sigma) g.o_d_bg_sigma[b] = (bgs[c] > 0.0f) ? dalpha[c] * bg_E[c] * bg_dist[c] : 0.0f;
@@ -468,7 +505,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       float incl = wave_incl_rscan_add(v) + rcarry;
       float excl = incl - v;
       rcarry = wave_bcast(incl, 0);
-      if (i < S) {
+      if (FULL || i < S) {
         const PerSample& s = ps[c];
         const float dq = excl * CRCP(q[c]);
         const float daocc = (inner[c] >= 0.0f && inner[c] <= 1.0f) ? -dq : 0.0f;
@@ -538,9 +575,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
         // sparsity sum
         du += k_sparse * (-p.sparse_scale) * CEXP(-p.sparse_scale * s.u);
 
-        const size_t b = (size_t)ray * S + i;
-        g.o_d_udf[b] = du;
-        g.o_d_grad[b * 3 + 0] = dgx; g.o_d_grad[b * 3 + 1] = dgy; g.o_d_grad[b * 3 + 2] = dgz;
+        float* ou = g.o_d_udf + (size_t)ray * S;
+        float* og = g.o_d_grad + (size_t)ray * S * 3;
+        const unsigned b = (unsigned)i;
+        ou[b] = du;
+        og[b * 3u + 0u] = dgx; og[b * 3u + 1u] = dgy; og[b * 3u + 2u] = dgz;
       }
     }
   }
@@ -568,16 +607,26 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
   }
   dim3 grid((p.N + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  // diagnostics (the 12 per-sample arrays of the full result dict) are a separate instantiation: the training path
+  // carries no stores, branches or address arithmetic for them
+  const bool diag = p.o_alpha_occ || p.o_raw_occ || p.o_true_cos || p.o_grad_mag || p.o_mid_z || p.o_dists ||
+                    p.o_inside || p.o_flip || p.o_vis_prob || p.o_alpha || p.o_alpha_plus || p.o_alpha_minus;
+  const bool full = (p.S == 64 * nc) && p.n_out == 0 && p.s_nominal >= p.S;
+#define NUDF_CF_LAUNCH(NCV)                                                                                   \
+  if (diag) hipLaunchKernelGGL((composite_fwd_kernel<NCV, true, false>), grid, block, 0, st, p);              \
+  else if (full) hipLaunchKernelGGL((composite_fwd_kernel<NCV, false, true>), grid, block, 0, st, p);        \
+  else hipLaunchKernelGGL((composite_fwd_kernel<NCV, false, false>), grid, block, 0, st, p)
   switch (nc) {
-    case 1: hipLaunchKernelGGL(composite_fwd_kernel<1>, grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL(composite_fwd_kernel<2>, grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL(composite_fwd_kernel<3>, grid, block, 0, st, p); break;
-    case 4: hipLaunchKernelGGL(composite_fwd_kernel<4>, grid, block, 0, st, p); break;
-    case 5: hipLaunchKernelGGL(composite_fwd_kernel<5>, grid, block, 0, st, p); break;
-    case 6: hipLaunchKernelGGL(composite_fwd_kernel<6>, grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL(composite_fwd_kernel<8>, grid, block, 0, st, p); break;
+    case 1: NUDF_CF_LAUNCH(1); break;
+    case 2: NUDF_CF_LAUNCH(2); break;
+    case 3: NUDF_CF_LAUNCH(3); break;
+    case 4: NUDF_CF_LAUNCH(4); break;
+    case 5: NUDF_CF_LAUNCH(5); break;
+    case 6: NUDF_CF_LAUNCH(6); break;
+    default: NUDF_CF_LAUNCH(8); break;
   }
-  if (p.ws) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(256), 0, st, p.ws, (int)grid.x, 5, p.sums);
+#undef NUDF_CF_LAUNCH
+  if (p.ws) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, p.ws, (int)grid.x, 5, p.sums);
   NUDF_CHECK_LAUNCH("nudf_composite_fwd");
   return 0;
 }
@@ -593,17 +642,22 @@ extern "C" int nudf_composite_bwd(const NudfComposite* args, const NudfComposite
   }
   dim3 grid((p.N + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const bool full = (p.S == 64 * nc) && p.n_out == 0 && p.s_nominal >= p.S;
+#define NUDF_CB_LAUNCH(NCV)                                                                         \
+  if (full) hipLaunchKernelGGL((composite_bwd_kernel<NCV, true>), grid, block, 0, st, p, *grads);   \
+  else hipLaunchKernelGGL((composite_bwd_kernel<NCV, false>), grid, block, 0, st, p, *grads)
   switch (nc) {
-    case 1: hipLaunchKernelGGL(composite_bwd_kernel<1>, grid, block, 0, st, p, *grads); break;
-    case 2: hipLaunchKernelGGL(composite_bwd_kernel<2>, grid, block, 0, st, p, *grads); break;
-    case 3: hipLaunchKernelGGL(composite_bwd_kernel<3>, grid, block, 0, st, p, *grads); break;
-    case 4: hipLaunchKernelGGL(composite_bwd_kernel<4>, grid, block, 0, st, p, *grads); break;
-    case 5: hipLaunchKernelGGL(composite_bwd_kernel<5>, grid, block, 0, st, p, *grads); break;
-    case 6: hipLaunchKernelGGL(composite_bwd_kernel<6>, grid, block, 0, st, p, *grads); break;
-    default: hipLaunchKernelGGL(composite_bwd_kernel<8>, grid, block, 0, st, p, *grads); break;
+    case 1: NUDF_CB_LAUNCH(1); break;
+    case 2: NUDF_CB_LAUNCH(2); break;
+    case 3: NUDF_CB_LAUNCH(3); break;
+    case 4: NUDF_CB_LAUNCH(4); break;
+    case 5: NUDF_CB_LAUNCH(5); break;
+    case 6: NUDF_CB_LAUNCH(6); break;
+    default: NUDF_CB_LAUNCH(8); break;
   }
+#undef NUDF_CB_LAUNCH
   if (grads->ws && grads->o_d_scal)
-    hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(256), 0, st, grads->ws, (int)grid.x, 3, grads->o_d_scal);
+    hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, grads->ws, (int)grid.x, 3, grads->o_d_scal);
   NUDF_CHECK_LAUNCH("nudf_composite_bwd");
   return 0;
 }

@@ -39,21 +39,45 @@ __device__ __forceinline__ float dpp_f(float identity, float v) {
 }
 
 __device__ __forceinline__ float wave_incl_scan_mul(float v) {
-  v *= dpp_f<NUDF_DPP_ROW_SHR(1), 0xf>(1.0f, v);
-  v *= dpp_f<NUDF_DPP_ROW_SHR(2), 0xf>(1.0f, v);
-  v *= dpp_f<NUDF_DPP_ROW_SHR(4), 0xf>(1.0f, v);
-  v *= dpp_f<NUDF_DPP_ROW_SHR(8), 0xf>(1.0f, v);
-  v *= dpp_f<NUDF_DPP_ROW_BCAST15, 0xa>(1.0f, v);
-  v *= dpp_f<NUDF_DPP_ROW_BCAST31, 0xc>(1.0f, v);
+  // v_mul_f32 with the DPP modifier on its first source: lanes whose DPP source does not exist (or whose row is
+  // masked off) are simply not written, so no identity operand is needed -- 6 VALU instructions.  hipcc does not
+  // fold update_dpp(1.0, v) + fmul (it does fold the add scan), which cost a v_mov identity + a v_mov_dpp per step.
+  // The s_nop 1 before each step is the 2-wait-state VALU-write -> DPP-read hazard (inline asm is not scanned).
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return v;
 }
 __device__ __forceinline__ float wave_incl_scan_add(float v) {
-  v += dpp_f<NUDF_DPP_ROW_SHR(1), 0xf>(0.0f, v);
-  v += dpp_f<NUDF_DPP_ROW_SHR(2), 0xf>(0.0f, v);
-  v += dpp_f<NUDF_DPP_ROW_SHR(4), 0xf>(0.0f, v);
-  v += dpp_f<NUDF_DPP_ROW_SHR(8), 0xf>(0.0f, v);
-  v += dpp_f<NUDF_DPP_ROW_BCAST15, 0xa>(0.0f, v);
-  v += dpp_f<NUDF_DPP_ROW_BCAST31, 0xc>(0.0f, v);
+  // same form as the product scan (hipcc folds only the four row_shr steps of the builtin version; the two masked
+  // row_bcast steps became v_mov identity + v_mov_dpp + v_add each)
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return v;
 }
 // lane l <- lane l-1 (lane 0 <- `first`) / lane l <- lane l+1 (lane 63 <- `last`)
@@ -64,17 +88,14 @@ __device__ __forceinline__ float wave_bcast(float v, int src) {
 }
 // sum over the 64 lanes, returned to every lane
 __device__ __forceinline__ float wave_sum(float v) { return wave_bcast(wave_incl_scan_add(v), 63); }
-// inclusive suffix sum: out[l] = sum_{j>=l} v[j].  Shuffle based: DPP has no backward row broadcast, and
-// total - prefix would cancel catastrophically for the small suffixes behind a surface.
-__device__ __forceinline__ float wave_incl_rscan_add(float v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    float o = __shfl_down(v, d, 64);
-    if (l + d < 64) v += o;
-  }
-  return v;
+// inclusive suffix sum: out[l] = sum_{j>=l} v[j]: reverse the lane order (one ds_bpermute, crossbar only), run the
+// DPP prefix scan, reverse back -- 8 instructions.  (DPP has no backward row broadcast, and total - prefix would
+// cancel catastrophically for the small suffixes behind a surface; the earlier version walked 6 shuffle steps of
+// bpermute + select + add.)
+__device__ __forceinline__ float wave_reverse(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((63 - lane_id()) << 2, __builtin_bit_cast(int, v)));
 }
+__device__ __forceinline__ float wave_incl_rscan_add(float v) { return wave_reverse(wave_incl_scan_add(wave_reverse(v))); }
 
 // ---- activations with torch semantics ----------------------------------------------
 // nn.Softplus(beta=100, threshold=20): x if 100x>20 else log1p(exp(100x))/100
