@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     }
 
     // ---- phase B: visibility probability = exclusive product scan (:400-412) ------------
+    // the NC per-chunk scans are independent (the carry multiplies afterwards): interleaved DPP steps
     float carry = 1.0f;
+    float qs[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
@@ -213,8 +215,13 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
       const float tn_other = (c + 1 < NC) ? wave_bcast(tcv[(c + 1 < NC) ? c + 1 : c], 0) : 0.f;
       const float tnext = wave_shift_down1(tcv[c], tn_other);
       float vm = (i < S - 1) ? ((tnext < 0.01f) ? 1.0f : 0.0f) : 1.0f;
-      float q = (FULL || i < S) ? (clip01(1.0f - aocc[c] + p.flip_saturation * vm) + 1e-7f) : 1.0f;
-      float inc = wave_incl_scan_mul(q) * carry;
+      qs[c] = (FULL || i < S) ? (clip01(1.0f - aocc[c] + p.flip_saturation * vm) + 1e-7f) : 1.0f;
+    }
+    wave_incl_scan_mul_n<NC>(qs);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = c * 64 + l;
+      const float inc = qs[c] * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
       if (FULL || i < S) {
@@ -234,11 +241,14 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     carry = 1.0f;
     float a_cr = 0, a_cg = 0, a_cb = 0, a_br = 0, a_bg = 0, a_bb = 0, a_depth = 0, a_nx = 0, a_ny = 0, a_nz = 0;
     float a_ws = 0, a_wall = 0;
+    float fs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) fs[c] = (FULL || (c * 64 + l) < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
+    wave_incl_scan_mul_n<NC>(fs);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      const float f = (FULL || i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
-      float inc = wave_incl_scan_mul(f) * carry;
+      const float inc = fs[c] * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
       const float w = (FULL || i < ST) ? alpha[c] * exc : 0.0f;
@@ -252,10 +262,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
         a_nx += w * nx[c]; a_ny += w * ny[c]; a_nz += w * nz[c];
       }
     }
-    a_cr = wave_sum(a_cr); a_cg = wave_sum(a_cg); a_cb = wave_sum(a_cb);
-    a_br = wave_sum(a_br); a_bg = wave_sum(a_bg); a_bb = wave_sum(a_bb);
-    a_depth = wave_sum(a_depth); a_nx = wave_sum(a_nx); a_ny = wave_sum(a_ny); a_nz = wave_sum(a_nz);
-    a_ws = wave_sum(a_ws); a_wall = wave_sum(a_wall);
+    {
+      float r[12] = {a_cr, a_cg, a_cb, a_br, a_bg, a_bb, a_depth, a_nx, a_ny, a_nz, a_ws, a_wall};
+      wave_sum_n<12>(r);
+      a_cr = r[0]; a_cg = r[1]; a_cb = r[2]; a_br = r[3]; a_bg = r[4]; a_bb = r[5];
+      a_depth = r[6]; a_nx = r[7]; a_ny = r[8]; a_nz = r[9]; a_ws = r[10]; a_wall = r[11];
+    }
     if (l == 0) {
       float bgr = 0.f, bgg = 0.f, bgb = 0.f;
       if (p.background_rgb) {  // colour += background_rgb * (1 - weights_sum)  (:527-528)
@@ -273,11 +285,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
   }
 
   // ---- batch-global sums: wave -> block -> one atomic per block ---------------------------
-  s_relax_n = wave_sum(s_relax_n); s_relax_d = wave_sum(s_relax_d);
-  s_near_n = wave_sum(s_near_n); s_near_d = wave_sum(s_near_d); s_sparse = wave_sum(s_sparse);
-  if (l == 0) {
-    red[wave][0] = s_relax_n; red[wave][1] = s_relax_d; red[wave][2] = s_near_n; red[wave][3] = s_near_d;
-    red[wave][4] = s_sparse;
+  {
+    float r[5] = {s_relax_n, s_relax_d, s_near_n, s_near_d, s_sparse};
+    wave_sum_n<5>(r);
+    if (l == 0) {
+      red[wave][0] = r[0]; red[wave][1] = r[1]; red[wave][2] = r[2]; red[wave][3] = r[3]; red[wave][4] = r[4];
+    }
   }
   __syncthreads();
   if (threadIdx.x < 5) {
@@ -411,6 +424,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     }
     // ---- recompute phase B ------------------------------------------------------------------
     float carry = 1.0f;
+    float sc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
@@ -419,7 +433,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       float vm = (i < S - 1) ? ((tnext < 0.01f) ? 1.0f : 0.0f) : 1.0f;
       inner[c] = 1.0f - ps[c].aocc + p.flip_saturation * vm;
       q[c] = (FULL || i < S) ? (clip01(inner[c]) + 1e-7f) : 1.0f;
-      float inc = wave_incl_scan_mul(q[c]) * carry;
+      sc[c] = q[c];
+    }
+    wave_incl_scan_mul_n<NC>(sc);       // the per-chunk scans are independent: interleaved DPP steps
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = c * 64 + l;
+      const float inc = sc[c] * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
       Vraw[c] = exc;
@@ -434,9 +454,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     carry = 1.0f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      f[c] = (FULL || (c * 64 + l) < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
+      sc[c] = f[c];
+    }
+    wave_incl_scan_mul_n<NC>(sc);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
-      f[c] = (FULL || i < ST) ? (1.0f - alpha[c] + 1e-7f) : 1.0f;
-      float inc = wave_incl_scan_mul(f[c]) * carry;
+      const float inc = sc[c] * carry;
       const float exc = wave_shift_up1(inc, carry);
       carry = wave_bcast(inc, 63);
       T[c] = exc;
@@ -472,10 +497,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     //   d f_i = (sum_{j>i} dw_j w_j) / f_i ;  d alpha_i = dw_i T_i - d f_i
     float dalpha[NC];
     float rcarry = 0.0f;
+    float rs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) rs[c] = dw[c] * w[c];
+    wave_incl_rscan_add_n<NC>(rs);
 #pragma unroll
     for (int c = NC - 1; c >= 0; --c) {
       const float v = dw[c] * w[c];
-      float incl = wave_incl_rscan_add(v) + rcarry;  // sum_{j>=i}
+      float incl = rs[c] + rcarry;  // sum_{j>=i}
       float excl = incl - v;                          // sum_{j>i}
       rcarry = wave_bcast(incl, 0);
       dalpha[c] = dw[c] * T[c] - excl * CRCP(f[c]);
@@ -499,10 +528,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     }
     rcarry = 0.0f;
 #pragma unroll
+    for (int c = 0; c < NC; ++c) rs[c] = dV_V[c];
+    wave_incl_rscan_add_n<NC>(rs);
+#pragma unroll
     for (int c = NC - 1; c >= 0; --c) {
       const int i = c * 64 + l;
       const float v = dV_V[c];
-      float incl = wave_incl_rscan_add(v) + rcarry;
+      float incl = rs[c] + rcarry;
       float excl = incl - v;
       rcarry = wave_bcast(incl, 0);
       if (FULL || i < S) {
@@ -584,8 +616,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     }
   }
 
-  d_invs = wave_sum(d_invs); d_beta = wave_sum(d_beta); d_gamma = wave_sum(d_gamma);
-  if (l == 0) { red[wave][0] = d_invs; red[wave][1] = d_beta; red[wave][2] = d_gamma; }
+  {
+    float r[3] = {d_invs, d_beta, d_gamma};
+    wave_sum_n<3>(r);
+    if (l == 0) { red[wave][0] = r[0]; red[wave][1] = r[1]; red[wave][2] = r[2]; }
+  }
   __syncthreads();
   if (threadIdx.x < 3 && g.o_d_scal) {
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
