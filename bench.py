@@ -51,8 +51,10 @@ WORKLOADS = {
 BLEND_WORKLOADS = {"garment_blend_1024x128": dict(color_pixel_weight=0.5, color_patch_weight=0.1)}
 
 
-def cpu_baseline(workload, seconds_budget=25.0):
-    """the oracle's full train step (fwd + loss + bwd + Adam) on the host cores, bounded sample."""
+def cpu_baseline(workload, seconds_budget=15.0, dev=None, precision="fp32"):
+    """the oracle's full train step (fwd + loss + bwd + Adam) on the host cores, bounded sample; and, with `dev`, the
+    second half of BASELINE's metric: PSNR of the HIP path's colours against the oracle's on the same rays and weights
+    (the oracle is the checker here, nothing else)."""
     from neuraludf_amd import synth
     from neuraludf_amd.train import DTU_MODEL_CONF  # noqa: F401
     from oracle import udf_oracle as O
@@ -70,11 +72,26 @@ def cpu_baseline(workload, seconds_budget=25.0):
     nets.beta["zeta"].requires_grad_(False)
     params = [t for d in (nets.udf, nets.color, nets.var, nets.beta, nets.nerf) for t in d.values() if t.requires_grad]
     opt = torch.optim.Adam(params, lr=5e-4)
-    cfg = O.RenderCfg(n_samples=rconf["n_samples"], n_importance=rconf["n_importance"], n_outside=rconf["n_outside"],
-                      up_sample_steps=rconf["up_sample_steps"])
+    cfg = O.RenderCfg(**{k: v for k, v in rconf.items() if k != "perturb"})
     scene = synth.make_scene(scene_kind)
     rays = synth.make_rays(scene, 0, n_rays, seed=1234)
     s_core = rconf["n_samples"] + rconf["n_importance"]
+
+    psnr = None
+    if dev is not None:
+        import math
+        from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
+        g = {k: m.to(dev) for k, m in build_modules(fields, seed=0).items()}      # same seed -> the same weights
+        rend = UDFRendererBlending(g["nerf"], g["udf"], g["var"], g["color"], g["beta"], **rconf)
+        with torch.no_grad():
+            got = rend.render(rays["rays_o"].to(dev), rays["rays_d"].to(dev), rays["near"].to(dev), rays["far"].to(dev),
+                              cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)["color"].cpu()
+            ref = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
+                           flip_saturation=1.0)["color"]
+        mse = float(((got - ref) ** 2).mean())          # exp_runner_blending.py:341-342 with mask = 1
+        psnr = {"value_db": 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-30)), "max_abs_diff": float((got - ref).abs().max()),
+                "rays": n_rays, "samples_per_ray": s_core, "precision": precision,
+                "what": "HIP colours vs oracle colours, identical rays / weights / sample positions"}
 
     def step():
         t_rand = torch.rand(n_rays, 1) - 0.5
@@ -104,15 +121,16 @@ def cpu_baseline(workload, seconds_budget=25.0):
     step()  # warm-up
     times = []
     t_start = time.time()
-    while len(times) < 5 and (time.time() - t_start) < seconds_budget:
+    while len(times) < 40 and (time.time() - t_start) < seconds_budget:
         t0 = time.time()
         step()
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": n_rays * s_core / med, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps "
-                                      f"(oracle/udf_oracle.py, fp32, median {med:.3f} s/step)"}
+    res = {"value": n_rays * s_core / med, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+           "kind": "port", "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps "
+                                     f"(oracle/udf_oracle.py, fp32, median {med:.3f} s/step)"}
+    return res, psnr
 
 
 def main():
@@ -245,7 +263,12 @@ def main():
             result["roofline_composite"] = {"error": repr(ex)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.workload)
+        try:
+            result["cpu_baseline"], psnr = cpu_baseline(args.workload, dev=dev, precision=args.precision)
+            if psnr is not None:
+                result["psnr_vs_ref"] = psnr
+        except Exception as ex:  # pragma: no cover - the GPU numbers above must still be reported
+            result["cpu_baseline"] = {"error": repr(ex)}
 
     if rank == 0:
         print(json.dumps(result))
