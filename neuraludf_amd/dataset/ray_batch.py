@@ -101,6 +101,48 @@ class RayBatchSource:
         px, py = self.draw_pixels(int(img_idx), batch_size, importance_sample, generator)
         return self.rays_at_pixels(int(img_idx), px, py, h_patch_size, crop_patch, with_near_far)
 
+    def gen_random_rays_at(self, img_idx, batch_size, importance_sample=False, generator=None):
+        """dataset.py:196-226: the [N, 10] ray record only (no patches, no uv)."""
+        px, py = self.draw_pixels(int(img_idx), batch_size, importance_sample, generator)
+        return self.rays_at_pixels(int(img_idx), px, py)["rays"]
+
+    # -- whole-image rays for validation / novel views (not per-iteration: plain device tensor ops) ----------------
+    def _pixel_dirs(self, cam_idx, resolution_level):
+        l = resolution_level
+        tx = torch.linspace(0, self.W - 1, self.W // l, device=self.device)
+        ty = torch.linspace(0, self.H - 1, self.H // l, device=self.device)
+        pixels_x, pixels_y = torch.meshgrid(tx, ty, indexing="ij")
+        p = torch.stack([pixels_x, pixels_y, torch.ones_like(pixels_y)], dim=-1)             # W, H, 3
+        p = torch.matmul(self.intrinsics_all_inv[cam_idx, None, None, :3, :3], p[:, :, :, None]).squeeze(-1)
+        return p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+
+    def gen_rays_at(self, img_idx, resolution_level=1):
+        """dataset.py:151-164 -> (rays_o, rays_v), each [H // l, W // l, 3]."""
+        v = self._pixel_dirs(img_idx, resolution_level)
+        rays_v = torch.matmul(self.pose_all[img_idx, None, None, :3, :3], v[:, :, :, None]).squeeze(-1)
+        rays_o = self.pose_all[img_idx, None, None, :3, 3].expand(rays_v.shape)
+        return rays_o.transpose(0, 1), rays_v.transpose(0, 1)
+
+    def gen_rays_between(self, idx_0, idx_1, ratio, resolution_level=1):
+        """dataset.py:296-327: camera interpolated between two views (rotation slerp of the world-to-camera
+        rotations, linear translation), intrinsics of view 0."""
+        import numpy as np
+        from scipy.spatial.transform import Rotation as Rot
+        from scipy.spatial.transform import Slerp
+        v = self._pixel_dirs(0, resolution_level)
+        pose_0 = np.linalg.inv(self.pose_all[idx_0].detach().cpu().numpy())
+        pose_1 = np.linalg.inv(self.pose_all[idx_1].detach().cpu().numpy())
+        rot = Slerp([0, 1], Rot.from_matrix(np.stack([pose_0[:3, :3], pose_1[:3, :3]])))(ratio)
+        pose = np.diag([1.0, 1.0, 1.0, 1.0]).astype(np.float32)
+        pose[:3, :3] = rot.as_matrix()
+        pose[:3, 3] = ((1.0 - ratio) * pose_0 + ratio * pose_1)[:3, 3]
+        pose = np.linalg.inv(pose)
+        rot_t = torch.from_numpy(pose[:3, :3]).to(self.device)
+        trans = torch.from_numpy(pose[:3, 3]).to(self.device)
+        rays_v = torch.matmul(rot_t[None, None, :3, :3], v[:, :, :, None]).squeeze(-1)
+        rays_o = trans[None, None, :3].expand(rays_v.shape)
+        return rays_o.transpose(0, 1), rays_v.transpose(0, 1)
+
     def near_far_from_sphere(self, rays_o, rays_d):
         """dataset.py:329-335 on already generated rays (the fused path is ``with_near_far=True``)."""
         a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)

@@ -83,6 +83,23 @@ def main():
             if v is not None:
                 out[f"{name}.{k}"] = v.numpy()
         out[f"{name}.near"], out[f"{name}.far"] = near.numpy(), far.numpy()
+    ro, rv = ds.gen_rays_at(2, resolution_level=4)
+    out["rays_at.o"], out["rays_at.v"] = ro.contiguous().numpy(), rv.contiguous().numpy()
+    ro, rv = ds.gen_rays_between(1, 3, 0.3, resolution_level=8)
+    out["rays_between.o"], out["rays_between.v"] = ro.contiguous().numpy(), rv.contiguous().numpy()
+    draws = []
+
+    def rec2(*a, **k):
+        t = real_randint(*a, **k)
+        draws.append(t.clone())
+        return t
+    torch.manual_seed(3)
+    torch.randint = rec2
+    try:
+        out["random_rays_at"] = ds.gen_random_rays_at(3, 40).numpy()
+    finally:
+        torch.randint = real_randint
+    out["random_rays_at.px"], out["random_rays_at.py"] = draws[0].numpy(), draws[1].numpy()
     ds.ref_src_pair = None
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):

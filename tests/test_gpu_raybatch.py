@@ -125,3 +125,21 @@ def test_training_iterations_from_generated_batches():
         lrs = [g_["lr"] for g_ in tr.optimizer.param_groups]
         assert lrs[1] == pytest.approx(5e-4 * 601 / 5000) and lrs[0] == pytest.approx(1e-4 * 601 / 10000)
         assert not torch.equal(w0, tr.color.state_dict()["lin_base0.weight_v"])
+
+
+def test_whole_image_rays_match_reference():
+    """gen_rays_at / gen_rays_between / gen_random_rays_at against the reference Dataset's own output."""
+    g = load_gold()
+    src = source(g)
+    ro, rv = src.gen_rays_at(2, resolution_level=4)
+    assert ro.shape == (src.H // 4, src.W // 4, 3)
+    np.testing.assert_allclose(ro.cpu().numpy(), g["rays_at.o"], atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), g["rays_at.v"], atol=5e-6)
+    ro, rv = src.gen_rays_between(1, 3, 0.3, resolution_level=8)
+    np.testing.assert_allclose(ro.cpu().numpy(), g["rays_between.o"], atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), g["rays_between.v"], atol=1e-5)
+    rays = src.rays_at_pixels(3, torch.from_numpy(g["random_rays_at.px"]), torch.from_numpy(g["random_rays_at.py"]))["rays"]
+    ref = g["random_rays_at"]
+    np.testing.assert_array_equal(rays.cpu().numpy()[:, [0, 1, 2, 6, 7, 8, 9]], ref[:, [0, 1, 2, 6, 7, 8, 9]])
+    np.testing.assert_allclose(rays.cpu().numpy()[:, 3:6], ref[:, 3:6], atol=5e-6)
+    assert src.gen_random_rays_at(3, 40).shape == (40, 10)

@@ -58,3 +58,22 @@ def test_patch_offsets_and_border():
     assert s["rays_patch_color"][0, 0].max() == 0.0 and s["rays_patch_color"][1, -1].max() == 0.0
     # centre tap of the corner pixel: align_corners=False puts it at (-0.5, -0.5) -> one quarter of the 2x2 footprint
     assert abs(s["rays_patch_color"][0, 12, 0] - 0.25) < 1e-6
+
+
+def test_whole_image_rays_host_logic():
+    """gen_rays_at / gen_rays_between are plain tensor code (validation views, not per iteration): checked on the host
+    against the reference Dataset's output; the per-iteration batch itself has no host path."""
+    import torch
+    from neuraludf_amd.dataset import RayBatchSource
+    g = load_gold()
+    src = RayBatchSource(g["images"], g["masks"], g["intrinsics_all"], g["pose_all"], device="cpu")
+    ro, rv = src.gen_rays_at(2, resolution_level=4)
+    np.testing.assert_allclose(ro.numpy(), g["rays_at.o"], atol=1e-6)
+    np.testing.assert_allclose(rv.numpy(), g["rays_at.v"], atol=5e-6)
+    ro, rv = src.gen_rays_between(1, 3, 0.3, resolution_level=8)
+    np.testing.assert_allclose(ro.numpy(), g["rays_between.o"], atol=1e-5)
+    np.testing.assert_allclose(rv.numpy(), g["rays_between.v"], atol=1e-5)
+    with pytest.raises(RuntimeError):
+        src.gen_random_rays_patches_at(0, 8)
+    n, f = src.near_far_from_sphere(torch.from_numpy(g["plain.rays"][:, :3]), torch.from_numpy(g["plain.rays"][:, 3:6]))
+    np.testing.assert_allclose(n.numpy(), g["plain.near"], atol=1e-5)
