@@ -231,6 +231,24 @@ def main():
                    "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam"},
     }
 
+    # ---- forward only ("also forward-only ray-samples/s"): the same batch rendered without autograd, all
+    # ranks (the ray-sharded render holds a collective), same bracketing
+    with torch.no_grad():
+        for _ in range(2):
+            tr.loss(batch, **({"blend": step_kw["blend"]} if step_kw else {}))
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.loss(batch, **({"blend": step_kw["blend"]} if step_kw else {}))
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t0) / args.steps
+    result["forward_only"] = {"value": world * rays_per_gpu * s_core / dtf, "unit": "ray-samples/s", "ms": dtf * 1e3,
+                              "what": "render + loss under no_grad, rank-local clock"}
+
     if not args.no_roofline:
         # ---- one instrumented step: HIP events around every GEMM launch on the launch stream.  EVERY rank takes
         # the step (it contains the data-parallel collectives); only rank 0 records and reports. ----

@@ -127,3 +127,21 @@ class Trainer:
         loss, out = self.step(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
                               blend=blend)
         return loss, out, s
+
+    @torch.no_grad()
+    def render_image(self, source, img_idx, resolution_level=4, chunk=65536, cos_anneal_ratio=1.0):
+        """validation render of one view (the loop of exp_runner_blending.py:506-560 without the file output): whole-image
+        rays from the source, rendered in chunks of `chunk` rays -- large chunks, the renderer's working set at 65 536
+        rays x 146 samples is a few GB of the 288 GB -- -> dict(color [H', W', 3], depth [H', W'], normals [H', W', 3])."""
+        rays_o, rays_d = source.gen_rays_at(img_idx, resolution_level=resolution_level)
+        Hh, Ww, _ = rays_o.shape
+        rays_o, rays_d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+        outs = {"color": [], "depth": [], "normals": []}
+        for i in range(0, rays_o.shape[0], chunk):
+            o, d = rays_o[i:i + chunk], rays_d[i:i + chunk]
+            near, far = source.near_far_from_sphere(o, d)
+            r = self.renderer.render(o, d, near, far, cos_anneal_ratio=cos_anneal_ratio, perturb_overwrite=0,
+                                     flip_saturation=1.0)
+            outs["color"].append(r["color"]); outs["depth"].append(r["depth"].reshape(-1)); outs["normals"].append(r["normals"])
+        return {"color": torch.cat(outs["color"]).reshape(Hh, Ww, 3), "depth": torch.cat(outs["depth"]).reshape(Hh, Ww),
+                "normals": torch.cat(outs["normals"]).reshape(Hh, Ww, 3)}

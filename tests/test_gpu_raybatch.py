@@ -143,3 +143,17 @@ def test_whole_image_rays_match_reference():
     np.testing.assert_array_equal(rays.cpu().numpy()[:, [0, 1, 2, 6, 7, 8, 9]], ref[:, [0, 1, 2, 6, 7, 8, 9]])
     np.testing.assert_allclose(rays.cpu().numpy()[:, 3:6], ref[:, 3:6], atol=5e-6)
     assert src.gen_random_rays_at(3, 40).shape == (40, 10)
+
+
+def test_render_image_chunking_is_exact():
+    """a validation view rendered in one chunk and in ragged chunks gives the same image (rays are independent)."""
+    from neuraludf_amd.train import Trainer
+    g = load_gold()
+    src = source(g)
+    tr = Trainer(torch.device("cuda"), dict(n_samples=16, n_importance=8, n_outside=4, up_sample_steps=2, perturb=0.0), seed=0)
+    a = tr.render_image(src, 1, resolution_level=4, chunk=1 << 20)
+    b = tr.render_image(src, 1, resolution_level=4, chunk=100)
+    assert a["color"].shape == (src.H // 4, src.W // 4, 3) and a["depth"].shape == (src.H // 4, src.W // 4)
+    for k in a:
+        assert torch.isfinite(a[k]).all()
+        assert float((a[k] - b[k]).abs().max()) < 1e-5, k
