@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--rays-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the extra forward-only timing (profiling runs)")
     ap.add_argument("--fused-adam", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "mixed16"],
                     help="fp32 = the parity path and the headline; mixed16 = BASELINE config 5 (16-bit MFMA operands, "
@@ -234,20 +235,21 @@ def main():
     # ---- forward only ("also forward-only ray-samples/s"): the same batch rendered without autograd, all
     # ranks (the ray-sharded render holds a collective), same bracketing
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(0 if args.no_forward_only else 2):
             tr.loss(batch, **({"blend": step_kw["blend"]} if step_kw else {}))
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(0 if args.no_forward_only else args.steps):
             tr.loss(batch, **({"blend": step_kw["blend"]} if step_kw else {}))
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         dtf = (time.perf_counter() - t0) / args.steps
-    result["forward_only"] = {"value": world * rays_per_gpu * s_core / dtf, "unit": "ray-samples/s", "ms": dtf * 1e3,
-                              "what": "render + loss under no_grad, rank-local clock"}
+    if not args.no_forward_only:
+        result["forward_only"] = {"value": world * rays_per_gpu * s_core / dtf, "unit": "ray-samples/s", "ms": dtf * 1e3,
+                                  "what": "render + loss under no_grad, rank-local clock"}
 
     if not args.no_roofline:
         # ---- one instrumented step: HIP events around every GEMM launch on the launch stream.  EVERY rank takes

@@ -11,7 +11,7 @@ timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "s
 timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -n 3 gpurun_out/bench.log
 if [ "${NUDF_PROFILE:-1}" = "1" ]; then
   rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/prof/run.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-forward-only > $GRAFT_REPO_ROOT/gpurun_out/prof/run.log 2>&1)
   find gpurun_out/prof -name "*kernel_stats*" | head -3
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" | cut -c1-200
   find gpurun_out/prof -name "*kernel_trace.csv" -size +1M -delete

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof && mkdir -p $R/gpurun_out/prof
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline "$@" > $R/gpurun_out/prof/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-forward-only "$@" > $R/gpurun_out/prof/run.log 2>&1
 f=$(find $R/gpurun_out/prof -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
