@@ -65,11 +65,13 @@ class GradBucket:
     def all_reduce(self):
         if world_size() == 1 or not self.params:
             return
-        grads = []
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            grads.append(p.grad)
+        # parameters that took no part in this step (e.g. the background NeRF when n_outside = 0: 0.6 M of the
+        # 1.29 M floats) have grad None on EVERY rank -- the ranks run the same graph on their ray shards -- and
+        # stay out of the message; Adam skips them exactly as in the single-process step
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        grads = [p.grad for p in live]
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split(self.sizes), grads)])
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
