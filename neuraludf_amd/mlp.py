@@ -1013,6 +1013,70 @@ class ColorEngine:
         return unpack_group(self.view + self.base, gv + gb), dCIN[:P]
 
 
+class PlainColorEngine:
+    """RenderingNetwork (fields.py:325-397): one ReLU chain over an input assembled by the caller, sigmoid colour head
+    (+ raw blending logits).  Not instantiated by any shipped conf (the runner uses the residual variant), so it runs on
+    the per-layer GEMM launches: any input width / mode, no fused chain."""
+
+    def __init__(self, net):
+        self.net = net
+        self.layers = [PackedLinear(getattr(net, f"lin{l}")) for l in range(net.num_layers - 1)]
+        self.dout = net.d_out
+
+    def params(self):
+        out = []
+        for pl in self.layers:
+            out += pl.params()
+        return out
+
+    def forward(self, Xin, P, keep_state=True):
+        """Xin [P, width] -> (out [P, last.out] with the first d_out columns through the sigmoid when squeeze_out)."""
+        dev, n = Xin.device, len(self.layers)
+        pack_group(self.layers)
+        X = _buf(P, self.layers[0].inp, dev)
+        X[:P, :Xin.shape[1]] = Xin
+        H = [X]
+        for l in range(n - 1):
+            pl = self.layers[l]
+            h = _buf(P, pl.out, dev)
+            gemm_nn(H[l], pl.Wt, P, pl.out, pl.in_pad, "RELU", C1=h, bias=pl.bias)
+            H.append(h)
+        pl = self.layers[n - 1]
+        nb = pl.out - self.dout
+        color = torch.empty(P, self.dout, device=dev)
+        logits = torch.empty(P, max(nb, 1), device=dev)
+        if self.net.squeeze_out:
+            gemm_nn(H[n - 1], pl.Wt, P, pl.out, pl.in_pad, "SIGMOID", C1=color, C3=logits, bias=pl.bias, iparam=self.dout)
+        else:
+            raw = _buf(P, pl.out, dev)
+            gemm_nn(H[n - 1], pl.Wt, P, pl.out, pl.in_pad, "NONE", C1=raw, bias=pl.bias)
+            color, logits = raw[:P, :self.dout].contiguous(), raw[:P, self.dout:pl.out].contiguous()
+        st = dict(H=H, P=P) if keep_state else None
+        return color, (logits if nb > 0 else None), st
+
+    def backward(self, st, color, d_color, d_logits):
+        """-> (param grads in params() order, d Xin [P, width])."""
+        P, H = st["P"], st["H"]
+        dev = color.device
+        pl = self.layers[-1]
+        nb = pl.out - self.dout
+        D = _buf(P, pl.out, dev, zero=True)
+        if self.net.squeeze_out:
+            if d_color is None:
+                d_color = torch.zeros_like(color)
+            if nb > 0 and d_logits is None:
+                d_logits = torch.zeros(P, nb, device=dev)
+            call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color.contiguous()), None, 0, self.dout,
+                 ptr(d_logits.contiguous()) if nb > 0 else None, max(nb, 1), nb, P, ptr(D), D.shape[1])
+        else:
+            if d_color is not None:
+                D[:P, :self.dout] = d_color
+            if nb > 0 and d_logits is not None:
+                D[:P, self.dout:pl.out] = d_logits
+        grads, dX = relu_chain_bwd(self.layers, H, H[1:], D, P, True)
+        return unpack_group(self.layers, grads), dX[:P, :self.layers[0].inp]
+
+
 class NerfEngine:
     """Background NeRF with view directions (fields.py:541-628)."""
 

@@ -232,7 +232,64 @@ class ResidualRenderingNetwork(nn.Module):
         return cb, col
 
 
-RenderingNetwork = ResidualRenderingNetwork   # north-star name; the runner instantiates the residual variant
+class _PlainColorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, X, *params):
+        ctx.set_materialize_grads(False)
+        need = any(ctx.needs_input_grad)
+        color, logits, st = engine.forward(X.detach().float().contiguous(), X.shape[0], keep_state=need)
+        ctx.engine, ctx.st = engine, st
+        ctx.save_for_backward(color)
+        if logits is None:
+            logits = color.new_zeros(0)
+        return color, logits
+
+    @staticmethod
+    def backward(ctx, d_color, d_logits):
+        (color,) = ctx.saved_tensors
+        if d_logits is not None and d_logits.numel() == 0:
+            d_logits = None
+        grads, dX = ctx.engine.backward(ctx.st, color, d_color, d_logits)
+        ctx.st = None
+        return (None, dX) + tuple(grads)
+
+
+class RenderingNetwork(nn.Module):
+    """fields.py:325-397: the plain (NeuS-style) colour MLP.  The runner instantiates ResidualRenderingNetwork; this
+    class keeps the reference name, constructor, state_dict and forward() contract for the three modes."""
+
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=0,
+                 squeeze_out=True, blending_cand_views=0):
+        super().__init__()
+        self.mode, self.squeeze_out, self.d_out = mode, squeeze_out, d_out
+        dims = [d_in + d_feature] + [d_hidden for _ in range(n_layers)] + [d_out + blending_cand_views]
+        self.embedview_fn = None
+        if multires_view > 0 and self.mode != 'no_view_dir':
+            self.embedview_fn, input_ch = get_embedder(multires_view)
+            dims[0] += (input_ch - 3)
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            setattr(self, "lin" + str(l), _wn(nn.Linear(dims[l], dims[l + 1]), weight_norm))
+        self.relu = nn.ReLU()
+        self.if_blending = blending_cand_views > 0
+        self._engine = None
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        if self._engine is None:
+            self._engine = mlp.PlainColorEngine(self)
+        if self.embedview_fn is not None:
+            view_dirs = self.embedview_fn(view_dirs)
+        normals = normals.detach() if normals is not None else None
+        if self.mode == 'idr':
+            x = torch.cat([points, view_dirs, normals, -1 * normals, feature_vectors], dim=-1)
+        elif self.mode == 'no_view_dir':
+            x = torch.cat([points, normals, -1 * normals, feature_vectors], dim=-1)
+        elif self.mode == 'no_normal':
+            x = torch.cat([points, view_dirs, feature_vectors], dim=-1)
+        else:
+            raise ValueError("unknown RenderingNetwork mode %r" % (self.mode,))
+        color, logits = _PlainColorFn.apply(self._engine, x, *self._engine.params())
+        return (color, logits) if self.if_blending else color
 
 
 # ------------------------------------------------------------------------------------------

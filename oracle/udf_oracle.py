@@ -197,6 +197,27 @@ def color_forward(sd: SD, pts: Tensor, normals: Tensor, dirs: Tensor, feat: Tens
     return color_base, color, x[:, cfg.d_out:]
 
 
+def rendering_forward(sd: SD, pts: Tensor, normals: Tensor, dirs: Tensor, feat: Tensor, mode: str = "idr",
+                      multires_view: int = 4, d_out: int = 3, squeeze_out: bool = True):
+    """RenderingNetwork.forward (fields.py:364-397), the plain colour MLP -> (color [P,d_out], extra columns)."""
+    vd = posenc(dirs, multires_view) if (multires_view > 0 and mode != "no_view_dir") else dirs
+    n = normals.detach() if normals is not None else None
+    if mode == "idr":
+        x = torch.cat([pts, vd, n, -1 * n, feat], -1)
+    elif mode == "no_view_dir":
+        x = torch.cat([pts, n, -1 * n, feat], -1)
+    else:
+        x = torch.cat([pts, vd, feat], -1)
+    n_lin = len([k for k in sd if k.endswith(".bias")])
+    for l in range(n_lin):
+        w = wn_weight(sd, f"lin{l}") if f"lin{l}.weight_g" in sd else sd[f"lin{l}.weight"]
+        x = F.linear(x, w, sd[f"lin{l}.bias"])
+        if l < n_lin - 1:
+            x = F.relu(x)
+    color = torch.sigmoid(x[:, :d_out]) if squeeze_out else x[:, :d_out]
+    return color, x[:, d_out:]
+
+
 # --------------------------------------------------------------------------- #
 # background NeRF                            models/fields.py:541-642
 # --------------------------------------------------------------------------- #

@@ -531,3 +531,42 @@ def test_color_loss_sharded_split_matches_fused(dev, with_mask):
     assert torch.equal(o0, o1) and torch.equal(d0, d1)
     o2, d2 = finish(sums_of(0, n // 2) + sums_of(n // 2, n))
     assert rel(o2, o0) < 1e-6 and rel(d2, d0) < 1e-6
+
+
+@pytest.mark.parametrize("case", [dict(mode="idr", d_in=12, multires_view=4, squeeze_out=True, blending_cand_views=0),
+                                  dict(mode="no_normal", d_in=6, multires_view=4, squeeze_out=True, blending_cand_views=10),
+                                  dict(mode="no_view_dir", d_in=9, multires_view=0, squeeze_out=False, blending_cand_views=0)],
+                         ids=["idr", "no_normal", "no_view_dir"])
+def test_plain_rendering_network(dev, case):
+    """RenderingNetwork (fields.py:325-397, the non-residual colour MLP; importable name of the call surface) on the
+    per-layer HIP GEMMs against the oracle: values, d feature, parameter gradients, all three modes."""
+    from neuraludf_amd.models import fields as nf
+    torch.manual_seed(5)
+    net = nf.RenderingNetwork(d_feature=256, d_out=3, d_hidden=96, n_layers=3, weight_norm=True, **case)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    P = 333
+    pts, nrm, dirs = (torch.randn(P, 3, generator=g) for _ in range(3))
+    feat = torch.randn(P, 256, generator=g)
+    fr = feat.clone().requires_grad_(True)
+    color, extra = O.rendering_forward(sd, pts, nrm, dirs, fr, mode=case["mode"], multires_view=case["multires_view"],
+                                       squeeze_out=case["squeeze_out"])
+    w1, w2 = torch.randn(P, 3, generator=g), torch.randn(P, max(extra.shape[1], 1), generator=g)
+    loss = (color * w1).sum() + ((extra * w2).sum() if extra.shape[1] else 0.0)
+    loss.backward()
+    net.to(dev)
+    fd = feat.to(dev).requires_grad_(True)
+    out = net(pts.to(dev), nrm.to(dev), dirs.to(dev), fd)
+    if case["blending_cand_views"] > 0:
+        c2, e2 = out
+        assert rel(e2, extra) < VTOL
+        l2 = (c2 * w1.to(dev)).sum() + (e2 * w2.to(dev)).sum()
+    else:
+        c2 = out
+        l2 = (c2 * w1.to(dev)).sum()
+    assert rel(c2, color) < VTOL
+    l2.backward()
+    # unsquashed outputs (squeeze_out=False) give O(10) gradients: 2x the usual bound on the max-normalised error
+    assert rel(fd.grad, fr.grad) < 2 * GTOL
+    for n, p in net.named_parameters():
+        assert rel(p.grad, sd[n].grad) < 2 * GTOL, n
