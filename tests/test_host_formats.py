@@ -180,3 +180,26 @@ def test_checkpoint_interchange_with_reference_modules(tmp_path):
                               is_finetune=True) == 0
     assert torch.equal(ref2["udf"].state_dict()["lin3.weight_v"], ref["udf"].state_dict()["lin3.weight_v"])
     assert ck.latest_checkpoint(str(tmp_path)) == "ckpt_002000.pth"
+
+
+def test_dropin_aliases_resolve_the_runner_imports():
+    """the import lines of exp_runner_blending.py:15-21 resolve to the drop-in classes after dropin.install()
+    (in a subprocess: the aliases must not leak into this test session)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import neuraludf_amd.dropin as d; d.install()\n"
+        "from models.fields import ResidualRenderingNetwork, SDFNetwork, UDFNetwork, BetaNetwork\n"
+        "from models.fields import SingleVarianceNetwork, NeRF, RenderingNetwork\n"
+        "from models.udf_renderer_blending import UDFRendererBlending, extract_fields, extract_gradient_fields\n"
+        "from loss.loss import ColorLoss\n"
+        "import models.embedder, models.patch_projector, loss.patch_metric\n"
+        "assert UDFNetwork.__module__ == 'neuraludf_amd.models.fields', UDFNetwork.__module__\n"
+        "assert UDFRendererBlending.__module__ == 'neuraludf_amd.models.udf_renderer_blending'\n"
+        "assert ColorLoss.__module__ == 'neuraludf_amd.loss.loss'\n"
+        "d.uninstall(); assert 'models.fields' not in sys.modules\n"
+        "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
