@@ -203,3 +203,39 @@ def test_dropin_aliases_resolve_the_runner_imports():
         "print('ok')\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_reference_runner_imports_through_the_dropin():
+    """the UNCHANGED reference runner (exp_runner_blending.py) imports with its `models.*` / `loss.*` lines bound to
+    the drop-in classes; its third-party imports that are absent from this image are stubbed.  Build container only."""
+    import subprocess
+    import sys
+    from refload import have_reference
+    if not have_reference():
+        pytest.skip("reference tree not present")
+    root = os.path.dirname(HERE)
+    code = f"""
+import sys, types
+sys.path.insert(0, {root!r}); sys.path.insert(0, '/root/reference')
+for name in ["cv2", "trimesh", "pyhocon", "icecream", "termcolor", "h5py", "mcubes", "skimage", "skimage.measure",
+             "tensorboard", "torch.utils.tensorboard", "custom_mc", "custom_mc._marching_cubes_lewiner"]:
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["icecream"].ic = lambda *a, **k: None
+sys.modules["termcolor"].colored = lambda s, *a, **k: s
+sys.modules["pyhocon"].ConfigFactory = object; sys.modules["pyhocon"].HOCONConverter = object
+sys.modules["torch.utils.tensorboard"].SummaryWriter = object
+sys.modules["custom_mc._marching_cubes_lewiner"].udf_mc_lewiner = None
+import neuraludf_amd.dropin as d
+d.install()
+import exp_runner_blending as r
+assert r.__file__.startswith('/root/reference/')
+for name in ("ResidualRenderingNetwork", "SDFNetwork", "UDFNetwork", "BetaNetwork", "SingleVarianceNetwork", "NeRF"):
+    assert getattr(r, name).__module__ == "neuraludf_amd.models.fields", name
+assert r.UDFRendererBlending.__module__ == "neuraludf_amd.models.udf_renderer_blending"
+assert r.extract_fields.__module__ == "neuraludf_amd.models.udf_renderer_blending"
+assert r.ColorLoss.__module__ == "neuraludf_amd.loss.loss"
+assert r.Dataset.__module__ == "dataset.dataset"          # the rest of the reference is untouched
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
