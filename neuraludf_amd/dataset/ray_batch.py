@@ -40,6 +40,30 @@ class RayBatchSource:
             self.masks = torch.ones_like(self.images)                                    # dataset.py:86-88
         self._valid = {}
 
+    @classmethod
+    def from_idr(cls, camera_dict, images, masks=None, object_camera_dict=None, downsample_factor=1.0, device="cuda"):
+        """the numeric part of Dataset.__init__ (dataset.py:59-127): `camera_dict` = the loaded `cameras*.npz`
+        (`world_mat_i`, `scale_mat_i`), `images` / `masks` = the decoded [n, H, W, 3] arrays already divided by 256
+        (decoding with cv2 / PIL stays the caller's job).  Also sets scale_mats_np and object_bbox_min / _max."""
+        import numpy as np
+        from . import cameras
+        n = len(images)
+        intr, poses, scale_mats = cameras.load_idr_cameras(camera_dict, n, downsample_factor)
+        self = cls(images, masks, intr, poses, device=device)
+        if downsample_factor != 1:              # dataset.py:99-108
+            import torch.nn.functional as F
+            def rs(t):
+                return F.interpolate(t.permute(0, 3, 1, 2).contiguous(), size=None, scale_factor=downsample_factor,
+                                     mode="bilinear").permute(0, 2, 3, 1).contiguous()
+            self.images, self.masks = rs(self.images), rs(self.masks)
+            self.H, self.W = self.images.shape[1], self.images.shape[2]
+        self.scale_mats_np = scale_mats
+        obj = np.asarray((object_camera_dict or camera_dict)["scale_mat_0"])
+        self.object_bbox_min, self.object_bbox_max = cameras.object_bbox(scale_mats[0], obj)
+        self.focal = self.intrinsics_all[0][0, 0]
+        self.prepare_ref_src_pairs()
+        return self
+
     # -- pixel draws: torch's generator, same call order as dataset.py:235-252 -------------------------------------
     def _valid_pixels(self, img_idx: int) -> torch.Tensor:
         v = self._valid.get(img_idx)

@@ -77,3 +77,23 @@ def test_whole_image_rays_host_logic():
         src.gen_random_rays_patches_at(0, 8)
     n, f = src.near_far_from_sphere(torch.from_numpy(g["plain.rays"][:, :3]), torch.from_numpy(g["plain.rays"][:, 3:6]))
     np.testing.assert_allclose(n.numpy(), g["plain.near"], atol=1e-5)
+
+
+def test_from_idr_builds_the_dataset_tensors():
+    """RayBatchSource.from_idr = Dataset.__init__'s numeric part: P = world_mat @ scale_mat decomposed (no OpenCV),
+    bounding box, neighbour pairs; on the host (no kernels involved)."""
+    from neuraludf_amd.dataset import RayBatchSource
+    g = load_gold()
+    n = g["images"].shape[0]
+    cam = {}
+    for i in range(n):
+        K, c2w = g["intrinsics_all"][i].astype(np.float64), g["pose_all"][i].astype(np.float64)
+        w2c = np.linalg.inv(c2w)
+        S = np.diag([2.0, 2.0, 2.0, 1.0]); S[:3, 3] = [0.1, -0.2, 0.3]
+        P = np.eye(4); P[:3, :4] = (K @ w2c)[:3, :4]
+        cam[f"world_mat_{i}"], cam[f"scale_mat_{i}"] = P @ np.linalg.inv(S), S        # so that world_mat @ scale_mat = K [R|t]
+    src = RayBatchSource.from_idr(cam, g["images"], g["masks"], device="cpu")
+    np.testing.assert_allclose(src.intrinsics_all.numpy()[:, :3, :3], g["intrinsics_all"][:, :3, :3], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(src.pose_all.numpy(), g["pose_all"], atol=2e-4)
+    np.testing.assert_allclose(src.object_bbox_min, [-1.01] * 3, atol=1e-9)
+    assert len(src.ref_src_pair) == n and len(src.scale_mats_np) == n
