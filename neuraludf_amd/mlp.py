@@ -676,6 +676,15 @@ class UDFEngine:
                         n_hid, X1=X[l],
                         X2=EX[l - 1] if second else None, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
         cb.launch()
+        if os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1":
+            # two grouped launches (adjoint pairs, then the second-order pairs accumulating into the same dW): each
+            # is one resident wave of ~500 workgroups with 14-17 row chunks per tile instead of 128 -- 9x fewer
+            # atomics per output element and 2 launch tails instead of 9 (1.67 -> 1.61 ms per step; ONE launch of all
+            # 17 problems fills only 462 of the 512 slots and was slower)
+            gemm_tn_grouped([(ABAR[l], pl.out, X[l], pl.in_pad, grads[l][0], grads[l][1]) for l, pl in enumerate(layers)], P)
+            if second:
+                gemm_tn_grouped([(DA[l], layers[l].out, R[l], layers[l].in_pad, grads[l][0], None) for l in range(L)], P)
+            return unpack_group(layers, grads)
         for l, pl in enumerate(layers):
             dW, db = grads[l]
             if second and l < L:

@@ -541,7 +541,9 @@ def test_plain_rendering_network(dev, case):
     """RenderingNetwork (fields.py:325-397, the non-residual colour MLP; importable name of the call surface) on the
     per-layer HIP GEMMs against the oracle: values, d feature, parameter gradients, all three modes."""
     from neuraludf_amd.models import fields as nf
-    torch.manual_seed(5)
+    # seed 6: with seed 5 one of the 96 k hidden pre-activations sits within fp32 rounding of the ReLU kink, so the two
+    # implementations take different sides there and one unit's whole adjoint differs (scripts/debug_plain.py)
+    torch.manual_seed(6)
     net = nf.RenderingNetwork(d_feature=256, d_out=3, d_hidden=96, n_layers=3, weight_norm=True, **case)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     g = torch.Generator().manual_seed(2)
@@ -566,7 +568,6 @@ def test_plain_rendering_network(dev, case):
         l2 = (c2 * w1.to(dev)).sum()
     assert rel(c2, color) < VTOL
     l2.backward()
-    # unsquashed outputs (squeeze_out=False) give O(10) gradients: 2x the usual bound on the max-normalised error
-    assert rel(fd.grad, fr.grad) < 2 * GTOL
+    assert rel(fd.grad, fr.grad) < GTOL
     for n, p in net.named_parameters():
-        assert rel(p.grad, sd[n].grad) < 2 * GTOL, n
+        assert rel(p.grad, sd[n].grad) < GTOL, n
