@@ -344,7 +344,10 @@ __device__ __forceinline__ void gemm_tn_body(const NudfGemmTN& p, float* smem, i
   const bool actj0 = (j0 + wn * 64) < p.NB;
   const bool actj1 = (j0 + wn * 64 + 32) < p.NB;
   const bool acti1 = (i0 + wm * 64 + 32) < p.NA;
-  const bool do_bias = (p.dbias != nullptr) && (j0 == 0) && (tid < BM);
+  // bias gradient = column sums of A: all 256 threads take part (thread -> column tid % 128, row half tid / 128), so
+  // the four waves stay balanced between the barriers (two waves doing all 32 rows held the other two up)
+  const bool do_bias = (p.dbias != nullptr) && (j0 == 0);
+  const int b_col = tid & (BM - 1), b_half = tid / BM;
   float bsum = 0.0f;
 
   if (nk > 0) {
@@ -395,15 +398,15 @@ __device__ __forceinline__ void gemm_tn_body(const NudfGemmTN& p, float* smem, i
     else if (ni == 1 && nj == 1) mma_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cur);
     __builtin_amdgcn_sched_barrier(0);
     if (do_bias && kt < nk1) {  // column sums of the first pair's A (bias gradient)
-      const float* as = As + cur * T_TILE + tid;
+      const float* as = As + cur * T_TILE + b_col + b_half * (BK / 2) * LDT_S;
 #pragma unroll
-      for (int k = 0; k < BK; ++k) bsum += as[k * LDT_S];
+      for (int k = 0; k < BK / 2; ++k) bsum += as[k * LDT_S];
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
 
-  if (do_bias && (i0 + tid) < p.NA) atomicAdd(p.dbias + i0 + tid, bsum);
+  if (do_bias && (i0 + b_col) < p.NA) atomicAdd(p.dbias + i0 + b_col, bsum);
   if (!(acti && actj0)) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
