@@ -71,6 +71,8 @@ typedef struct NudfGemmTN {
   float* dbias;                                 /* [NA] += column sums of A1, or NULL     */
   int32_t M, NA, NB;
   int32_t rows_per_block;                       /* 0 = choose                             */
+  int32_t prec;                                 /* MFMA operand precision: 0 = fp32 (exact), 2 = bf16 operands converted
+                                                   from the fp32 tiles on the fly, fp32 accumulate (config-5 mode)   */
 } NudfGemmTN;
 
 /* C[NA,NB] += A1^T B1 (+ A2^T B2): weight gradients, reduction over the M points */
@@ -86,6 +88,7 @@ typedef struct NudfGemmTNProblem {
 } NudfGemmTNProblem;
 typedef struct NudfGemmTNGroup {
   int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
+  int32_t prec;                                 /* as NudfGemmTN.prec                     */
   NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
 } NudfGemmTNGroup;
 int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);

@@ -33,7 +33,7 @@ class GemmTN(C.Structure):
     _fields_ = [("A1", c_fp), ("lda1", i32), ("na1", i32), ("B1", c_fp), ("ldb1", i32),
                 ("A2", c_fp), ("lda2", i32), ("na2", i32), ("B2", c_fp), ("ldb2", i32),
                 ("C", c_fp), ("ldc", i32), ("dbias", c_fp), ("M", i32), ("NA", i32), ("NB", i32),
-                ("rows_per_block", i32)]
+                ("rows_per_block", i32), ("prec", i32)]
 
 
 TN_MAX_PROBLEMS = 12
@@ -45,7 +45,7 @@ class GemmTNProblem(C.Structure):
 
 
 class GemmTNGroup(C.Structure):
-    _fields_ = [("n_problems", i32), ("M", i32), ("rows_per_block", i32), ("total_tiles", i32),
+    _fields_ = [("n_problems", i32), ("M", i32), ("rows_per_block", i32), ("total_tiles", i32), ("prec", i32),
                 ("prob", GemmTNProblem * TN_MAX_PROBLEMS)]
 
 

@@ -23,6 +23,9 @@
 #define LDT_S (BM + 4)  // TN kernel: both operands are straight copies
 #define T_TILE (BK * LDT_S)
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -388,10 +391,47 @@ __device__ __forceinline__ void gemm_tn_body(const NudfGemmTN& p, float* smem, i
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // config-5 mode: bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Lane (i, h) of an operand holds the 8
+  // reduction indices 8h .. 8h+7 of its column: 8 strided ds_read_b32 of the SAME fp32 LDS tiles, converted on the fly
+  // (RNE).  16x the fp32 MFMA rate, so this loop is bound by the LDS reads / HBM, not by the matrix pipe.
+  auto mma_tile16 = [&](auto NI, auto NJ, int cur) {
+    constexpr int kNI = decltype(NI)::value, kNJ = decltype(NJ)::value;
+    const float* as = As + cur * T_TILE + (8 * (lane >> 5)) * LDT_S + wm * 64 + (lane & 31);
+    const float* bs = Bs + cur * T_TILE + (8 * (lane >> 5)) * LDT_S + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 a16[2], b16[2];
+#pragma unroll
+      for (int i = 0; i < kNI; ++i) {
+        f32x8 v;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = as[(16 * kk + t) * LDT_S + 32 * i];
+        a16[i] = __builtin_convertvector(v, bf16x8);
+      }
+#pragma unroll
+      for (int j = 0; j < kNJ; ++j) {
+        f32x8 v;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = bs[(16 * kk + t) * LDT_S + 32 * j];
+        b16[j] = __builtin_convertvector(v, bf16x8);
+      }
+#pragma unroll
+      for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+        for (int i = 0; i < kNI; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16[i], b16[j], acc[i][j], 0, 0, 0);
+    }
+  };
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
     __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+    if (p.prec != 0) {
+      if (ni == 2 && nj == 2) mma_tile16(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, cur);
+      else if (ni == 2 && nj == 1) mma_tile16(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cur);
+      else if (ni == 1 && nj == 2) mma_tile16(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, cur);
+      else if (ni == 1 && nj == 1) mma_tile16(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cur);
+    } else
     if (ni == 2 && nj == 2) mma_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, cur);
     else if (ni == 2 && nj == 1) mma_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cur);
     else if (ni == 1 && nj == 2) mma_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, cur);
@@ -445,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(NudfGemmTNGroup g
   p.B1 = q.B1; p.ldb1 = q.ldb1;
   p.A2 = nullptr; p.lda2 = 0; p.na2 = 0; p.B2 = nullptr; p.ldb2 = 0;
   p.C = q.C; p.ldc = q.ldc; p.dbias = q.dbias;
-  p.M = g.M; p.NA = q.NA; p.NB = q.NB; p.rows_per_block = g.rows_per_block;
+  p.M = g.M; p.NA = q.NA; p.NB = q.NB; p.rows_per_block = g.rows_per_block; p.prec = g.prec;
   gemm_tn_body(p, smem, gt - q.tile_start, chunk);
 }
 

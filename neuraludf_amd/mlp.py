@@ -114,6 +114,7 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
     a.C, a.ldc = ptr(C), C.shape[1]
     a.dbias = ptr(dbias)
     a.M, a.NA, a.NB, a.rows_per_block = M, NA, NB, 0
+    a.prec = 0 if PRECISION == "fp32" else 2
     if PROFILE is not None:
         _timed("gemm_tn", 2.0 * M * NA * NB * (2 if A2 is not None else 1), lambda: call("nudf_gemm_tn", a))
         return
@@ -214,6 +215,7 @@ def gemm_tn_grouped(jobs, M):
         chunk = jobs[base:base + _lib.TN_MAX_PROBLEMS]
         g = _lib.GemmTNGroup()
         g.n_problems, g.M, g.rows_per_block = len(chunk), M, 0
+        g.prec = 0 if PRECISION == "fp32" else 2       # mixed16: bf16 operands for the weight gradients as well
         flops = 0.0
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
