@@ -649,14 +649,28 @@ class UDFEngine:
                         pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
                         pe_dst=R[l + 1] if nxt_skip else None)
             cb.launch()
-            call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp,
-                 1.0 / float(net.scale), ptr(grads[L][0]))
+        grouped = os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1"
+        inv_scale = 1.0 / float(net.scale)
+        if second and not grouped:
+            call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp, inv_scale, ptr(grads[L][0]))
         plL = layers[L]
         F = plL.out - 1
         ABAR = [None] * (L + 1)
-        ABAR[L] = _buf(P, plL.out, dev, zero=False)
-        call("nudf_udf_head_bwd", ptr(sign), ptr(d_udf), ptr(d_feat), d_feat_ld, P, F,
-             1.0 / float(net.scale), ptr(ABAR[L]), ABAR[L].shape[1])
+        head4_path = grouped and os.environ.get("NUDF_UDF_HEAD4", "1") == "1"
+        if second and grouped and not head4_path:
+            call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp, inv_scale, ptr(grads[L][0]))
+        if head4_path:
+            # the head's adjoint is [sign * d udf / scale | d feat]: d feat is used where it lies (tile load, GEMM operand)
+            # and column 0 travels as a 4-wide operand -- no [P, 257] copy (52 us), no separate column-sum kernel (36 us)
+            head4 = torch.zeros(pad_rows(P), 4, device=dev)
+            if d_udf is not None:
+                head4[:P, 0] = sign * d_udf.reshape(-1) * inv_scale
+            r1, ldr1 = head4, 4
+        else:
+            ABAR[L] = _buf(P, plL.out, dev, zero=False)
+            call("nudf_udf_head_bwd", ptr(sign), ptr(d_udf), ptr(d_feat), d_feat_ld, P, F, inv_scale, ptr(ABAR[L]),
+                 ABAR[L].shape[1])
+            r1, ldr1 = ABAR[L], ABAR[L].shape[1]
         for l in range(L):
             ABAR[l] = _buf(P, layers[l].out, dev, zero=False)
         # adjoint sweep: the tile starts as d feat (ABAR[L] columns 1..F); column 0 enters as a rank-1 term
@@ -670,7 +684,7 @@ class UDFEngine:
             if l == L:
                 cb.step("BWD", pl.frag(_kind("bwd_feat", "bwd")), k8(F), layers[l - 1].out, X1=X[l],
                         X2=EX[l - 1] if second else None,
-                        C1=ABAR[l - 1], r1_row=ABAR[L], ldr1=ABAR[L].shape[1], r1_col=pl.W, scale=sc,
+                        C1=ABAR[l - 1], r1_row=r1, ldr1=ldr1, r1_col=pl.W, scale=sc,
                         xscale=self._xs(l - 1))
             else:
                 n_hid = layers[l - 1].out           # the skip layer's embedding columns carry no parameter gradient
@@ -678,14 +692,28 @@ class UDFEngine:
                         n_hid, X1=X[l],
                         X2=EX[l - 1] if second else None, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
         cb.launch()
-        if os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1":
+        if grouped:
             # two grouped launches (adjoint pairs, then the second-order pairs accumulating into the same dW): each
             # is one resident wave of ~500 workgroups with 14-17 row chunks per tile instead of 128 -- 9x fewer
-            # atomics per output element and 2 launch tails instead of 9 (1.67 -> 1.61 ms per step; ONE launch of all
-            # 17 problems fills only 462 of the 512 slots and was slower)
-            gemm_tn_grouped([(ABAR[l], pl.out, X[l], pl.in_pad, grads[l][0], grads[l][1]) for l, pl in enumerate(layers)], P)
+            # atomics per output element and 2 launch tails instead of 9 (1.67 -> 1.56 ms per step; ONE launch of all
+            # 17 problems fills only 462 of the 512 slots and was slower).  The head layer enters as two problems:
+            # rows 1.. of dW from d feat, row 0 from the 4-wide column-0 operand.
+            dWL, dbL = grads[L]
+            jobs = [(ABAR[l], layers[l].out, X[l], layers[l].in_pad, grads[l][0], grads[l][1]) for l in range(L)]
+            if head4_path:
+                assert d_feat.shape[1] == d_feat_ld and d_feat.is_contiguous()
+                jobs.append((d_feat, F, X[L], plL.in_pad, dWL[1:], dbL[1:]))
+                jobs.append((head4, 1, X[L], plL.in_pad, dWL[:1], dbL[:1]))
+            else:
+                jobs.append((ABAR[L], plL.out, X[L], plL.in_pad, dWL, dbL))
+            gemm_tn_grouped(jobs, P)
             if second:
-                gemm_tn_grouped([(DA[l], layers[l].out, R[l], layers[l].in_pad, grads[l][0], None) for l in range(L)], P)
+                jobs = [(DA[l], layers[l].out, R[l], layers[l].in_pad, grads[l][0], None) for l in range(L)]
+                if head4_path:
+                    sg4 = torch.zeros(pad_rows(P), 4, device=dev)
+                    sg4[:P, 0] = sign * inv_scale  # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
+                    jobs.append((sg4, 1, R[L], plL.in_pad, dWL[:1], None))
+                gemm_tn_grouped(jobs, P)
             return unpack_group(layers, grads)
         for l, pl in enumerate(layers):
             dW, db = grads[l]
