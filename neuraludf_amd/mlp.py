@@ -649,16 +649,14 @@ class UDFEngine:
                         pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
                         pe_dst=R[l + 1] if nxt_skip else None)
             cb.launch()
-        grouped = os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1"
+        grouped = os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1"      # A/B switches (profiling)
+        head4_path = grouped and os.environ.get("NUDF_UDF_HEAD4", "1") == "1"
         inv_scale = 1.0 / float(net.scale)
-        if second and not grouped:
+        if second and not head4_path:
             call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp, inv_scale, ptr(grads[L][0]))
         plL = layers[L]
         F = plL.out - 1
         ABAR = [None] * (L + 1)
-        head4_path = grouped and os.environ.get("NUDF_UDF_HEAD4", "1") == "1"
-        if second and grouped and not head4_path:
-            call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp, inv_scale, ptr(grads[L][0]))
         if head4_path:
             # the head's adjoint is [sign * d udf / scale | d feat]: d feat is used where it lies (tile load, GEMM operand)
             # and column 0 travels as a 4-wide operand -- no [P, 257] copy (52 us), no separate column-sum kernel (36 us)
