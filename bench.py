@@ -291,9 +291,10 @@ def main():
             result["cpu_baseline"] = {"error": repr(ex)}
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
+        barrier()              # rank 0 did the extra single-rank measurements; leave the group together
         dist.destroy_process_group()
 
 
