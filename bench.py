@@ -43,6 +43,9 @@ WORKLOADS = {
                            "dtu"),
     "dtu_shipped_512x114+32": (512, dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5,
                                          perturb=1.0), "dtu"),
+    # BASELINE config 5 per GPU: 8192 rays x 256 samples over 8 GPUs = 1024 rays x (128 + 128) each
+    "dtu_scan24_1024x256": (1024, dict(n_samples=128, n_importance=128, n_outside=0, up_sample_steps=4, perturb=1.0),
+                            "dtu"),
     # BASELINE config 3: garment scene, mix schedule, pixel + patch blending over 8 source views (7x7 patches)
     "garment_blend_1024x128": (1024, dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0,
                                           upsampling_type="mix", use_norm_grad_for_cosine=True, h_patch_size=3),
