@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must be loaded before libnudf, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnudf.so")
+LIB_PATH = os.environ.get("NUDF_LIB") or os.path.join(_HERE, "libnudf.so")      # NUDF_LIB: A/B builds of the library
 
 c_fp = C.c_void_p
 i32 = C.c_int32
