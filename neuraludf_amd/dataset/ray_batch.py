@@ -10,6 +10,8 @@ the ndc uv, the camera-space direction, near / far and the ground-truth patches.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib
@@ -62,6 +64,22 @@ class RayBatchSource:
         self.object_bbox_min, self.object_bbox_max = cameras.object_bbox(scale_mats[0], obj)
         self.focal = self.intrinsics_all[0][0, 0]
         self.prepare_ref_src_pairs()
+        return self
+
+    @classmethod
+    def from_directory(cls, data_dir, dataset_name="dtu", render_cameras_name="cameras.npz", object_cameras_name=None,
+                       downsample_factor=1.0, device="cuda"):
+        """Dataset.__init__ on a data directory (dataset.py:40-127): `image/*.png` + `mask/*.png` (or the BlendedMVS
+        names) and the IDR camera files.  Missing masks mean all-ones, as at dataset.py:86-88."""
+        import numpy as np
+        from . import images as im
+        img_files, mask_files = im.list_dataset_files(data_dir, dataset_name)
+        images = im.load_image_stack(img_files)
+        masks = im.load_image_stack(mask_files) if mask_files else None
+        cams = np.load(os.path.join(data_dir, render_cameras_name))
+        obj = np.load(os.path.join(data_dir, object_cameras_name)) if object_cameras_name else None
+        self = cls.from_idr(cams, images, masks, obj, downsample_factor, device)
+        self.images_lis, self.masks_lis, self.data_dir = img_files, mask_files, data_dir
         return self
 
     # -- pixel draws: torch's generator, same call order as dataset.py:235-252 -------------------------------------

@@ -97,3 +97,32 @@ def test_from_idr_builds_the_dataset_tensors():
     np.testing.assert_allclose(src.pose_all.numpy(), g["pose_all"], atol=2e-4)
     np.testing.assert_allclose(src.object_bbox_min, [-1.01] * 3, atol=1e-9)
     assert len(src.ref_src_pair) == n and len(src.scale_mats_np) == n
+
+
+def test_from_directory_reads_the_reference_layout(tmp_path):
+    """image/*.png + mask/*.png + cameras.npz -> resident tensors: BGR / 256 like cv.imread, sorted file order."""
+    from PIL import Image
+    from neuraludf_amd.dataset import RayBatchSource
+    from neuraludf_amd.dataset import images as im
+    g = load_gold()
+    n, H, W = 3, 24, 32
+    rng = np.random.default_rng(0)
+    os.makedirs(tmp_path / "image"); os.makedirs(tmp_path / "mask")
+    rgb = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    msk = (rng.random((n, H, W)) > 0.5).astype(np.uint8) * 255
+    for i in (2, 0, 1):                                   # written out of order: the loader sorts
+        Image.fromarray(rgb[i]).save(tmp_path / "image" / f"{i:03d}.png")
+        Image.fromarray(msk[i]).save(tmp_path / "mask" / f"{i:03d}.png")        # single-channel mask file
+    cam = {}
+    for i in range(n):
+        K, c2w = g["intrinsics_all"][i].astype(np.float64), g["pose_all"][i].astype(np.float64)
+        P = np.eye(4); P[:3, :4] = (K @ np.linalg.inv(c2w))[:3, :4]
+        cam[f"world_mat_{i}"], cam[f"scale_mat_{i}"] = P, np.eye(4)
+    np.savez(tmp_path / "cameras.npz", **cam)
+    src = RayBatchSource.from_directory(str(tmp_path), device="cpu")
+    assert src.images.shape == (n, H, W, 3) and src.n_images == n
+    np.testing.assert_array_equal(src.images.numpy(), rgb[..., ::-1].astype(np.float32) / np.float32(256.0))
+    np.testing.assert_array_equal(src.masks.numpy(), np.repeat(msk[..., None], 3, -1).astype(np.float32) / np.float32(256.0))
+    np.testing.assert_allclose(src.pose_all.numpy(), g["pose_all"][:n], atol=2e-4)
+    assert [os.path.basename(p) for p in src.images_lis] == ["000.png", "001.png", "002.png"]
+    assert im.read_bgr(str(tmp_path / "mask" / "000.png")).shape == (H, W, 3)
