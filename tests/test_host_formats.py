@@ -239,3 +239,37 @@ print("ok")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_shipped_confs_construct_the_dropin_objects():
+    """every conf file the reference ships parses, and its sections construct the drop-in networks, renderer, loss and
+    schedules exactly the way exp_runner_blending.py:64-146 consumes them (CPU construction only; build container)."""
+    import contextlib
+    import glob
+    import io
+    from refload import have_reference
+    if not have_reference():
+        pytest.skip("reference tree not present")
+    from neuraludf_amd.loss.loss import ColorLoss
+    from neuraludf_amd.models import fields
+    from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
+    files = sorted(glob.glob("/root/reference/confs/*.conf"))
+    assert len(files) == 4
+    for f in files:
+        c = nconf.parse_file(f, case="scan24")
+        assert "CASE_NAME" not in c["dataset.data_dir"] and c["general.model_type"] == "udf"
+        with contextlib.redirect_stdout(io.StringIO()):
+            nerf = fields.NeRF(**c["model.nerf"])
+            udf = fields.UDFNetwork(**c["model.udf_network"])
+            var = fields.SingleVarianceNetwork(**c["model.variance_network"])
+            col = fields.ResidualRenderingNetwork(**c["model.rendering_network"])
+            beta = fields.BetaNetwork(**c["model.beta_network"])
+            rend = UDFRendererBlending(nerf, udf, var, col, beta, **c["model.udf_renderer"])
+            loss = ColorLoss(**c["color_loss"])
+        s = sch.Schedules.from_conf(c, is_finetune=f.endswith("_ft.conf"))
+        assert rend.n_samples == 64 and rend.n_importance in (50, 80) and loss.h_patch_size in (3, 5)
+        assert s.end_iter == c.get_int("train.end_iter") and s.learning_rate == c.get_float("train.learning_rate")
+        n_par = sum(p.numel() for m in (nerf, udf, var, col, beta) for p in m.parameters())
+        assert n_par == 1291484, n_par          # SURVEY section 8(e): 1 291 484 floats
+        a = s.at(0)
+        assert 0.0 <= a["cos_anneal_ratio"] <= 1.0
