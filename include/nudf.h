@@ -347,7 +347,8 @@ typedef struct NudfChain {
   int32_t init;                    /* NUDF_CH_INIT_*                                                 */
   int32_t k0;                      /* initial tile width (multiple of 4, <= 288)                     */
   int32_t x_div;                   /* x row of point p is p / x_div (samples per ray for per-ray directions; >= 1) */
-  int32_t tile_rows;               /* 0 = choose, 32 or 64 points per workgroup                      */
+  int32_t tile_rows;               /* 0 = choose; 32 / 64 points per workgroup (shared tile); 128 = prefer the
+                                      wave-private kernel (4 waves x 32 points; fp32 steps, 16-byte aligned rows) */
   int32_t lda0, ldg0;
   int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */
   float pe_in_scale;

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libnudf.so")
 SOURCES = ["nudf_api.hip", "gemm_f32_mfma.hip", "rays_embed.hip", "composite.hip", "upsample.hip",
-           "blend.hip", "optim.hip", "mlp_chain.hip", "raybatch.hip"]
+           "blend.hip", "optim.hip", "mlp_chain.hip", "mlp_chain_rows.hip", "raybatch.hip"]
 
 
 def _hipcc() -> str:

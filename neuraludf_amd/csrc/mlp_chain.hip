@@ -20,43 +20,8 @@
 #include "nudf_common.h"
 #include "../../include/nudf.h"
 
-#define CH_LD 292          // activation row stride in floats (K <= 288): m*292 mod 64 = 36m -> 16 consecutive rows hit
-                           // 16 distinct multiples of 4 -> conflict-free ds_read_b128
-#define CH_THREADS 256
-
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x16 ch_mfma(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// softplus'(a) = s and 1 - s from the STORED activation h = softplus100(a) / xscale (see gemm_f32_mfma.hip)
-__device__ __forceinline__ void ch_sp_derivs(float hstored, float xscale, float& s, float& om) {
-  const float x = 100.0f * xscale * hstored;
-  if (x > 20.0f) {
-    s = 1.0f;
-    om = 0.0f;
-  } else {
-    const float e = __expf(-x);
-    om = e;
-    s = (x < 0.01f) ? x * (1.0f - x * (0.5f - x * 0.16666667f)) : 1.0f - e;
-  }
-}
-
-// positional-encoding element c of point x (value or JVP with tangent v); same arithmetic as posenc_kernel
-__device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, int L, float in_scale, int jvp) {
-  const int blk = c / 3, j = c - blk * 3;
-  const float xv = x3[j] * in_scale;
-  if (blk == 0) return jvp ? v3[j] * in_scale : xv;
-  const int k = (blk - 1) >> 1;
-  const float f = (float)(1 << k);
-  const float a = xv * f;
-  const bool is_sin = ((blk - 1) & 1) == 0;
-  if (!jvp) return is_sin ? sinf(a) : cosf(a);
-  return (is_sin ? cosf(a) : -sinf(a)) * f * v3[j] * in_scale;
-}
+#include "mlp_chain_shared.h"
+#include <stdlib.h>
 
 template <int TM>
 struct ChainSmem {
@@ -88,14 +53,10 @@ __device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& 
 // K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
 // the body, so the compiler's s_waitcnt counters let the NEXT group's LDS / L2 reads stay in flight under the
 // current group's 4*NRT*NCT MFMAs.  G (groups of 8 k) is even; the last prefetch re-reads the last group.
-#define CH_KOFF(r) (((r) & 3) + 8 * ((r) >> 2))
 
 // Stored-activation operand of the epilogue (X1), fetched for ALL tiles of the wave while the last two k groups
 // are still being multiplied: the HBM latency of the epilogue operands then hides under MFMAs instead of
 // sitting between the barrier and the first epilogue instruction.
-#define CH_USES_X1(e)                                                                                           \
-  ((e) == NUDF_CH_MULSP || (e) == NUDF_CH_TANGENT || (e) == NUDF_CH_BWD || (e) == NUDF_CH_MULMASK || (e) == NUDF_CH_ADDMASK)
-
 struct ChPrefetch {
   const float* X1;
   int ldx1;
@@ -590,6 +551,20 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
   }
 }
 
+int nudf_chain_rows_class(const NudfChain& p);                              // mlp_chain_rows.hip
+int nudf_mlp_chain_rows_launch(const NudfChain& p, int cls, hipStream_t st);
+
+// NUDF_CHAIN_ROWS=1 lets large launches choose the wave-private kernel on their own (measured in round 2: equal to
+// the workgroup-shared tiles on the forward sweeps, 10-20 % slower on the sweeps that stream stored state, see
+// DESIGN.md section 4.1b); tile_rows = 128 requests it explicitly.  Read once.
+static bool nudf_chain_rows_auto() {
+  static const int on = [] {
+    const char* e = getenv("NUDF_CHAIN_ROWS");
+    return (e && e[0] == '1') ? 1 : 0;
+  }();
+  return on != 0;
+}
+
 extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   const NudfChain& p = *args;
   if (p.P <= 0 || p.n_steps <= 0) return 0;
@@ -604,8 +579,21 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     return (int)hipErrorInvalidValue;
   }
   hipStream_t st = (hipStream_t)stream;
+  // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of
+  // that kernel is 1024 waves = 32 768 points, so it is chosen when the last round is at least ~80 % full; the
+  // up-sampling rounds (5-8 k points) and awkward sizes keep the workgroup-shared tiles below.
+  bool rows_ok = p.tile_rows == 128 || p.tile_rows == 0;
+  if (rows_ok && p.tile_rows == 0) {
+    const long long round = 1024LL * 32, rounds = (p.P + round - 1) / round;
+    rows_ok = nudf_chain_rows_auto() && p.P >= 24576 && (double)p.P >= 0.8 * (double)(rounds * round);
+  }
+  if (rows_ok) {
+    const int cls = nudf_chain_rows_class(p);
+    if (cls >= 0) return nudf_mlp_chain_rows_launch(p, cls, st);
+    // contract of the wave-private kernel not met (16-bit operands, unaligned row buffers): workgroup-shared tiles
+  }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
-  if (p.tile_rows == 32 || (p.tile_rows == 0 && p.P <= 256 * 64)) {
+  if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {
     hipLaunchKernelGGL(mlp_chain_kernel<32>, dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
   } else {
     hipLaunchKernelGGL(mlp_chain_kernel<64>, dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);

@@ -1,0 +1,510 @@
+// Fused MLP layer chains, wave-private layout (gfx950): every WAVE owns a tile of 32 points for the whole
+// sweep -- all <= 256 output features of every layer -- so no wave ever waits for another one: the kernel has no
+// barrier at all, each of the CU's 4 SIMDs runs one free-running wave (a 128-point workgroup = 4 such waves,
+// 150 KB of LDS).  Same step tables (NudfChain), same arithmetic and same fp32 summation order as the
+// workgroup-shared kernel of mlp_chain.hip, which stays the path for launches too small to fill 1024 waves.
+//
+// Differences that matter on CDNA4:
+//  * the product is computed TRANSPOSED: v_mfma_f32_32x32x2_f32(weights, activations) -> the accumulator lane owns
+//    ONE POINT and its 16 registers are 4 groups of 4 CONSECUTIVE FEATURES, so the epilogue moves 16 bytes per
+//    lane per instruction everywhere: ds_write_b128 into the LDS tile (conflict-free at row stride 292), and
+//    global_load/store_dwordx4 for the stored-state operands / outputs (4 instead of 16 VMEM instructions per
+//    32x32 tile and operand -- what lets a wave keep four tiles of two operands in flight inside the 6-bit vmcnt);
+//  * one ds_read_b128 of the activation tile feeds 4 * NT MFMAs (NT = feature tiles, up to 8) instead of 8;
+//  * nothing covers a wave's latencies but the wave itself (one wave per SIMD), so every epilogue operand is
+//    requested ahead of its use: the stored-state operands (X1, X2) of feature tiles 0..3 under the last two k
+//    groups of the K loop, those of tile t + 4 as soon as tile t has been consumed; the bias of step s + 1 is staged
+//    through LDS during step s and enters as the accumulators' initial value (bias-first summation: results differ
+//    from the workgroup-shared kernel by the rounding of that one addition);
+//  * the 4 waves of a workgroup read the same weight fragments; re-aligning them with a barrier per step
+//    (CHR_STEP_SYNC) so that three of the four reads hit the CU's vector L1 measured 3 % SLOWER and is off.
+#include "mlp_chain_shared.h"
+#include <stdlib.h>
+
+#define CHR_WAVES 4
+#ifndef CHR_STEP_SYNC
+#define CHR_STEP_SYNC 0      // 1: barrier at the top of every step (L1 sharing of the weight stream): measured -3 %
+#endif
+#define CHR_ROWS 32
+
+struct ChainRowsSmem {
+  float act[CHR_WAVES][CHR_ROWS * CH_LD];   // 149 504 B
+  float bias[CHR_WAVES][2][256];            //   8 192 B (double-buffered: step s reads [s & 1], stages [~s & 1])
+  float xs[CHR_WAVES][CHR_ROWS * 3];
+  float vs[CHR_WAVES][CHR_ROWS * 3];
+};
+
+// LDS traffic of one wave is processed in program order; only the compiler has to be told not to move a tile read
+// above the tile writes of other lanes
+__device__ __forceinline__ void chr_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void chr_write_pe(float* act, const float* xs, const float* vs, const NudfChain& p, int lane,
+                                             int m0, int col0, float scale, float* gdst, int ldg, int gcol0, int zero_to) {
+  const int E = 3 * (2 * p.pe_L + 1);
+  for (int e = lane; e < CHR_ROWS * E; e += 64) {
+    const int r = e / E, c = e - r * E;
+    const float val = ch_pe(xs + r * 3, vs + r * 3, c, p.pe_L, p.pe_in_scale, p.pe_jvp) * scale;
+    act[r * CH_LD + col0 + c] = val;
+    if (gdst && (m0 + r) < p.P) gdst[(size_t)(m0 + r) * ldg + gcol0 + c] = val;
+  }
+  const int npad = zero_to - (col0 + E);
+  if (npad > 0)
+    for (int e = lane; e < CHR_ROWS * npad; e += 64) {
+      const int r = e / npad, c = e - r * npad;
+      act[r * CH_LD + col0 + E + c] = 0.0f;
+    }
+}
+
+// Launch-time contract of this kernel (checked by nudf_chain_rows_supported, else the workgroup-shared kernel
+// runs): every [P, ld] buffer that is accessed quad-wise -- X1, X2, C1 (except the UDFHEAD / SIGMOIDN heads) and the
+// TANGENT / RELU mirrors in C2 -- is 16-byte aligned with ld % 4 == 0, and act_col0 % 4 == 0 (except SIGMOIDN).
+
+// Values the epilogue needs per step, pinned in SGPRs: left to itself the compiler re-reads NudfChainStep fields
+// from the kernel-argument segment inside the tile loop (an s_load + lgkmcnt(0) wait per quad).
+template <class T>
+__device__ __forceinline__ T chr_pin(T x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+
+// global-address-space views of the step's buffers: a pointer that went through chr_pin is a generic pointer to
+// the compiler (flat_load: counted by lgkmcnt as well, so it would tie the LDS waits to HBM latency)
+typedef const float __attribute__((address_space(1)))* chr_gcp;
+typedef float __attribute__((address_space(1)))* chr_gp;
+
+struct ChrStep {
+  unsigned row, x1, x2, c1, c2;          // per lane: row and row * ld of the step's buffers
+  chr_gcp X1, X2;
+  chr_gp C1, C2;
+  int N, nq, iparam, act_col0, act_write, lim1, lim2;
+  float scale, xscale;
+};
+
+// Features f0..f0+3 of one point of a stored [P, ld] operand (accumulator layout: lane = point, 4 consecutive
+// registers = 4 consecutive features).  Columns are clamped into [0, N): the values of features >= N are never
+// used, so the loads carry no predicate.
+typedef const f32x4 __attribute__((address_space(1)))* chr_gcp4;
+typedef f32x4 __attribute__((address_space(1)))* chr_gp4;
+__device__ __forceinline__ f32x4 chr_load_quad(chr_gcp X, unsigned rowoff, int f0, int nq) {
+  return *(chr_gcp4)(X + (rowoff + (unsigned)min(f0, nq)));
+}
+
+// features [lo, hi) -> C[row, f - shift], element-wise (heads, split outputs)
+__device__ __forceinline__ void chr_store_range(chr_gp C, unsigned rowoff, int f0, int lo, int hi, int shift,
+                                                const f32x4& v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (f0 + i >= lo && f0 + i < hi) C[rowoff + (unsigned)(f0 + i - shift)] = v[i];
+}
+
+// Epilogue of one [32 points x 32 features] accumulator tile (bias already inside the accumulator), streamed as four
+// quads of consecutive features: compute -> re-request this quad of the operand window for tile t + CHR_WIN -> store.
+// Features >= N of the last tile need no masking: their accumulators are exactly 0 (zero-padded weight fragments,
+// zero staged bias), every epilogue maps that to a finite value, and such values only ever reach pad columns --
+// of the LDS tile, where the next step's zero weight rows meet them, and of the [P, ld] buffers, which no consumer
+// reads (operand loads clamp their columns into [0, N)).
+template <int EPI>
+__device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act, const ChrStep& cs, int t, int h, int ln,
+                                             const f32x16& a, float (&w1)[16], float (&w2)[16], bool reload, int t_next) {
+  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
+  const int fb = 32 * t + 4 * h;
+  const int N = cs.N;
+  float r1 = 0.0f;
+  // rank-1 term (column 0 of the abs head in the UDF adjoint sweep, the density head's adjoint in the NeRF's)
+  const bool has_r1 = (EPI == NUDF_CH_BWD || EPI == NUDF_CH_MULMASK) && st.r1_row != nullptr;
+  if (has_r1) r1 = st.r1_row[(size_t)cs.row * st.ldr1];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f0 = fb + 8 * q;
+    f32x4 o, o2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * q + i;
+      float v = a[r];
+      if (has_r1) v += r1 * st.r1_col[min(f0 + i, N - 1)];
+      const float x1 = U1 ? w1[r] : 0.0f, x2 = U2 ? w2[r] : 0.0f;
+      if (EPI == NUDF_CH_SOFTPLUS) {
+        // softplus100 from the two hardware transcendentals, see mlp_chain.hip
+        const float tt = 100.0f * v;
+        const float z = __builtin_amdgcn_exp2f(fabsf(tt) * -1.44269504f);
+        o[i] = (fmaxf(tt, 0.0f) + __builtin_amdgcn_logf(1.0f + z) * 0.69314718f) * (0.01f * cs.scale);
+      } else if (EPI == NUDF_CH_NONE) {
+        o[i] = v * cs.scale;
+      } else if (EPI == NUDF_CH_UDFHEAD) {
+        o[i] = fabsf(v) * cs.scale;
+        o2[i] = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);
+      } else if (EPI == NUDF_CH_RELU) {
+        o[i] = fmaxf(v, 0.0f);
+        o2[i] = o[i];
+      } else if (EPI == NUDF_CH_RELUADD) {
+        o[i] = fmaxf(v + x2, 0.0f);
+      } else if (EPI == NUDF_CH_SIGMOIDN) {
+        o2[i] = v;
+        o[i] = (f0 + i < cs.iparam) ? 1.0f / (1.0f + expf(-v)) : 0.0f;
+      } else if (EPI == NUDF_CH_MULMASK) {
+        o[i] = (x1 > 0.0f) ? v * cs.scale : 0.0f;
+      } else if (EPI == NUDF_CH_ADDMASK) {
+        o[i] = (x1 > 0.0f) ? (v + x2) * cs.scale : 0.0f;
+      } else {
+        const float x = 100.0f * cs.xscale * x1;
+        const float om = __builtin_amdgcn_exp2f(x * -1.44269504f);
+        const float sg = 1.0f - om;
+        if (EPI == NUDF_CH_MULSP) {
+          // skip split: the embedding columns (>= iparam) hold PE values in X1, whose "softplus derivative" overflows
+          const bool hid = cs.iparam <= 0 || f0 + i < cs.iparam;
+          o[i] = hid ? v * sg * cs.scale : 0.0f;
+          o2[i] = v * cs.scale;
+        } else if (EPI == NUDF_CH_TANGENT) {
+          o[i] = v * sg * cs.scale;
+          o2[i] = v * x2 * 100.0f * om;
+        } else {  // NUDF_CH_BWD
+          o[i] = v * cs.scale * sg + x2;
+        }
+      }
+    }
+    // this quad of the window is consumed: request it for tile t_next (in place)
+    if (reload) {
+      if (U1) {
+        const f32x4 nv = chr_load_quad(cs.X1, cs.x1, 32 * t_next + 4 * h + 8 * q, cs.nq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1[4 * q + i] = nv[i];
+      }
+      if (U2 && cs.X2) {
+        const f32x4 nv = chr_load_quad(cs.X2, cs.x2, 32 * t_next + 4 * h + 8 * q, cs.nq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w2[4 * q + i] = nv[i];
+      }
+    }
+    // ---- stores ----
+    if (EPI == NUDF_CH_UDFHEAD) {
+      if (q == 0 && t == 0 && h == 0) {     // feature 0 = register 0 of the lower half-wave
+        if (cs.C2) cs.C2[cs.row] = o[0];
+        if (cs.C1) cs.C1[cs.row] = o2[0];
+      }
+      continue;
+    }
+    if (EPI == NUDF_CH_SIGMOIDN) {
+      if (cs.C1) chr_store_range(cs.C1, cs.c1, f0, 0, min(N, cs.iparam), 0, o);
+      if (cs.C2) {
+        if (N <= cs.iparam) chr_store_range(cs.C2, cs.c2, f0, 0, N, 0, o);             // C2 mirrors the sigmoid outputs
+        else chr_store_range(cs.C2, cs.c2, f0, cs.iparam, N, cs.iparam, o2);           // raw columns
+      }
+    } else {
+      // whole quads; lim1 / lim2 = columns the row holds (the tail of the last quad lands in pad columns)
+      if (cs.C1 && f0 < cs.lim1) *(chr_gp4)(cs.C1 + (cs.c1 + (unsigned)f0)) = o;
+      if (EPI == NUDF_CH_MULSP) {
+        if (cs.iparam > 0 && cs.C2) chr_store_range(cs.C2, cs.c2, f0, cs.iparam, N, cs.iparam, o2);   // embedding branch
+      } else if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_RELU) {
+        if (cs.C2 && f0 < cs.lim2) *(chr_gp4)(cs.C2 + (cs.c2 + (unsigned)f0)) = o2;
+      }
+    }
+    if (cs.act_write) {
+      float* ap = act + ln * CH_LD + cs.act_col0 + f0;
+      if (EPI != NUDF_CH_SIGMOIDN) {
+        *reinterpret_cast<f32x4*>(ap) = o;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ap[i] = o[i];
+      }
+    }
+  }
+}
+
+// All feature tiles of a step, straight-line (accumulator tile and window slot are compile-time registers).  Tile t's
+// stored-state operands sit in window slot t % W (the first W tiles were requested under the K loop) and are
+// re-requested for tile t + W, quad by quad, as they are consumed.  The scheduling barriers keep the tile bodies
+// apart: hoisting the accumulator reads / window loads of later tiles is what made the register allocator spill.
+template <int EPI, int W>
+__device__ __forceinline__ void chr_epilogue(const NudfChainStep& st, float* act, const ChrStep& cs, int NT, int h, int ln,
+                                             f32x16 (&acc)[8], float (&px1)[W][16], float (&px2)[W][16]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t >= NT) return;
+    chr_epi_tile<EPI>(st, act, cs, t, h, ln, acc[t], px1[t % W], px2[t % W], t + W < NT, t + W);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// K loop of one step: NCT feature tiles x 32 points.  Two register sets, the next k group's LDS / L2 reads are
+// issued above the current group's 4 * NCT MFMAs (sched_barriers pin them there); `tail` issues the epilogue's
+// operand requests after the last weight loads, so that the in-order vmcnt lets them stay in flight under the last
+// 4 * NCT MFMAs.  MFMA operand order (weights, activations): the product comes out transposed.
+template <int NCT, class Tail>
+__device__ __forceinline__ void chr_mma(const float* __restrict__ arow, const f32x4* __restrict__ bptr, size_t bstride,
+                                        int G, const float* bb, f32x16 (&acc)[8], Tail&& tail) {
+  f32x4 a0, a1, b0[NCT], b1[NCT];
+  // accumulators start as the bias (staged in LDS by the previous step): lane half h holds features 4h + 8q + i
+#pragma unroll
+  for (int j = 0; j < NCT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bb + 32 * j + 8 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][4 * q + i] = b[i];
+    }
+  a0 = *reinterpret_cast<const f32x4*>(arow);
+#pragma unroll
+  for (int j = 0; j < NCT; ++j) b0[j] = bptr[j * 64];
+#pragma unroll 1
+  for (int g = 0; g < G - 2; g += 2) {
+    {
+      const f32x4* bq = bptr + (size_t)(g + 1) * bstride;
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) b1[j] = bq[j * 64];
+      a1 = *reinterpret_cast<const f32x4*>(arow + (g + 1) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[j] = ch_mfma(b0[j][jj], a0[jj], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const f32x4* bq = bptr + (size_t)(g + 2) * bstride;
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) b0[j] = bq[j * 64];
+      a0 = *reinterpret_cast<const f32x4*>(arow + (g + 2) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[j] = ch_mfma(b1[j][jj], a1[jj], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    const f32x4* bq = bptr + (size_t)(G - 1) * bstride;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) b1[j] = bq[j * 64];
+    a1 = *reinterpret_cast<const f32x4*>(arow + (G - 1) * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) acc[j] = ch_mfma(b0[j][jj], a0[jj], acc[j]);
+  __builtin_amdgcn_sched_barrier(0);
+  tail();      // b0 / a0 are dead here: the window's registers do not add to the K loop's peak
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) acc[j] = ch_mfma(b1[j][jj], a1[jj], acc[j]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// bias of a step -> this wave's LDS staging buffer (zeros beyond N / without a bias): lane l stages features 4l..4l+3
+__device__ __forceinline__ f32x4 chr_bias_fetch(const NudfChainStep& st, int lane) {
+  f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (st.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = 4 * lane + i;
+      b[i] = (f < st.N) ? st.bias[f] : 0.0f;
+    }
+  }
+  return b;
+}
+
+// XCLS = which stored-state operands the sweep's epilogues read: 0 none (forward sweeps), 1 X1 only (input-gradient
+// sweeps), 2 X1 and X2 (tangent / adjoint sweeps); W = tiles per operand window.  Separate instantiations keep the
+// windows (16 W registers per operand) and the unused epilogues out of the sweeps that do not need them.
+template <int XCLS, int W>
+__global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfChain p) {
+  __shared__ __attribute__((aligned(16))) ChainRowsSmem sm;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, ln = lane & 31;
+  const int m0 = (blockIdx.x * CHR_WAVES + wave) * CHR_ROWS;
+  if (m0 >= p.P) return;     // whole-wave exit: nothing in this kernel waits for another wave
+  float* act = sm.act[wave];
+  float* xs = sm.xs[wave];
+  float* vs = sm.vs[wave];
+
+  // ---- tile initialisation ---------------------------------------------------------------------
+  if (p.x) {
+    for (int e = lane; e < CHR_ROWS * 3; e += 64) {
+      int r = m0 + e / 3;
+      if (r > p.P - 1) r = p.P - 1;
+      xs[e] = p.x[(size_t)(r / p.x_div) * 3 + (e % 3)];
+      vs[e] = p.v ? p.v[(size_t)r * 3 + (e % 3)] : 0.0f;
+    }
+  }
+  *reinterpret_cast<f32x4*>(sm.bias[wave][0] + 4 * lane) = chr_bias_fetch(p.step[0], lane);
+  chr_wave_sync();
+  if (p.init == NUDF_CH_INIT_LOAD) {
+    const int k4 = p.k0 >> 2;
+    for (int e = lane; e < CHR_ROWS * k4; e += 64) {
+      const int r = e / k4, c4 = e - r * k4;
+      int gr = m0 + r;
+      if (gr > p.P - 1) gr = p.P - 1;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(p.A0 + (size_t)gr * p.lda0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(act + r * CH_LD + c4 * 4) = val;
+    }
+  } else if (p.init == NUDF_CH_INIT_POSENC) {
+    chr_write_pe(act, xs, vs, p, lane, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0);
+  } else if (p.init == NUDF_CH_INIT_SEED) {
+    const int C = p.k0;
+    for (int e = lane; e < CHR_ROWS * C; e += 64) {
+      const int r = e / C, c = e - r * C;
+      int gr = m0 + r;
+      const bool live = gr < p.P;
+      if (!live) gr = p.P - 1;
+      float s, om;
+      ch_sp_derivs(p.A0[(size_t)gr * p.lda0 + c], p.seed_xscale, s, om);
+      const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
+      act[r * CH_LD + c] = val;
+      if (p.G0 && live) p.G0[(size_t)gr * p.ldg0 + c] = val;
+    }
+  }
+  chr_wave_sync();
+
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * CHR_WAVES + wave) * 32 : nullptr;
+  if (dbg && lane == 0) {
+    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    dbg[1] = __builtin_amdgcn_s_memtime();
+  }
+
+  const float* arow = act + ln * CH_LD + 4 * h;
+  ChrStep cs;
+  cs.row = (unsigned)(m0 + ln);
+
+  // ---- the layer chain ---------------------------------------------------------------------------
+  for (int si = 0; si < p.n_steps; ++si) {
+    const NudfChainStep& st = p.step[si];
+    const int G = st.K >> 3;
+    const int NT = (st.N + 31) >> 5;
+    const f32x4* __restrict__ bptr = reinterpret_cast<const f32x4*>(st.Bp) + lane;
+    const size_t bstride = (size_t)NT * 64;
+    cs.x1 = cs.row * (unsigned)st.ldx1;
+    cs.x2 = cs.row * (unsigned)st.ldx2;
+    cs.c1 = cs.row * (unsigned)st.ldc1;
+    cs.c2 = cs.row * (unsigned)st.ldc2;
+    cs.X1 = (chr_gcp)chr_pin(st.X1);
+    cs.X2 = (chr_gcp)chr_pin(st.X2);
+    cs.C1 = (chr_gp)chr_pin(st.C1);
+    cs.C2 = (chr_gp)chr_pin(st.C2);
+    cs.N = chr_pin(st.N);
+    cs.nq = chr_pin(((st.N + 3) & ~3) - 4);
+    cs.iparam = chr_pin(st.iparam);
+    cs.act_col0 = chr_pin(st.act_col0);
+    cs.act_write = chr_pin(st.act_write);
+    {
+      const int flim = (st.epi == NUDF_CH_MULSP && st.iparam > 0) ? min(st.N, st.iparam) : st.N;
+      cs.lim1 = chr_pin(min((flim + 3) & ~3, st.ldc1));
+      cs.lim2 = chr_pin(min((st.N + 3) & ~3, st.ldc2));
+    }
+    cs.scale = chr_pin(st.scale);
+    cs.xscale = chr_pin(st.xscale);
+
+#if CHR_STEP_SYNC
+    __builtin_amdgcn_s_barrier();     // speed only (L1 sharing of the weight stream); terminated waves are not counted
+#endif
+    f32x16 acc[8];       // initialised inside chr_mma (only the NT tiles that exist) from the staged bias
+    const float* bb = sm.bias[wave][si & 1] + 4 * h;
+    // next step's bias: requested now, staged into LDS after the K loop
+    f32x4 nbias = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (si + 1 < p.n_steps) nbias = chr_bias_fetch(p.step[si + 1], lane);
+
+    float px1[W][16], px2[W][16];
+    const bool u1 = XCLS >= 1 && CH_USES_X1(st.epi), u2 = XCLS >= 2 && CH_USES_X2(st.epi) && st.X2 != nullptr;
+    auto tail = [&]() {
+      if (XCLS == 0) return;
+#pragma unroll
+      for (int u = 0; u < W; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v1 = {0.0f, 0.0f, 0.0f, 0.0f}, v2 = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (u1 && u < NT) v1 = chr_load_quad(cs.X1, cs.x1, 32 * u + 4 * h + 8 * q, cs.nq);
+          if (XCLS >= 2 && u2 && u < NT) v2 = chr_load_quad(cs.X2, cs.x2, 32 * u + 4 * h + 8 * q, cs.nq);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            px1[u][4 * q + i] = v1[i];
+            if (XCLS >= 2) px2[u][4 * q + i] = v2[i];
+          }
+        }
+    };
+    switch (NT) {
+      case 1: chr_mma<1>(arow, bptr, bstride, G, bb, acc, tail); break;
+      case 2: chr_mma<2>(arow, bptr, bstride, G, bb, acc, tail); break;
+      case 3: chr_mma<3>(arow, bptr, bstride, G, bb, acc, tail); break;
+      case 4: chr_mma<4>(arow, bptr, bstride, G, bb, acc, tail); break;
+      case 5: chr_mma<5>(arow, bptr, bstride, G, bb, acc, tail); break;
+      case 6: chr_mma<6>(arow, bptr, bstride, G, bb, acc, tail); break;
+      case 7: chr_mma<7>(arow, bptr, bstride, G, bb, acc, tail); break;
+      default: chr_mma<8>(arow, bptr, bstride, G, bb, acc, tail); break;
+    }
+    *reinterpret_cast<f32x4*>(sm.bias[wave][(si + 1) & 1] + 4 * lane) = nbias;
+    if (dbg && lane == 0) dbg[2 + 2 * si] = __builtin_amdgcn_s_memtime();
+
+    switch (st.epi) {
+      case NUDF_CH_SOFTPLUS: chr_epilogue<NUDF_CH_SOFTPLUS, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_NONE: chr_epilogue<NUDF_CH_NONE, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_RELU: chr_epilogue<NUDF_CH_RELU, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_SIGMOIDN: chr_epilogue<NUDF_CH_SIGMOIDN, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_UDFHEAD: chr_epilogue<NUDF_CH_UDFHEAD, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_MULSP: if (XCLS >= 1) chr_epilogue<NUDF_CH_MULSP, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_MULMASK: if (XCLS >= 1) chr_epilogue<NUDF_CH_MULMASK, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_TANGENT: if (XCLS >= 2) chr_epilogue<NUDF_CH_TANGENT, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_BWD: if (XCLS >= 2) chr_epilogue<NUDF_CH_BWD, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_ADDMASK: if (XCLS >= 2) chr_epilogue<NUDF_CH_ADDMASK, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      case NUDF_CH_RELUADD: if (XCLS >= 2) chr_epilogue<NUDF_CH_RELUADD, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
+      default: break;
+    }
+    if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();
+    chr_wave_sync();
+    if (st.pe_tail_col >= 0) {
+      const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
+      chr_write_pe(act, xs, vs, p, lane, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col,
+                   min((pe_end + 15) & ~15, 288));
+      chr_wave_sync();
+    }
+  }
+}
+
+// The launch-time contract above; also picks the operand class.  Returns -1 when the workgroup-shared kernel must run.
+int nudf_chain_rows_class(const NudfChain& p) {
+  int cls = 0;
+  auto vec_ok = [](const void* q, int ld) { return ((((uintptr_t)q) | ((unsigned)ld << 2)) & 15) == 0; };
+  for (int i = 0; i < p.n_steps; ++i) {
+    const NudfChainStep& s = p.step[i];
+    if (s.prec != 0) return -1;
+    const int e = s.epi;
+    if (CH_USES_X1(e)) {
+      if (!s.X1 || !vec_ok(s.X1, s.ldx1)) return -1;
+      cls = cls < 1 ? 1 : cls;
+    }
+    if (CH_USES_X2(e)) {
+      if (s.X2 && !vec_ok(s.X2, s.ldx2)) return -1;
+      cls = 2;
+    }
+    if (e != NUDF_CH_UDFHEAD && e != NUDF_CH_SIGMOIDN) {
+      if (s.C1 && !vec_ok(s.C1, s.ldc1)) return -1;
+      if (s.act_write && (s.act_col0 & 3)) return -1;
+    }
+    if ((e == NUDF_CH_TANGENT || e == NUDF_CH_RELU) && s.C2 && !vec_ok(s.C2, s.ldc2)) return -1;
+    if (s.r1_row && ((e != NUDF_CH_BWD && e != NUDF_CH_MULMASK) || !s.r1_col)) return -1;
+  }
+  return cls;
+}
+
+// launch (argument checks are done by nudf_mlp_chain): one workgroup = 4 waves = 128 points
+int nudf_mlp_chain_rows_launch(const NudfChain& p, int cls, hipStream_t st) {
+  const dim3 grid((p.P + CHR_WAVES * CHR_ROWS - 1) / (CHR_WAVES * CHR_ROWS)), block(CHR_WAVES * 64);
+  // operand window (tiles in flight per stored-state operand): 4 with one operand; 2 with two operands (3 makes the
+  // register allocator spill ~100 values per step; NUDF_CHAIN_WIN2=3 selects that build for measurements)
+  static const int win2 = [] {
+    const char* e = getenv("NUDF_CHAIN_WIN2");
+    return (e && e[0] == '3') ? 3 : 2;
+  }();
+  if (cls == 0) hipLaunchKernelGGL((mlp_chain_rows_kernel<0, 4>), grid, block, 0, st, p);
+  else if (cls == 1) hipLaunchKernelGGL((mlp_chain_rows_kernel<1, 4>), grid, block, 0, st, p);
+  else if (win2 == 3) hipLaunchKernelGGL((mlp_chain_rows_kernel<2, 3>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((mlp_chain_rows_kernel<2, 2>), grid, block, 0, st, p);
+  NUDF_CHECK_LAUNCH("nudf_mlp_chain(rows)");
+  return 0;
+}

@@ -1,0 +1,52 @@
+// Pieces shared by the two fused-chain kernels (mlp_chain.hip: workgroup-shared 32/64-point tiles;
+// mlp_chain_rows.hip: wave-private 32-point tiles): tile geometry, the positional encoding, softplus derivatives.
+#pragma once
+#include "nudf_common.h"
+#include "../../include/nudf.h"
+
+#define CH_LD 292          // activation row stride in floats (K <= 288): m*292 mod 64 = 36m -> 16 consecutive rows hit
+                           // 16 distinct multiples of 4 -> conflict-free ds_read_b128
+#define CH_THREADS 256
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 ch_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// softplus'(a) = s and 1 - s from the STORED activation h = softplus100(a) / xscale (see gemm_f32_mfma.hip)
+__device__ __forceinline__ void ch_sp_derivs(float hstored, float xscale, float& s, float& om) {
+  const float x = 100.0f * xscale * hstored;
+  if (x > 20.0f) {
+    s = 1.0f;
+    om = 0.0f;
+  } else {
+    const float e = __expf(-x);
+    om = e;
+    s = (x < 0.01f) ? x * (1.0f - x * (0.5f - x * 0.16666667f)) : 1.0f - e;
+  }
+}
+
+// positional-encoding element c of point x (value or JVP with tangent v); same arithmetic as posenc_kernel
+__device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, int L, float in_scale, int jvp) {
+  const int blk = c / 3, j = c - blk * 3;
+  const float xv = x3[j] * in_scale;
+  if (blk == 0) return jvp ? v3[j] * in_scale : xv;
+  const int k = (blk - 1) >> 1;
+  const float f = (float)(1 << k);
+  const float a = xv * f;
+  const bool is_sin = ((blk - 1) & 1) == 0;
+  if (!jvp) return is_sin ? sinf(a) : cosf(a);
+  return (is_sin ? cosf(a) : -sinf(a)) * f * v3[j] * in_scale;
+}
+
+
+// accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#define CH_KOFF(r) (((r) & 3) + 8 * ((r) >> 2))
+
+#define CH_USES_X1(e)                                                                                           \
+  ((e) == NUDF_CH_MULSP || (e) == NUDF_CH_TANGENT || (e) == NUDF_CH_BWD || (e) == NUDF_CH_MULMASK || (e) == NUDF_CH_ADDMASK)
+
+#define CH_USES_X2(e) ((e) == NUDF_CH_TANGENT || (e) == NUDF_CH_BWD || (e) == NUDF_CH_ADDMASK || (e) == NUDF_CH_RELUADD)

@@ -1,0 +1,67 @@
+"""Full-size golden fixture: BASELINE config 2 (512 rays x (64 + 64 hierarchical samples in 4 rounds), P = 65 536
+points per render_core) run through the REFERENCE code itself (imported read-only from /root/reference, build
+container only):
+
+    python tests/golden/make_golden_full.py
+
+Writes tests/golden/ref_cfg2_full.npz (fp16-free, ~7 MB): rays, the reference's sample positions, every per-ray /
+per-sample output the parity test compares, the loss, and the gradient of EVERY parameter that takes part (UDF,
+colour, variance, beta nets).  Weights are rebuilt by the test from the seeds (see make_golden.py)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from common import build_modules, perturb_, state_dicts, checksum  # noqa: E402
+from refload import load_reference  # noqa: E402
+from neuraludf_amd import synth  # noqa: E402
+
+KW = dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)
+N_RAYS = 512
+KEYS = ["z_vals", "color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum",
+        "gradient_error", "gradient_error_near_surface", "sparse_error"]
+
+
+def loss_of(out, rays):
+    return ((out["color"] - rays["true_rgb"]).abs().mean() + 0.5 * (out["color_base"] - rays["true_rgb"]).abs().mean()
+            + 0.1 * out["gradient_error"] + 0.01 * out["gradient_error_near_surface"] + 0.001 * out["sparse_error"])
+
+
+def main():
+    rf, rr, rl = load_reference()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    mods = perturb_(build_modules(rf, seed=0))
+    sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
+    scene = synth.make_scene("tiny")
+    rays = synth.make_rays(scene, 0, N_RAYS, seed=11, margin=6)
+    r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **KW)
+    t0 = time.time()
+    out = r.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7, perturb_overwrite=0,
+                   flip_saturation=0.9)
+    loss = loss_of(out, rays)
+    loss.backward()
+    print("reference fwd+bwd %.1f s, loss %.6f" % (time.time() - t0, loss.item()))
+    data = {"ray_" + k: v.numpy() for k, v in rays.items()}
+    data.update({"out_" + k: out[k].detach().numpy().astype(np.float32) for k in KEYS})
+    data["loss"] = np.float64(loss.item())
+    n = 0
+    for net in ("udf", "color", "var", "beta"):
+        for pn, p in mods[net].named_parameters():
+            if p.grad is not None:
+                data[f"grad_{net}_{pn}"] = p.grad.numpy()
+                n += p.grad.numel()
+    for k, v in sums.items():
+        data["wsum_" + k] = np.float64(v)
+    path = os.path.join(HERE, "ref_cfg2_full.npz")
+    np.savez_compressed(path, **data)
+    print("wrote", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "param-grad floats", n)
+
+
+if __name__ == "__main__":
+    main()
