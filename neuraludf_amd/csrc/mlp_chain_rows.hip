@@ -104,7 +104,8 @@ __device__ __forceinline__ void chr_store_range(chr_gp C, unsigned rowoff, int f
 // Epilogue of one [32 points x 32 features] accumulator tile (bias already inside the accumulator), streamed as four
 // quads of consecutive features: compute -> re-request this quad of the operand window for tile t + CHR_WIN -> store.
 // Features >= N of the last tile need no masking: their accumulators are exactly 0 (zero-padded weight fragments,
-// zero staged bias), every epilogue maps that to a finite value, and such values only ever reach pad columns --
+// zero staged bias), every epilogue maps that to a FINITE value (see the |h| below), and such values only ever reach
+// pad columns --
 // of the LDS tile, where the next step's zero weight rows meet them, and of the [P, ld] buffers, which no consumer
 // reads (operand loads clamp their columns into [0, N)).
 template <int EPI>
@@ -150,13 +151,15 @@ __device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act
       } else if (EPI == NUDF_CH_ADDMASK) {
         o[i] = (x1 > 0.0f) ? (v + x2) * cs.scale : 0.0f;
       } else {
-        const float x = 100.0f * cs.xscale * x1;
+        // 1 - softplus'(a) = exp(-100 h) from the stored activation h >= 0.  |h|: features >= N of the last tile read
+        // a clamped column of X1 that need not be a softplus output (the skip layer's input carries PE values < 0
+        // behind its 217 hidden columns); exp(+70) would overflow to inf and 0 * inf = NaN would reach the tile's
+        // pad columns, where the next step multiplies them by its zero weight rows.  Free (source modifier).
+        const float x = 100.0f * cs.xscale * fabsf(x1);
         const float om = __builtin_amdgcn_exp2f(x * -1.44269504f);
         const float sg = 1.0f - om;
         if (EPI == NUDF_CH_MULSP) {
-          // skip split: the embedding columns (>= iparam) hold PE values in X1, whose "softplus derivative" overflows
-          const bool hid = cs.iparam <= 0 || f0 + i < cs.iparam;
-          o[i] = hid ? v * sg * cs.scale : 0.0f;
+          o[i] = v * sg * cs.scale;               // columns >= iparam (skip split): finite, meet zero weight rows
           o2[i] = v * cs.scale;
         } else if (EPI == NUDF_CH_TANGENT) {
           o[i] = v * sg * cs.scale;

@@ -14,86 +14,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch  # noqa: E402
-from common import build_modules, perturb_  # noqa: E402
+from chain_sweeps import compare, engines, sweeps as _sweeps  # noqa: E402
 from neuraludf_amd import mlp  # noqa: E402
-from neuraludf_amd.models import fields  # noqa: E402
 
 dev = torch.device("cuda:0")
-mods = perturb_(build_modules(fields, seed=0))
-udf = mods["udf"].to(dev)
-col = mods["color"].to(dev)
-nerf = mods["nerf"].to(dev)
-eng = udf.engine()
-ceng = col.engine()
-neng = nerf.engine()
 what = set(sys.argv[1:]) or {"check", "time"}
+eng = engines(dev)["eng"]
 
 
-def sweeps(P, tile, seed=0, S=64):
-    """all chain launches of one train step's MLP work at P points -> dict of result tensors."""
-    mlp.CHAIN_TILE = tile
-    g = torch.Generator().manual_seed(seed)
-    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
-    d_udf = torch.randn(P, generator=g).to(dev)
-    d_g = torch.randn(P, 3, generator=g).to(dev)
-    rays_d = torch.nn.functional.normalize(torch.randn((P + S - 1) // S, 3, generator=g), dim=-1).to(dev)
-    out = {}
-    st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
-    out.update(udf=st["udf"], sign=st["sign"], feat=st["feat"][:, :256], X4=st["X"][4][:P, :256], X8=st["X"][8][:P])
-    gr, DA = eng.gradient(x, st)
-    out.update(g=gr, DA0=DA[0][:P], DA3=DA[3][:P, :217], DA7=DA[7][:P])
-    out["uo"] = eng.forward(x, need_grad_state=False, udf_only=True)["udf"]
-    # colour net on the UDF features
-    CIN = st["feat"]
-    Pc = (P // S) * S
-    cb, cc, logits, cst = ceng.forward(CIN, rays_d, S, Pc)
-    out.update(cb=cb, cc=cc)
-    if logits is not None:
-        out["logits"] = logits
-    d_cb = torch.randn(Pc, 3, generator=g).to(dev)
-    d_cc = torch.randn(Pc, 3, generator=g).to(dev)
-    d_lg = torch.randn(Pc, logits.shape[1], generator=g).to(dev) if logits is not None else None
-    cgr, dCIN = ceng.backward(cst, cb, cc, d_cb, d_cc, d_lg)
-    out["dCIN"] = dCIN[:, :256]
-    for i, t in enumerate(cgr):
-        out[f"cg{i}"] = t
-    d_feat = torch.zeros(P, ceng.cin_ld, device=dev)
-    d_feat[:Pc] = dCIN[:Pc]
-    grads = eng.backward(x, st, DA, d_udf, d_feat, ceng.cin_ld, d_g)
-    for i, t in enumerate(grads):
-        out[f"p{i}"] = t
-    # background NeRF
-    Pn = (min(P, 32768) // S) * S
-    pts4 = torch.randn(Pn, 4, generator=g).to(dev) * 0.5
-    sig, rgb = nerf.evaluate(pts4, rays_d[:Pn // S].contiguous(), S)
-    out.update(nsig=sig.detach(), nrgb=rgb.detach())
-    (sig.sum() + (rgb * torch.randn(rgb.shape, generator=g).to(dev)).sum()).backward()
-    for i, prm in enumerate(nerf.parameters()):
-        if prm.grad is not None:
-            out[f"n{i}"] = prm.grad.detach().clone()
-            prm.grad = None
-    return out
-
-
-def compare(a, b, tag):
-    """value tensors must agree to fp32 rounding; ReLU-net gradients additionally flip whole elements where a
-    pre-activation sits within an ulp of 0 (the two kernels add the bias in a different order), so they are judged by
-    their relative L2 difference and the fraction of elements that moved."""
-    worst, worst_l2, nbit, bad = 0.0, 0.0, 0, []
-    for k in a:
-        d = (a[k] - b[k]).abs()
-        ref = float(a[k].abs().max()) + 1e-30
-        l2 = float(d.double().pow(2).sum().sqrt() / (a[k].double().pow(2).sum().sqrt() + 1e-30))
-        if torch.equal(a[k], b[k]):
-            nbit += 1
-        smooth = k[0] not in "cn" or k in ("cb", "cc", "nsig", "nrgb")       # colour / NeRF gradients have ReLU kinks
-        frac = float((d > 1e-5 * ref).float().mean())
-        worst = max(worst, float(d.max()) / ref if smooth else 0.0)
-        worst_l2 = max(worst_l2, l2)
-        if (smooth and float(d.max()) / ref > 2e-5) or l2 > 2e-3 or frac > 2e-2:
-            bad.append((k, float(d.max()) / ref, l2, frac))
-    print(f"check {tag}: {len(a)} tensors, {nbit} bit-identical, worst rel diff (smooth tensors) {worst:.3e}, "
-          f"worst rel L2 {worst_l2:.3e}", "MISMATCH " + str(bad) if bad else "OK", flush=True)
+def sweeps(P, tile, seed=0):
+    return _sweeps(dev, P, tile, seed)
 
 
 if "check" in what:

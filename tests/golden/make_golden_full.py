@@ -29,8 +29,11 @@ KEYS = ["z_vals", "color", "color_base", "weights", "depth", "udf", "gradients",
 
 
 def loss_of(out, rays):
+    # sparse_error = mean sum exp(-25000 udf) is left out of the differentiated loss: its gradient amplifies an fp32
+    # ulp of udf into percents, for the fp32 reference as much as for any other fp32 evaluation (its value is compared,
+    # its backward is checked on identical inputs in test_gpu_kernels.py::test_composite_stagewise)
     return ((out["color"] - rays["true_rgb"]).abs().mean() + 0.5 * (out["color_base"] - rays["true_rgb"]).abs().mean()
-            + 0.1 * out["gradient_error"] + 0.01 * out["gradient_error_near_surface"] + 0.001 * out["sparse_error"])
+            + 0.1 * out["gradient_error"] + 0.01 * out["gradient_error_near_surface"])
 
 
 def main():

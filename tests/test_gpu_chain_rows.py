@@ -1,0 +1,53 @@
+"""The wave-private fused-chain kernel (csrc/mlp_chain_rows.hip, tile_rows = 128) against the workgroup-shared
+kernel (csrc/mlp_chain.hip) -- the path every oracle test of test_gpu_kernels.py pins -- on the same inputs, for
+every sweep of the three networks: point counts around the 32-point wave tiles and the 128-point workgroups (ragged
+last wave, whole waves without points), and one size with two full rounds of workgroups.
+
+The two kernels run the same products in the same k order; the wave-private one starts its accumulators from the
+bias (bias-first), so values agree to fp32 rounding (2e-5 of the tensor's magnitude), not to the bit.  Gradients of
+the ReLU networks can additionally move by whole elements where a pre-activation lies within an ulp of zero; those
+tensors are held to a relative L2 bound (chain_sweeps.compare)."""
+import pytest
+import torch
+
+from chain_sweeps import compare, sweeps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("P", [1, 31, 33, 97, 128, 129, 1000, 4133])
+def test_rows_kernel_matches_shared_kernel_ragged_sizes(dev, P):
+    a = sweeps(dev, P, 64, seed=P)
+    b = sweeps(dev, P, 128, seed=P)
+    assert set(a) == set(b)
+    bad, nbit, worst, worst_l2 = compare(a, b, f"P={P}", verbose=False, l2_tol=max(3e-3, 10.0 / P))
+    assert not bad, bad
+    for k in a:
+        assert bool(torch.isfinite(b[k]).all()), k
+
+
+def test_rows_kernel_two_rounds_and_rerun_is_deterministic(dev):
+    P = 128 * 300 + 77
+    a = sweeps(dev, P, 64, seed=3)
+    b = sweeps(dev, P, 128, seed=3)
+    c = sweeps(dev, P, 128, seed=3)
+    bad, _, worst, worst_l2 = compare(a, b, f"P={P} shared vs rows", verbose=True)
+    assert not bad, bad
+    # the chains themselves are run-to-run identical (only the weight-gradient GEMMs use fp32 atomics)
+    for k in ("udf", "feat", "X8", "g", "DA0", "uo", "cb", "cc", "dCIN", "nsig", "nrgb"):
+        assert torch.equal(b[k], c[k]), k
+
+
+def test_rows_kernel_is_the_one_that_ran(dev):
+    """tile_rows = 128 must reach the wave-private kernel: its bias-first summation differs from the shared kernel's
+    in the last bits, so bit-identical results would mean a silent fall-back."""
+    a = sweeps(dev, 4096, 64, seed=9)
+    b = sweeps(dev, 4096, 128, seed=9)
+    assert not torch.equal(a["feat"], b["feat"])
+    assert float((a["feat"] - b["feat"]).abs().max()) < 2e-5 * float(a["feat"].abs().max())
