@@ -224,6 +224,25 @@ typedef struct NudfPatchBlend {   /* patch_projector.py:45-164, fields.py:521-53
 int nudf_patch_blend_fwd(const NudfPatchBlend* a, void* stream);
 int nudf_patch_blend_bwd(const NudfPatchBlend* a, const float* d_patch, float* d_logits, float* d_w, void* stream);
 
+/* Un-fused warps = the reference's projector interface itself (PatchProjector.pixel_warp / .patch_warp,
+ * models/patch_projector.py:21-43, 45-164): per-VIEW samples and validity masks, forward only (the reference builds
+ * the homographies under no_grad and the sample positions carry no gradient to any parameter).  The training path
+ * uses the fused kernels above and never materialises these tensors. */
+int nudf_pixel_warp(const NudfPixelBlend* a /* logits, pix unused */, float* colors /* [P,V,3] */,
+                    float* mask /* [P,V] 0/1 */, void* stream);
+typedef struct NudfPatchWarp {
+  const float* pts;               /* [N,S,3]                                                */
+  const float* normals;           /* [N,S,3] plane normals in world space                   */
+  const float* uv;                /* [N,2] ray pixel in the reference image (pixel units)   */
+  const float* ref_cam;           /* [24], as in NudfPatchBlend                             */
+  const float* src_cam;           /* [V,24]                                                 */
+  const float* imgs;              /* [V,3,H,W] (img_layout 0) or [V,H,W,3] (img_layout 1)   */
+  int32_t N, S, V, H, W, hps, img_layout;
+  float* colors;                  /* [N,S,V,(2h+1)^2,3]                                     */
+  float* mask;                    /* [N,S,V,(2h+1)^2] 0/1                                   */
+} NudfPatchWarp;
+int nudf_patch_warp(const NudfPatchWarp* a, void* stream);
+
 /* loss/patch_metric.py:21-41, 76-84; d_out/d_pred NULL = forward only */
 int nudf_ssim_patch(const float* pred, const float* gt, const float* window, int N, int Npx, float* out,
                     const float* d_out, float* d_pred, void* stream);

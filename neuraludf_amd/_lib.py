@@ -102,6 +102,12 @@ class PatchBlend(C.Structure):
                 ("patch_colors", c_fp), ("patch_mask", c_fp), ("img_layout", i32)]
 
 
+class PatchWarp(C.Structure):
+    _fields_ = [("pts", c_fp), ("normals", c_fp), ("uv", c_fp), ("ref_cam", c_fp), ("src_cam", c_fp), ("imgs", c_fp),
+                ("N", i32), ("S", i32), ("V", i32), ("H", i32), ("W", i32), ("hps", i32), ("img_layout", i32),
+                ("colors", c_fp), ("mask", c_fp)]
+
+
 ADAM_MAX_TENSORS = 64
 ADAM_MAX_GROUPS = 4
 
@@ -177,7 +183,7 @@ SYMBOLS = [
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
     "nudf_pixel_blend_fwd", "nudf_pixel_blend_bwd", "nudf_pixel_composite_fwd", "nudf_pixel_composite_bwd",
-    "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch",
+    "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch", "nudf_pixel_warp", "nudf_patch_warp",
     "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
     "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
     "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
@@ -213,6 +219,8 @@ _ARGTYPES = {
     "nudf_pixel_composite_bwd": [C.POINTER(PixelComposite), _P, _P, _P, _P, _P, _P],
     "nudf_patch_blend_fwd": [C.POINTER(PatchBlend), _P],
     "nudf_patch_blend_bwd": [C.POINTER(PatchBlend), _P, _P, _P, _P],
+    "nudf_pixel_warp": [C.POINTER(PixelBlend), _P, _P, _P],
+    "nudf_patch_warp": [C.POINTER(PatchWarp), _P],
     "nudf_ssim_patch": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "nudf_adam_step": [C.POINTER(Adam), _P],
     "nudf_mlp_chain": [C.POINTER(Chain), _P],

@@ -165,6 +165,47 @@ extern "C" int nudf_pixel_blend_bwd(const NudfPixelBlend* a, const float* d_pix,
 }
 
 // ------------------------------------------------------------------------------------------
+// un-fused warps: PatchProjector.pixel_warp / .patch_warp return the PER-VIEW samples (the reference's projector API,
+// models/patch_projector.py:21-43, 45-164).  The training path never materialises them (see the fused kernels);
+// these two forward-only kernels exist for callers of the projector interface itself.
+// ------------------------------------------------------------------------------------------
+__global__ void pixel_warp_kernel(NudfPixelBlend p, float* __restrict__ colors, float* __restrict__ mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.P) return;
+  const float x = p.pts[(size_t)i * 3 + 0], y = p.pts[(size_t)i * 3 + 1], z = p.pts[(size_t)i * 3 + 2];
+  const int V = p.V, H = p.H, W = p.W;
+  FORV(v) {
+    const float* pr = p.proj + v * 12;
+    const float X = pr[0] * x + pr[1] * y + pr[2] * z + pr[3];
+    const float Y = pr[4] * x + pr[5] * y + pr[6] * z + pr[7];
+    const float Z = fmaxf(pr[8] * x + pr[9] * y + pr[10] * z + pr[11], 1e-3f);
+    float xn = 2.0f * (X / Z) / (float)(W - 1) - 1.0f;
+    float yn = 2.0f * (Y / Z) / (float)(H - 1) - 1.0f;
+    if (xn > 1.0f || xn < -1.0f) xn = 2.0f;   // projector_utils.py:39-43
+    if (yn > 1.0f || yn < -1.0f) yn = 2.0f;
+    const bool m = (fabsf(xn) < 1.0f) && (fabsf(yn) < 1.0f);
+    const float ix = (xn + 1.0f) * 0.5f * (float)(W - 1);
+    const float iy = (yn + 1.0f) * 0.5f * (float)(H - 1);
+    float col[3];
+    if (p.img_layout) bilinear3<true>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col);
+    else bilinear3<false>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col);
+    const size_t o = (size_t)i * V + v;
+    colors[o * 3] = col[0]; colors[o * 3 + 1] = col[1]; colors[o * 3 + 2] = col[2];
+    mask[o] = m ? 1.0f : 0.0f;
+  }
+}
+extern "C" int nudf_pixel_warp(const NudfPixelBlend* a, float* colors, float* mask, void* stream) {
+  if (a->P <= 0) return 0;
+  if (a->V > MAXV) {
+    nudf_set_error("nudf_pixel_warp: too many views", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(pixel_warp_kernel, dim3((a->P + 127) / 128), dim3(128), 0, (hipStream_t)stream, *a, colors, mask);
+  NUDF_CHECK_LAUNCH("nudf_pixel_warp");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // composite of the blended pixel colours (with the inside/background mix of :503-506): one wave per ray
 //   x_s = pix_s*inside_s + bg_in_s*(1-inside_s)  (s < S, only when a background exists) ; x_s = bg_tail (s >= S)
 //   out = sum_s w_s x_s
@@ -450,6 +491,85 @@ extern "C" int nudf_patch_blend_bwd(const NudfPatchBlend* a, const float* d_patc
     else hipLaunchKernelGGL((patch_blend_kernel<true, 2, 4>), grid, block, 0, st, *a, d_patch, d_logits, d_w);
   }
   NUDF_CHECK_LAUNCH("nudf_patch_blend_bwd");
+  return 0;
+}
+
+// one wave per (ray, sample); lanes over the (2h+1)^2 patch pixels (PC chunks of 64).  Same plane-induced
+// homographies as patch_blend_kernel, but the plane normal is the caller's `normals` (patch_projector.py:99-131).
+template <int PC>
+__global__ __launch_bounds__(256) void patch_warp_kernel(NudfPatchWarp p) {
+  const int l = threadIdx.x & 63;
+  const long long sidx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sidx >= (long long)p.N * p.S) return;
+  const int ray = (int)(sidx / p.S);
+  const int V = p.V, H = p.H, W = p.W, h = p.hps, ws = 2 * p.hps + 1, Npx = ws * ws;
+  const float* ref = p.ref_cam;
+  const float u0 = p.uv[ray * 2], v0 = p.uv[ray * 2 + 1];
+  const float px = p.pts[sidx * 3], py = p.pts[sidx * 3 + 1], pz = p.pts[sidx * 3 + 2];
+  const float nx = p.normals[sidx * 3], ny = p.normals[sidx * 3 + 1], nz = p.normals[sidx * 3 + 2];
+  const float* Rr = ref + 9;
+  const float rn[3] = {Rr[0] * nx + Rr[1] * ny + Rr[2] * nz, Rr[3] * nx + Rr[4] * ny + Rr[5] * nz,
+                       Rr[6] * nx + Rr[7] * ny + Rr[8] * nz};
+  const float pr[3] = {Rr[0] * px + Rr[1] * py + Rr[2] * pz + ref[18], Rr[3] * px + Rr[4] * py + Rr[5] * pz + ref[19],
+                       Rr[6] * px + Rr[7] * py + Rr[8] * pz + ref[20]};
+  const float d1 = rn[0] * pr[0] + rn[1] * pr[1] + rn[2] * pr[2];
+  const float sgn = (d1 < 0.0f) ? -1.0f : 1.0f;
+  const float dd = fmaxf(fabsf(d1), 1e-8f) * sgn;
+  const float ex = px - ref[21], ey = py - ref[22], ez = pz - ref[23];
+  const float sdist = sqrtf(ex * ex + ey * ey + ez * ez);
+  FORV(v) {
+    const float* cam = p.src_cam + v * 24;
+    const float* Ks = cam;
+    const float* Rl = cam + 9;
+    const float* tl = cam + 18;
+    const float* c2 = cam + 21;
+    const float d2 = rn[0] * c2[0] + rn[1] * c2[1] + rn[2] * c2[2];
+    const bool valid_h = (fabsf(d1) > 1e-3f) && (fabsf(d1 - d2) > 1e-3f) && ((d2 / d1) < 1.0f);
+    const float q0 = valid_h ? rn[0] / dd : 0.0f, q1 = valid_h ? rn[1] / dd : 0.0f, q2 = valid_h ? rn[2] / dd : 1.0f / sdist;
+    float M1[9], M2[9], Hm[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      M1[i * 3 + 0] = Rl[i * 3 + 0] + tl[i] * q0;
+      M1[i * 3 + 1] = Rl[i * 3 + 1] + tl[i] * q1;
+      M1[i * 3 + 2] = Rl[i * 3 + 2] + tl[i] * q2;
+    }
+    mat3_mul(Ks, M1, M2);
+    mat3_mul(M2, ref, Hm);
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      const int pi = c * 64 + l;
+      if (pi >= Npx) continue;
+      const float hx = u0 + (float)((pi % ws) - h), hy = v0 + (float)((pi / ws) - h);
+      const float t0 = Hm[0] * hx + Hm[1] * hy + Hm[2];
+      const float t1 = Hm[3] * hx + Hm[4] * hy + Hm[5];
+      const float t2 = Hm[6] * hx + Hm[7] * hy + Hm[8];
+      const float den = fmaxf(t2, 1e-8f);
+      const float gxp = t0 / den, gyp = t1 / den;
+      const bool mk = (t2 > 0.0f) && (gxp < (float)(W - h)) && (gyp < (float)(H - h)) && (gxp >= (float)h) && (gyp >= (float)h);
+      const float xn = fminf(fmaxf(2.0f * gxp / (float)(W - 1) - 1.0f, -10.0f), 10.0f);
+      const float yn = fminf(fmaxf(2.0f * gyp / (float)(H - 1) - 1.0f, -10.0f), 10.0f);
+      const float ix = (xn + 1.0f) * 0.5f * (float)(W - 1), iy = (yn + 1.0f) * 0.5f * (float)(H - 1);
+      float col[3];
+      if (p.img_layout) bilinear3<true>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col);
+      else bilinear3<false>(p.imgs + (size_t)v * 3 * H * W, H, W, ix, iy, col);
+      const size_t o = ((size_t)sidx * V + v) * Npx + pi;
+      p.colors[o * 3] = col[0]; p.colors[o * 3 + 1] = col[1]; p.colors[o * 3 + 2] = col[2];
+      p.mask[o] = mk ? 1.0f : 0.0f;
+    }
+  }
+}
+extern "C" int nudf_patch_warp(const NudfPatchWarp* a, void* stream) {
+  if (a->N <= 0 || a->S <= 0) return 0;
+  const int npx = (2 * a->hps + 1) * (2 * a->hps + 1);
+  if (a->V > MAXV || npx > 128) {
+    nudf_set_error("nudf_patch_warp: V <= 10 and h_patch_size <= 5 required", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  const long long n = (long long)a->N * a->S;
+  dim3 grid((unsigned)((n + 3) / 4)), block(256);
+  if (npx <= 64) hipLaunchKernelGGL(patch_warp_kernel<1>, grid, block, 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(patch_warp_kernel<2>, grid, block, 0, (hipStream_t)stream, *a);
+  NUDF_CHECK_LAUNCH("nudf_patch_warp");
   return 0;
 }
 

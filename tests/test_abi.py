@@ -29,7 +29,7 @@ def test_ctypes_structs_match_header_field_counts():
     for cname, st in [("NudfGemmNN", _lib.GemmNN), ("NudfGemmTN", _lib.GemmTN), ("NudfComposite", _lib.Composite),
                       ("NudfCompositeGrad", _lib.CompositeGrad), ("NudfUpsample", _lib.Upsample),
                       ("NudfPixelBlend", _lib.PixelBlend), ("NudfPixelComposite", _lib.PixelComposite),
-                      ("NudfPatchBlend", _lib.PatchBlend), ("NudfAdamTensor", _lib.AdamTensor),
+                      ("NudfPatchBlend", _lib.PatchBlend), ("NudfPatchWarp", _lib.PatchWarp), ("NudfAdamTensor", _lib.AdamTensor),
                       ("NudfAdamGroup", _lib.AdamGroup), ("NudfChainStep", _lib.ChainStep), ("NudfRayBatch", _lib.RayBatch)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
