@@ -54,7 +54,7 @@ WORKLOADS = {
 BLEND_WORKLOADS = {"garment_blend_1024x128": dict(color_pixel_weight=0.5, color_patch_weight=0.1)}
 
 
-def cpu_baseline(workload, seconds_budget=15.0, dev=None, precision="fp32"):
+def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_rays=None):
     """the oracle's full train step (fwd + loss + bwd + Adam) on the host cores, bounded sample; and, with `dev`, the
     second half of BASELINE's metric: PSNR of the HIP path's colours against the oracle's on the same rays and weights
     (the oracle is the checker here, nothing else)."""
@@ -62,8 +62,9 @@ def cpu_baseline(workload, seconds_budget=15.0, dev=None, precision="fp32"):
     from neuraludf_amd.train import DTU_MODEL_CONF  # noqa: F401
     from oracle import udf_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    _, rconf, scene_kind = WORKLOADS[workload]
-    n_rays = 64
+    rays_cfg, rconf, scene_kind = WORKLOADS[workload]
+    # the timed configuration's own ray count (512 for the headline): a warm-up + >= 3 full steps fit the budget
+    n_rays = int(n_rays or min(rays_cfg, 512))
     # seeded reference-identical init through the drop-in modules (CPU construction only, no kernels)
     from neuraludf_amd.models import fields
     from common import build_modules, state_dicts
@@ -88,13 +89,19 @@ def cpu_baseline(workload, seconds_budget=15.0, dev=None, precision="fp32"):
         rend = UDFRendererBlending(g["nerf"], g["udf"], g["var"], g["color"], g["beta"], **rconf)
         with torch.no_grad():
             got = rend.render(rays["rays_o"].to(dev), rays["rays_d"].to(dev), rays["near"].to(dev), rays["far"].to(dev),
-                              cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)["color"].cpu()
+                              cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
+            got = {k: got[k].cpu() for k in ("color", "z_vals")}
             ref = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
-                           flip_saturation=1.0)["color"]
-        mse = float(((got - ref) ** 2).mean())          # exp_runner_blending.py:341-342 with mask = 1
-        psnr = {"value_db": 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-30)), "max_abs_diff": float((got - ref).abs().max()),
-                "rays": n_rays, "samples_per_ray": s_core, "precision": precision,
-                "what": "HIP colours vs oracle colours, identical rays / weights / sample positions"}
+                           flip_saturation=1.0)
+        mse = float(((got["color"] - ref["color"]) ** 2).mean())          # exp_runner_blending.py:341-342 with mask = 1
+        same = (got["z_vals"] - ref["z_vals"]).abs().max(dim=1)[0] < 1e-4
+        psnr = {"value_db": 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-30)),
+                "max_abs_diff": float((got["color"] - ref["color"]).abs().max()),
+                "max_abs_diff_on_rays_with_identical_samples": float((got["color"] - ref["color"])[same].abs().max()) if bool(same.any()) else None,
+                "rays": n_rays, "rays_with_identical_samples": int(same.sum()), "samples_per_ray": s_core, "precision": precision,
+                "what": "HIP colours vs oracle colours END TO END on identical rays / weights: the hierarchical sampling runs "
+                        "on both sides, so rays whose quantile bins flip (tests/test_gpu_fullsize_parity.py) enter with "
+                        "different sample positions"}
 
     def step():
         t_rand = torch.rand(n_rays, 1) - 0.5
@@ -124,14 +131,14 @@ def cpu_baseline(workload, seconds_budget=15.0, dev=None, precision="fp32"):
     step()  # warm-up
     times = []
     t_start = time.time()
-    while len(times) < 40 and (time.time() - t_start) < seconds_budget:
+    while len(times) < 40 and (len(times) < 3 or (time.time() - t_start) < seconds_budget):
         t0 = time.time()
         step()
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
     res = {"value": n_rays * s_core / med, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
-           "kind": "port", "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps "
+           "kind": "port", "rays": n_rays, "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps "
                                      f"(oracle/udf_oracle.py, fp32, median {med:.3f} s/step)"}
     return res, psnr
 
@@ -206,8 +213,17 @@ def main():
     for _ in range(args.warmup):
         tr.step(batch, **step_kw)
     torch.cuda.synchronize()
+    # A generation-2 pass of Python's cyclic GC over the ~10^6 objects a torch process holds takes ~80 ms of host time
+    # (measured, scripts/fwd_only_probe.py: it is what made the forward-only figure of round 1 read 6.26 ms on one box
+    # and 2.29 ms on the next -- that pass is host-bound at ~1 ms of enqueueing per 2.3 ms of kernels).  Freeze the
+    # set-up objects into the permanent generation, as a training loop should: the timed regions then see only the
+    # cheap young-generation collections.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     torch.cuda.synchronize()
+    nd.collective_counts(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.step(batch, **step_kw)
@@ -222,6 +238,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * rays_per_gpu * s_core / (dt / args.steps)
+    coll = nd.collective_counts()
 
     result = {
         "metric": "ray-samples/sec (train step)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
@@ -233,6 +250,10 @@ def main():
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
                    "step": "render + L1/eikonal loss + backward + Adam", "parallelism": f"ray-sharded dp{world}",
                    "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam"},
+        # data-parallel exchange of the timed region (neuraludf_amd/dist.py): packed loss sums + gradient bucket
+        "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend if world > 1 else None,
+        "collectives_per_step": {k: v / args.steps for k, v in coll.items()} if world > 1 else None,
+        "gradient_message_floats": (tr.bucket.last_message_floats if world > 1 else None),
     }
 
     # ---- forward only ("also forward-only ray-samples/s"): the same batch rendered without autograd, all
@@ -279,6 +300,7 @@ def main():
         result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
                                  "tflops": v[1] / v[2] / 1e12} for k, v in agg.items()}
         result["roofline"]["traffic"] = pmc_traffic(dom, args.workload) if args.precision == "fp32" else None
+        result["roofline"]["traffic_source"] = getattr(pmc_traffic, "source", None) if result["roofline"]["traffic"] else None
         # ---- fused composite kernel alone (HBM roof) ----
         try:
             result["roofline_composite"] = composite_roofline(dev, rays_per_gpu, s_core)
@@ -287,7 +309,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"], psnr = cpu_baseline(args.workload, dev=dev, precision=args.precision)
+            result["cpu_baseline"], psnr = cpu_baseline(args.workload, dev=dev, precision=args.precision, n_rays=rays_per_gpu)
             if psnr is not None:
                 result["psnr_vs_ref"] = psnr
         except Exception as ex:  # pragma: no cover - the GPU numbers above must still be reported
@@ -308,9 +330,11 @@ def pmc_traffic(kernel, workload):
     prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
     if workload != "dtu_scan24_512x128":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % kernel)
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic_%s.json" % (r, kernel)) for r in (2, 1))
+                 if os.path.exists(q)), None)
+    if path is None:
         return None
+    pmc_traffic.source = os.path.relpath(path, ROOT) + " (rocprofv3 PMC passes recorded beforehand, scripts/pmc_traffic.sh)"
     try:
         d = json.load(open(path))
         f = w = n = 0
@@ -326,8 +350,9 @@ def pmc_traffic(kernel, workload):
 
 
 def composite_roofline(dev, N, S, reps=50):
-    """time nudf_composite_fwd / _bwd alone on resident inputs (L2/MALL-resident at this size; the
-    larger 8192x256 shape is reported next to it)."""
+    """time nudf_composite_fwd alone on resident inputs at the step's own size and at two larger ones.  Only a working
+    set beyond the 256 MB Infinity Cache is labelled "hbm" (the launches re-read the same buffers): the step's own
+    size is L2-resident and launch-bound, 8192 x 256 (101 MB) is MALL-resident."""
     from neuraludf_amd.models.udf_renderer_blending import _CompositeFn
     out = {}
     for (n, s) in [(N, S), (8192, 256), (32768, 256)]:
@@ -370,7 +395,8 @@ def composite_roofline(dev, N, S, reps=50):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
         bytes_fwd = 48.0 * n * s + 68.0 * n
-        out[f"fwd_{n}x{s}"] = {"bound": "hbm", "achieved": bytes_fwd / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+        level = "hbm" if bytes_fwd > 256e6 else ("mall (256 MB Infinity Cache resident)" if bytes_fwd > 32e6 else "l2 / launch latency")
+        out[f"fwd_{n}x{s}"] = {"bound": level, "achieved": bytes_fwd / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_fwd / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                "avg_launch_us": us, "algorithmic_bytes": bytes_fwd}
     return out

@@ -32,8 +32,14 @@ def latest_checkpoint(base_exp_dir, end_iter=None):
     d = os.path.join(base_exp_dir, "checkpoints")
     if not os.path.isdir(d):
         return None
-    names = sorted(n for n in os.listdir(d) if n.endswith(".pth") and n.startswith("ckpt_")
-                   and (end_iter is None or int(n[5:-4]) <= end_iter))
+    def keep(n):
+        if not n.endswith("pth"):                 # the reference's own test: model_name[-3:] == 'pth' -- any name
+            return False
+        if end_iter is None:
+            return True
+        digits = n[5:-4]
+        return n.startswith("ckpt_") and digits.isdigit() and int(digits) <= end_iter
+    names = sorted(n for n in os.listdir(d) if keep(n))
     return names[-1] if names else None
 
 
@@ -41,7 +47,8 @@ def load_checkpoint(path, nerf, udf_network, variance_network, color_network, be
                     map_location=None, is_finetune=False):
     """-> iter_step (0 when fine-tuning, :483-484).  Loading bumps the parameters' version counters (load_state_dict
     copies in place), which is what invalidates the packed-weight caches of the MLP engines."""
-    ckpt = torch.load(path, map_location=map_location)
+    # weights_only=False: the reference runner stores numpy floats (its learning rates) in the optimizer state
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
     nerf.load_state_dict(ckpt["nerf"])
     udf_network.load_state_dict(ckpt["udf_network_fine"])
     variance_network.load_state_dict(ckpt["variance_network_fine"])

@@ -75,10 +75,43 @@ class _ColorLossFn(torch.autograd.Function):
         return d_cb, d_c, None, None, None, None, None, None
 
 
+class _ColorLossFromSumsFn(torch.autograd.Function):
+    """second half of the ray-sharded fused ColorLoss: the GLOBAL sums [sum|cb-gt|, sum|c-gt|, D] (already all-reduced,
+    packed with the renderer's sums by the caller, dist.py (1)) -> (total, color_base_loss, color_loss); the backward
+    differentiates the global loss w.r.t. the LOCAL rays (global denominator), one launch."""
+
+    @staticmethod
+    def forward(ctx, cb, c, gt, sums, has_mask, w_b, w_c, w_px):
+        from .._lib import call, ptr
+        ctx.set_materialize_grads(False)
+        cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
+        out = torch.empty(3, device=cb_.device)
+        den = torch.empty(1, device=cb_.device)
+        call("nudf_color_loss_finish", ptr(sums.detach().contiguous()), 1 if has_mask else 0, float(w_b), float(w_c),
+             float(w_px), ptr(out), ptr(den))
+        ctx.save_for_backward(cb_, c_, gt_, den)
+        ctx.w = (float(w_b), float(w_c), float(w_px))
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, d0, d1, d2):
+        from .._lib import call, ptr
+        cb_, c_, gt_, den = ctx.saved_tensors
+        if d0 is None and d1 is None and d2 is None:
+            return (None,) * 8
+        z = den.new_zeros(())
+        d_out = torch.stack([d if d is not None else z for d in (d0, d1, d2)])
+        d_cb, d_c = torch.empty_like(cb_), torch.empty_like(c_)
+        call("nudf_color_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), *ctx.w, ptr(d_out), ptr(d_cb),
+             ptr(d_c))
+        return d_cb, d_c, None, None, None, None, None, None
+
+
 def _l1_sum(pred, gt):
-    if pred.is_cuda and pred.dtype == torch.float32 and gt.shape == pred.shape and gt.dtype == torch.float32:
-        return _L1SumFn.apply(pred, gt)
-    return (pred - gt).abs().sum()       # host tensors: only the world_size-2 CPU test of the sharding algebra
+    if not (pred.is_cuda and pred.dtype == torch.float32 and gt.shape == pred.shape and gt.dtype == torch.float32):
+        from .._lib import NudfError
+        raise NudfError("ColorLoss runs on fp32 CUDA tensors (no host path)")
+    return _L1SumFn.apply(pred, gt)
 
 
 class ColorPixelLoss(nn.Module):
@@ -128,15 +161,13 @@ class ColorPatchLoss(nn.Module):
 
 
 def _global_trimmed_mean(error, m, ratio):
-    import torch.distributed as dist
-    w = nudf_dist.world_size()
-    errs = [torch.zeros_like(error) for _ in range(w)]
-    ms = [torch.zeros_like(m, dtype=torch.float32) for _ in range(w)]
-    dist.all_gather(errs, error.detach())
-    dist.all_gather(ms, m.float())
-    errs[nudf_dist.rank()] = error                                       # keep the local autograd edge
-    e = torch.cat(errs)
-    mm = torch.cat(ms).bool()
+    """order statistics over the WHOLE ray batch: one all-gather of the per-ray (error, mask) pairs, then the same
+    trim on every rank; the local rows keep their autograd edge."""
+    n, r = error.shape[0], nudf_dist.rank()
+    both = nudf_dist.all_gather_rows(torch.stack([error.detach().to(torch.float32), m.to(torch.float32)], dim=1))
+    e = both[:, 0].to(error.dtype)
+    e = torch.cat([e[:r * n], error, e[(r + 1) * n:]])                    # keep the local autograd edge
+    mm = both[:, 1] > 0.5
     es, idx = torch.sort(e, descending=True)
     mk = mm[idx].clone()
     mk[:int(ratio * mk.sum())] = False
@@ -164,6 +195,27 @@ class ColorLoss(nn.Module):
         self.color_weight = color_weight
         self.color_pixel_weight = color_pixel_weight
         self.color_patch_weight = color_patch_weight
+
+    # ---- ray-sharded two-phase form: the caller packs `local_sums` with its other batch-global partial sums into ONE
+    # all-reduce (dist.py (1)) and hands the global values to `from_global_sums` -----------------------------------
+    def fusable(self, color_base, color, gt_color, color_pixel, patch_colors):
+        return (color_base is not None and color is not None and color_pixel is None and patch_colors is None
+                and color.is_cuda and color.dtype == torch.float32 and color.shape == gt_color.shape == color_base.shape)
+
+    def local_sums(self, color_base, color, gt_color, pixel_mask):
+        """-> [sum|cb-gt|, sum|c-gt|, mask count (or element count)] of the LOCAL rays, no autograd."""
+        from .._lib import call, ptr
+        cb_, c_, gt_ = color_base.detach().contiguous(), color.detach().contiguous(), gt_color.detach().contiguous()
+        m_ = pixel_mask.detach().float().contiguous() if pixel_mask is not None else None
+        sums = torch.empty(3, device=cb_.device)
+        call("nudf_color_loss_sums", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_), m_.numel() if m_ is not None else 0,
+             ptr(sums))
+        return sums
+
+    def from_global_sums(self, color_base, color, gt_color, pixel_mask, sums):
+        total, lb, lc = _ColorLossFromSumsFn.apply(color_base, color, gt_color, sums, pixel_mask is not None,
+                                                   self.color_base_weight, self.color_weight, self.color_pixel_weight)
+        return {'loss': total, 'color_base_loss': lb, 'color_loss': lc, 'color_pixel_loss': 0.0, 'color_patch_loss': 0.0}
 
     def forward(self, color_base, color, gt_color, color_pixel, pixel_mask, patch_colors, gt_patch_colors, patch_mask):
         if (color_base is not None and color is not None and color_pixel is None and patch_colors is None

@@ -281,6 +281,13 @@ class PackedLinear:
         self._frags = {}
         return self
 
+    def invalidate(self):
+        """forget the packed weights.  The cache is keyed on the parameters' (data_ptr, _version); in-place writes
+        through `p.data` (p.data.copy_(), EMA, manual re-initialisation) do NOT bump `_version`, so whoever does that
+        must call this (or `module.invalidate()` / `engine.invalidate()`)."""
+        self._ver = None
+        self._frags = {}
+
     def frag(self, kind):
         """fragment-ordered copies for the fused chains (cached until the parameters change):
         'fwd'  B = W^T [inp, out]            'bwd'  B = W [out, inp]
@@ -441,9 +448,26 @@ def pack_group(layers, kinds=None):
         pl._ver = pl._new_ver
 
 
-def unpack_group(layers, grads):
-    """packed (dW, db) per layer -> parameter gradients in params() order, ONE launch per <= 16 layers."""
+def unpack_group(layers, grads, slot=None):
+    """packed (dW, db) per layer -> parameter gradients in params() order, ONE launch per <= 16 layers.
+    `slot`: optional flat fp32 tensor of exactly sum(p.numel() for the layers' params) elements (a segment of the
+    data-parallel gradient bucket, dist.GradBucket): the kernel then writes dv / dg / db straight into it and the
+    returned gradients are views of it, so the all-reduce needs no `cat` and no copy back."""
     out_per_layer = []
+    off = 0
+    if slot is not None:
+        need = sum(p.numel() for pl in layers for p in pl.params())
+        if slot.numel() != need or slot.dtype != torch.float32 or not slot.is_contiguous():
+            raise _lib.NudfError("gradient slot has %d elements, the layers need %d" % (slot.numel(), need))
+
+    def take(shape_like):
+        nonlocal off
+        if slot is None:
+            return torch.empty_like(shape_like)
+        n = shape_like.numel()
+        v = slot[off:off + n].view(shape_like.shape)
+        off += n
+        return v
     for base in range(0, len(layers), _lib.PACK_MAX_LAYERS):
         chunk = layers[base:base + _lib.PACK_MAX_LAYERS]
         a = _lib.UnpackMulti()
@@ -453,23 +477,22 @@ def unpack_group(layers, grads):
             dW, db = grads[base + li]
             ps = pl.params()
             v = ps[0].detach().contiguous()
-            dv = torch.empty_like(v)
+            dv = take(v)
             L = a.layer[li]
             L.dW, L.v, L.perm, L.dv = ptr(dW), ptr(v), ptr(pl.perm), ptr(dv)
             L.out, L.in_, L.ldw, L.row_start = pl.out, pl.inp, pl.in_pad, rows
-            dbo = torch.empty(pl.out, device=v.device)      # fresh tensor: autograd takes it without a clone
-            L.db_in, L.db_out = ptr(db), ptr(dbo)
-            keep.append(db)
-            db = dbo
+            dg = None
             if pl.weight_norm:
                 g = ps[1].detach().contiguous()
-                dg = torch.empty_like(g)
+                dg = take(g)
                 L.g, L.inv_norm, L.dg = ptr(g), ptr(pl.inv_norm), ptr(dg)
-                out_per_layer.append([dv, dg, db])
                 keep += [v, g]
             else:
-                out_per_layer.append([dv, db])
                 keep += [v]
+            dbo = take(ps[-1].detach())         # fresh tensor (or bucket view): autograd takes it without a clone
+            L.db_in, L.db_out = ptr(db), ptr(dbo)
+            keep.append(db)
+            out_per_layer.append([dv, dg, dbo] if pl.weight_norm else [dv, dbo])
             rows += pl.out
         a.n_layers, a.total_rows = len(chunk), rows
         call("nudf_weightnorm_unpack_grad_multi", a)
@@ -495,6 +518,10 @@ class UDFEngine:
         for pl in self.layers:
             out += pl.params()
         return out
+
+    def invalidate(self):
+        for pl in self.layers:
+            pl.invalidate()
 
     def _embed(self, x, P, X, tangent=None):
         net = self.net
@@ -712,14 +739,14 @@ class UDFEngine:
                     sg4[:P, 0] = sign * inv_scale  # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
                     jobs.append((sg4, 1, R[L], plL.in_pad, dWL[:1], None))
                 gemm_tn_grouped(jobs, P)
-            return unpack_group(layers, grads)
+            return unpack_group(layers, grads, getattr(self, "grad_slot", None))
         for l, pl in enumerate(layers):
             dW, db = grads[l]
             if second and l < L:
                 gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db, A2=DA[l], na2=pl.out, B2=R[l])
             else:
                 gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db)
-        return unpack_group(layers, grads)
+        return unpack_group(layers, grads, getattr(self, "grad_slot", None))
 
     def _forward_layers(self, x, need_grad_state, feat_ld=0, udf_only=False):
         """per-layer GEMM launches.  x [P,3] -> dict(udf [P], sign [P], feat [P, max(feat_ld, F)], state...).
@@ -882,6 +909,10 @@ class ColorEngine:
             out += pl.params()
         return out
 
+    def invalidate(self):
+        for pl in self.view + self.base:
+            pl.invalidate()
+
     @property
     def cin_ld(self):
         return pad32(self.F + 3)
@@ -992,7 +1023,7 @@ class ColorEngine:
         for i, pl in enumerate(self.base):
             jobs.append((Db[i], pl.out, HB[i], pl.in_pad, grads[n + i][0], grads[n + i][1]))
         gemm_tn_grouped(jobs, P)
-        return unpack_group(self.view + self.base, grads), dCIN[:P]
+        return unpack_group(self.view + self.base, grads, getattr(self, "grad_slot", None)), dCIN[:P]
 
     def _forward_layers(self, CIN, rays_d, S, P, keep_state=True):
         """CIN [P, pad(F+3)] = [feature F | pts 3 | 0] (written by the UDF head + nudf_copy_cols)."""
@@ -1149,6 +1180,10 @@ class NerfEngine:
             out += pl.params()
         return out
 
+    def invalidate(self):
+        for pl in self._all():
+            pl.invalidate()
+
     # -- dispatch: fused LDS-resident chains (default) or per-layer GEMM launches -------------------
     def _skip_layer(self):
         """index of the pts layer whose input is cat([input_pts, h]) (fields.py:607-609), or -1."""
@@ -1271,7 +1306,7 @@ class NerfEngine:
         jobs.append((Dsig, 1, h_last, self.alpha.in_pad, grads[D + 2][0], grads[D + 2][1]))
         jobs.append((Drgb, 3, hv, self.rgb.in_pad, grads[D + 3][0], grads[D + 3][1]))
         gemm_tn_grouped(jobs, P)
-        return unpack_group(layers, grads)
+        return unpack_group(layers, grads, getattr(self, "grad_slot", None))
 
     def _forward_layers(self, pts4, rays_d, S, P, keep_state=True):
         dev = pts4.device

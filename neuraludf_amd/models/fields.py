@@ -116,6 +116,12 @@ class UDFNetwork(nn.Module):
             self._engine = mlp.UDFEngine(self)
         return self._engine
 
+    def invalidate(self):
+        """drop the packed-weight caches after an in-place write through `.data` (which does not bump the
+        parameters' version counters, the cache key): see mlp.PackedLinear.invalidate."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
     def evaluate(self, x, want_grad=True, feat_ld=0):
         """fused value + spatial gradient: -> (udf [P], featbuf [P, max(feat_ld, F)], grad [P,3] or empty)."""
         eng = self.engine()
@@ -214,6 +220,12 @@ class ResidualRenderingNetwork(nn.Module):
         if self._engine is None:
             self._engine = mlp.ColorEngine(self)
         return self._engine
+
+    def invalidate(self):
+        """drop the packed-weight caches after an in-place write through `.data` (which does not bump the
+        parameters' version counters, the cache key): see mlp.PackedLinear.invalidate."""
+        if self._engine is not None:
+            self._engine.invalidate()
 
     def evaluate(self, CIN, rays_d, S):
         """CIN: [P, pad(F+3)] = [feat | pts | 0] as produced by UDFNetwork.evaluate(feat_ld=engine.cin_ld)."""
@@ -347,6 +359,12 @@ class NeRF(nn.Module):
         if self._engine is None:
             self._engine = mlp.NerfEngine(self)
         return self._engine
+
+    def invalidate(self):
+        """drop the packed-weight caches after an in-place write through `.data` (which does not bump the
+        parameters' version counters, the cache key): see mlp.PackedLinear.invalidate."""
+        if self._engine is not None:
+            self._engine.invalidate()
 
     def evaluate(self, pts4, rays_d, S):
         eng = self.engine()

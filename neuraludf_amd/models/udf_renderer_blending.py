@@ -247,6 +247,7 @@ class UDFRendererBlending:
         self.diagnostics = True            # fill the debug keys of the result dict
         self.compute_sparse_random = False
         self.data_parallel = False         # all-reduce the batch-global loss sums over the process group
+        self.defer_loss_sums = False       # data parallel only: hand the LOCAL sums to the caller (key '_loss_sums')
         from .patch_projector import PatchProjector
         self.patch_projector = PatchProjector(self.h_patch_size)
         self._u_cache = {}
@@ -266,6 +267,12 @@ class UDFRendererBlending:
         gamma = bn.get_gamma().clip(1e-6, 1e6).reshape(1)
         scal = torch.cat([inv_s, beta, gamma])
         return scal, torch.stack([1.0 / inv_s[0], 1.0 / beta[0]]).detach()
+
+    def errors_from_sums(self, sums, n_local):
+        """[eik_num, eik_den, eikns_num, eikns_den, sparse_sum] (batch-global when data parallel) -> (gradient_error,
+        gradient_error_near_surface, sparse_error); the sparsity mean runs over ALL rays of the batch."""
+        n_rays = float(n_local) * (nudf_dist.world_size() if self.data_parallel else 1)
+        return _ErrorsFn.apply(sums, n_rays)
 
     def _quantiles(self, k, dev):
         key = (k, str(dev))
@@ -376,10 +383,16 @@ class UDFRendererBlending:
                                   bg_color, scal)
         color, color_base, weights, depth, normals, wsum, wsum_all, sums = outs[:8]
         diag = dict(zip(_DIAG, outs[8:])) if self.diagnostics else {}
-        if self.data_parallel:
-            sums = nudf_dist.all_reduce_sum(sums)
-        n_rays = float(N) * (nudf_dist.world_size() if self.data_parallel else 1)
-        gradient_error, gradient_error_ns, sparse_error = _ErrorsFn.apply(sums, n_rays)   # (:533, :536, :553)
+        local_sums = None
+        if self.data_parallel and self.defer_loss_sums and nudf_dist.world_size() > 1:
+            # ray-sharded step: the caller packs these five LOCAL sums with its other batch-global partial sums into ONE
+            # all-reduce and finishes with `errors_from_sums` (train.Trainer.loss; dist.py (1))
+            local_sums = sums
+            gradient_error = gradient_error_ns = sparse_error = None
+        else:
+            if self.data_parallel:
+                sums = nudf_dist.all_reduce_sum(sums)
+            gradient_error, gradient_error_ns, sparse_error = self.errors_from_sums(sums, N)   # (:533, :536, :553)
 
         color_pixel = patch_colors = patch_mask = None
         if color_maps is not None:
@@ -398,6 +411,8 @@ class UDFRendererBlending:
             'gradient_error_near_surface': gradient_error_ns, 'normals': normals, 'gradients': g3,
             'udf': udf.reshape(N, S), 'sparse_error': sparse_error, 'weight_sum': wsum, 'weight_sum_fg_bg': wsum_all,
         }
+        if local_sums is not None:
+            ret['_loss_sums'] = local_sums
         if self.diagnostics:
             ret.update({
                 'gradients_flip': diag["flip"][:, :, None] * g3, 'inside_sphere': diag["inside"],

@@ -81,9 +81,12 @@ class Schedules:
     color_pixel_weight: float = 0.0
     color_patch_weight: float = 0.0
     is_finetune: bool = False
+    # the runner's --reg_weights_schedule flag (default False, exp_runner_blending.py:885, 361-365): without it the loop
+    # uses the CONSTANT igr_ns_weight / sparse_weight of the conf; only with it regularization_weights_schedule applies
+    reg_weights_schedule: bool = False
 
     @classmethod
-    def from_conf(cls, conf, is_finetune=False):
+    def from_conf(cls, conf, is_finetune=False, reg_weights_schedule=False):
         t, c = conf["train"], conf["color_loss"]
         return cls(end_iter=t.get_int("end_iter"), learning_rate=t.get_float("learning_rate"),
                    learning_rate_geo=t.get_float("learning_rate_geo"),
@@ -94,7 +97,8 @@ class Schedules:
                    sparse_weight=t.get_float("sparse_weight", default=0.0),
                    color_base_weight=c.get_float("color_base_weight", 0.0), color_weight=c.get_float("color_weight", 0.0),
                    color_pixel_weight=c.get_float("color_pixel_weight", 0.0),
-                   color_patch_weight=c.get_float("color_patch_weight", 0.0), is_finetune=is_finetune)
+                   color_patch_weight=c.get_float("color_patch_weight", 0.0), is_finetune=is_finetune,
+                   reg_weights_schedule=reg_weights_schedule)
 
     def apply_learning_rates(self, optimizer, iter_step):
         """the first lines of every training iteration (:264-268): group 0 = geometry, groups 1.. = the rest."""
@@ -110,7 +114,10 @@ class Schedules:
 
     def at(self, iter_step):
         """everything the loop needs at this iteration, as a dict of python floats."""
-        ns, sp = regularization_weights(iter_step, self.end_iter, self.igr_ns_weight, self.sparse_weight)
+        if self.reg_weights_schedule:
+            ns, sp = regularization_weights(iter_step, self.end_iter, self.igr_ns_weight, self.sparse_weight)
+        else:                                      # exp_runner_blending.py:361-363
+            ns, sp = self.igr_ns_weight, self.sparse_weight
         b, c, px, pt = color_loss_weights(iter_step, self.color_base_weight, self.color_weight,
                                           self.color_pixel_weight, self.color_patch_weight, self.is_finetune)
         return dict(cos_anneal_ratio=cos_anneal_ratio(iter_step, self.anneal_end),

@@ -14,6 +14,10 @@ from .loss.loss import ColorLoss
 from .models import fields
 from .models.udf_renderer_blending import UDFRendererBlending
 
+def other_scalars(var, beta):
+    return list(var.parameters()) + list(beta.parameters())
+
+
 # shipped DTU conf (confs/udf_dtu_blending.conf:56-118)
 DTU_MODEL_CONF = dict(
     nerf=dict(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4],
@@ -30,9 +34,14 @@ DTU_MODEL_CONF = dict(
 
 class Trainer:
     def __init__(self, device, renderer_conf, color_loss_conf=None, train_conf=None, seed=0, data_parallel=False,
-                 fields_mod=fields, renderer_cls=UDFRendererBlending, loss_cls=ColorLoss, fused_adam=False):
+                 fields_mod=fields, renderer_cls=UDFRendererBlending, loss_cls=ColorLoss, fused_adam=False,
+                 model_conf=None):
+        """`model_conf`: the `model { ... }` section of a conf (nerf, udf_network, variance_network, rendering_network,
+        beta_network); default = the shipped DTU conf."""
         torch.manual_seed(seed)
-        c = DTU_MODEL_CONF
+        c = dict(DTU_MODEL_CONF)
+        if model_conf is not None:
+            c.update({k: dict(model_conf[k]) for k in DTU_MODEL_CONF if k in model_conf})
         with contextlib.redirect_stdout(io.StringIO()):
             self.nerf = fields_mod.NeRF(**c["nerf"]).to(device)
             self.udf = fields_mod.UDFNetwork(**c["udf_network"]).to(device)
@@ -61,10 +70,21 @@ class Trainer:
         with contextlib.redirect_stdout(io.StringIO()):
             self.color_loss = loss_cls(**lc)
         self.data_parallel = data_parallel
+        self._beta_flag = True
         if data_parallel:
             self.renderer.data_parallel = True
+            self.renderer.defer_loss_sums = True
             self.color_loss.set_data_parallel(True)
-            self.bucket = nudf_dist.GradBucket([p for g in self.param_groups for p in g])
+            # bucket layout in order of readiness in the backward; the NeRF (unused when n_outside = 0) last
+            # a network with an MLP engine is laid out in the ENGINE's parameter order ([v, g, bias] per layer -- the order
+            # its unpack kernel writes), not in nn.Module registration order ([bias, g, v] under weight_norm)
+            def seg(m):
+                e = m.engine() if hasattr(m, "engine") else None
+                ps = list(e.params()) if e is not None else list(m.parameters())
+                assert {id(p) for p in ps} == {id(p) for p in m.parameters()}
+                return ps, e
+            self.bucket = nudf_dist.GradBucket([(other_scalars(self.var, self.beta), None), seg(self.color), seg(self.udf),
+                                                seg(self.nerf)], device=device)
 
     def modules(self):
         return dict(nerf=self.nerf, udf=self.udf, var=self.var, color=self.color, beta=self.beta)
@@ -85,13 +105,40 @@ class Trainer:
         if out["patch_mask"] is not None:
             patch_mask = (out["patch_mask"].float()[:, None] * (weight_sum > 0.5).float()) > 0.
         pixel_mask = batch["mask"] if tc["mask_weight"] > 0 else None
-        cl = self.color_loss(out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"], pixel_mask,
-                             out["patch_colors"], batch.get("gt_patch_colors"), patch_mask)
+        cargs = (out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"], pixel_mask, out["patch_colors"],
+                 batch.get("gt_patch_colors"), patch_mask)
+        bce_sum = None
+        if tc["mask_weight"] > 0:
+            bce_sum = torch.nn.functional.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3), batch["mask"],
+                                                               reduction="sum")
+        if "_loss_sums" in out:
+            # ray-sharded step: ONE all-reduce of every batch-global partial sum -- the renderer's five, the fused colour
+            # loss's three and the mask term's two (dist.py (1)); everything after it is the same arithmetic on every rank
+            parts = [out.pop("_loss_sums")]
+            fused = self.color_loss.fusable(out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"],
+                                            out["patch_colors"])
+            if fused:
+                parts.append(self.color_loss.local_sums(out["color_base"], out["color"], batch["true_rgb"], pixel_mask))
+            if bce_sum is not None:
+                parts.append(torch.stack([bce_sum, bce_sum.new_tensor(float(weight_sum.numel()))]))
+            packed = nudf_dist.all_reduce_sum(torch.cat([p.reshape(-1) for p in parts]))
+            ge, gens, se = self.renderer.errors_from_sums(packed[:5], weight_sum.shape[0])
+            out["gradient_error"], out["gradient_error_near_surface"], out["sparse_error"] = ge, gens, se
+            k = 5
+            if fused:
+                cl = self.color_loss.from_global_sums(out["color_base"], out["color"], batch["true_rgb"], pixel_mask,
+                                                      packed[k:k + 3])
+                k += 3
+            else:
+                cl = self.color_loss(*cargs)            # pixel / patch terms: their own (counted) collectives
+            mask_loss = packed[k] / packed[k + 1] if bce_sum is not None else None
+        else:
+            cl = self.color_loss(*cargs)
+            mask_loss = bce_sum / float(weight_sum.numel()) if bce_sum is not None else None
         loss = cl["loss"] + out["gradient_error_near_surface"] * tc["igr_ns_weight"] \
             + out["sparse_error"] * tc["sparse_weight"] + out["gradient_error"] * tc["igr_weight"]
-        if tc["mask_weight"] > 0:
-            loss = loss + torch.nn.functional.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3),
-                                                                   batch["mask"]) * tc["mask_weight"]
+        if mask_loss is not None:
+            loss = loss + mask_loss * tc["mask_weight"]
         return loss, out
 
     def step(self, batch, **kw):
@@ -126,7 +173,24 @@ class Trainer:
             blend = dict(color_maps=src_images, w2cs=torch.inverse(src_c2ws), intrinsics=src_intr, query_c2w=ref_c2w)
         loss, out = self.step(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
                               blend=blend)
+        self._trainability_toggles(out, iter_step + 1)
         return loss, out, s
+
+    def _trainability_toggles(self, out, iter_step, check_every=100):
+        """exp_runner_blending.py:352-358: once the variance has dropped below 2 beta and 0.01, beta becomes trainable;
+        a frozen variance becomes trainable after 20 000 iterations.  Both are no-ops for the shipped confs (beta and
+        the variance are trainable from the start).  The first test reads two device scalars, so it is evaluated every
+        `check_every` iterations only (the reference syncs on it every iteration)."""
+        var_p = getattr(self.var, "variance", None)
+        if var_p is not None and var_p.requires_grad is False and iter_step > 20000:
+            self.var.set_trainable()
+        beta_p = getattr(self.beta, "beta", None)
+        if (self._beta_flag and beta_p is not None and not beta_p.requires_grad and var_p is not None and var_p.requires_grad
+                and iter_step % check_every == 0):
+            variance, beta = float(out["variance"].mean()), float(out["beta"].reshape(-1)[0])
+            if variance < 2 * beta and variance < 0.01:
+                self.beta.set_beta_trainable()
+                self._beta_flag = False
 
     @torch.no_grad()
     def render_image(self, source, img_idx, resolution_level=4, chunk=65536, cos_anneal_ratio=1.0):

@@ -56,7 +56,9 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from neuraludf_amd import dist as nd
+        from neuraludf_amd.loss import loss as L
         from neuraludf_amd.loss.loss import ColorPixelLoss, _global_trimmed_mean
+        L._l1_sum = lambda pred, gt: (pred - gt).abs().sum()      # host stand-in for the HIP reduction (test only)
         theta, x, gt, pmask = _toy_problem()
         n = x.shape[0]
         theta = theta.clone().requires_grad_(True)
@@ -81,7 +83,9 @@ def _worker(rank, world, port, ret):
 
 def test_sharded_loss_and_gradients_equal_single_process():
     sys.path.insert(0, ROOT)
+    from neuraludf_amd.loss import loss as L
     from neuraludf_amd.loss.loss import ColorPixelLoss
+    L._l1_sum = lambda pred, gt: (pred - gt).abs().sum()          # host stand-in for the HIP reduction (test only)
     theta, x, gt, pmask = _toy_problem()
     theta = theta.clone().requires_grad_(True)
     color, sums, perr = _local_terms(theta, x)
@@ -112,7 +116,62 @@ def test_sharded_loss_and_gradients_equal_single_process():
 def test_shard_covers_batch_without_overlap():
     sys.path.insert(0, ROOT)
     from neuraludf_amd import dist as nd
-    t = torch.arange(103)
+    t = torch.arange(104)
     for w in (1, 2, 4, 8):
         parts = [nd.shard(t, r, w) for r in range(w)]
         assert torch.equal(torch.cat(parts), t)
+        assert len({p.shape[0] for p in parts}) == 1
+    with pytest.raises(ValueError):          # unequal shards would break the renderer's batch-global normalisation
+        nd.shard(torch.arange(103), 0, 2)
+
+
+def _bucket_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neuraludf_amd import dist as nd
+        g = torch.Generator().manual_seed(5)
+        shapes = [(3, 4), (5,), (2, 2), (7,), (1,)]
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+
+        class Eng:            # stands for an mlp engine: writes its gradients straight into its bucket segment
+            grad_slot = None
+        eng = Eng()
+        b = nd.GradBucket([([ps[4]], None), (ps[0:2], eng), ([ps[2]], None), ([ps[3]], None)])
+        assert eng.grad_slot is not None and eng.grad_slot.numel() == 17
+        nd.collective_counts(reset=True)
+        for step in range(2):
+            for p in ps:
+                p.grad = None
+            # engine segment: gradients ARE bucket views (what autograd installs after unpack_group(slot=...))
+            v0 = eng.grad_slot[:12].view(3, 4)
+            v1 = eng.grad_slot[12:17]
+            v0.copy_(torch.full((3, 4), float(rank + 1 + step)))
+            v1.copy_(torch.arange(5.0) * (rank + 1))
+            ps[0].grad, ps[1].grad = v0, v1
+            ps[4].grad = torch.tensor([10.0 * (rank + 1)])        # a gradient that lives outside the bucket: copied in / out
+            ps[2].grad = torch.ones(2, 2) * (rank + 2)
+            # ps[3] (the trailing segment) took no part in the step: grad None, not sent
+            b.all_reduce()
+            assert b.last_message_floats == 1 + 17 + 4
+            assert ps[0].grad.data_ptr() == v0.data_ptr()
+        ret[rank] = ([p.grad.clone() if p.grad is not None else None for p in ps], nd.collective_counts())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucket_views_copies_and_unused_tail():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        grads, counts = ret[r]
+        assert torch.equal(grads[0], torch.full((3, 4), 2.0 + 3.0))          # step 1: (1+1) + (2+1)
+        assert torch.equal(grads[1], torch.arange(5.0) * 3)
+        assert torch.equal(grads[4], torch.tensor([30.0]))
+        assert torch.equal(grads[2], torch.ones(2, 2) * 5)
+        assert grads[3] is None
+        assert counts["all_reduce"] == 2 and counts["all_gather"] == 0            # one collective per step

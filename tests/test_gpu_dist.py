@@ -36,16 +36,13 @@ def test_rccl_collectives_single_rank():
               torch.randn(2, device=dev, requires_grad=True)]
         ps[0].grad, ps[1].grad = torch.ones_like(ps[0]), torch.full_like(ps[1], 3.0)      # ps[2].grad stays None
         b = nd.GradBucket(ps)
-        flat = torch.cat([g.reshape(-1) for g in (ps[0].grad, ps[1].grad, torch.zeros_like(ps[2]))])
-        dist.all_reduce(flat)
+        assert b.flat.numel() == 21 + 11 + 2 and b.flat.is_cuda
+        # the bucket's collective itself (world_size() == 1 short-circuits it in production; issue its body directly)
+        torch._foreach_copy_(b.views[:2], [ps[0].grad, ps[1].grad])
+        dist.all_reduce(b.flat[:32], op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
-        assert float(flat.sum()) == 21.0 + 33.0
-        # the bucket path itself (world_size() == 1 short-circuits it in production; call the body directly)
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
-        fl = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(fl, op=dist.ReduceOp.SUM)
-        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(fl.split(b.sizes), grads)])
-        assert torch.equal(grads[1], torch.full_like(ps[1], 3.0))
+        assert float(b.flat[:32].sum()) == 21.0 + 33.0
+        assert torch.equal(b.views[1], torch.full_like(ps[1], 3.0))
     finally:
         dist.destroy_process_group()
 
@@ -73,10 +70,12 @@ def test_two_rank_step_equals_full_batch(tmp_path):
     r = _run([os.path.join(here, "dp_gpu_worker.py"), out], {})
     assert r.returncode == 0, r.stderr[-3000:]
     got = torch.load(out)
-    loss, flat = build_and_grads(torch.device("cuda:0"), 1, 0, False)
+    loss, flat, _ = build_and_grads(torch.device("cuda:0"), 1, 0, False)
     assert abs(got["loss"] - loss) < 1e-5 * max(1.0, abs(loss)), (got["loss"], loss)
     den = float(flat.abs().max())
     assert float((got["grads"] - flat).abs().max()) < 2e-4 * den
+    # exactly two collectives per ray-sharded step: the packed partial sums and the gradient bucket
+    assert got["collectives"] == {"all_reduce": 2, "all_gather": 0}, got["collectives"]
 
 
 def test_bench_two_rank_flow():
@@ -91,4 +90,25 @@ def test_bench_two_rank_flow():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_rays"] == 128 and d["value"] > 0 and "roofline" in d
+    assert d["collectives_per_step"] == {"all_reduce": 2.0, "all_gather": 0.0} and d["gradient_message_floats"] > 600000
     assert "cpu_baseline" not in d
+
+
+def test_two_rank_step_rccl(tmp_path):
+    """the same 2-rank ray-sharded step over RCCL (backend "nccl"), one rank per GPU: needs two GPUs -- skipped on the
+    one-GPU boxes, runs wherever the driver gives the tests a multi-GPU node.  Checks loss / gradients against the
+    single-process full batch and that the step issued exactly two collectives (packed sums + gradient bucket)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from dp_gpu_worker import build_and_grads
+    out = str(tmp_path / "dp_rccl.pt")
+    r = _run([os.path.join(here, "dp_gpu_worker.py"), out, "nccl"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    loss, flat = build_and_grads(torch.device("cuda:0"), 1, 0, False)[:2]
+    assert abs(got["loss"] - loss) < 1e-5 * max(1.0, abs(loss)), (got["loss"], loss)
+    assert float((got["grads"] - flat).abs().max()) < 2e-4 * float(flat.abs().max())
+    assert got["collectives"] == {"all_reduce": 2, "all_gather": 0}, got["collectives"]

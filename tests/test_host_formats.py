@@ -19,7 +19,15 @@ HERE = os.path.dirname(__file__)
 def test_schedules_match_reference_runner():
     g = json.load(open(os.path.join(HERE, "golden", "ref_schedules.json")))
     for name, c in g["confs"].items():
-        s = sch.Schedules(**c)
+        # the golden rows hold the reference's regularization_weights_schedule(), i.e. the runner WITH its
+        # --reg_weights_schedule flag; without the flag (the default, and what the *_ft launch scripts use) the loop
+        # takes the conf's constants (exp_runner_blending.py:361-365)
+        s = sch.Schedules(reg_weights_schedule=True, **c)
+        s_off = sch.Schedules(**c)
+        assert s_off.reg_weights_schedule is False
+        for it in g["steps"]:
+            a = s_off.at(it)
+            assert a["igr_ns_weight"] == c["igr_ns_weight"] and a["sparse_weight"] == c["sparse_weight"], (name, it)
         for it, row in zip(g["steps"], g["values"][name]):
             if row is None:
                 continue
