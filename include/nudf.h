@@ -153,6 +153,10 @@ typedef struct NudfCompositeGrad {
 
 int nudf_composite_fwd(const NudfComposite* args, void* stream);
 int nudf_composite_bwd(const NudfComposite* args, const NudfCompositeGrad* grads, void* stream);
+/* Layout of the FULL case (S = 128 / 256 / 512 inside samples, no outside samples, no diagnostics): 1 = lane l owns
+ * S/64 consecutive samples (16-byte vector accesses), 0 (default) = sample i in lane i % 64 for every shape.  Same
+ * arithmetic, different association of the two product scans; A-B switch (the two measure the same on MI355X). */
+void nudf_set_composite_blocked(int on);
 
 /* ------------------------------------------------------------------------------------
  * Hierarchical importance re-sampling (no autograd), one wavefront per ray.

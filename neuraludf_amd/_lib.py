@@ -178,7 +178,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_composite_fwd",
-    "nudf_composite_bwd", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
+    "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",

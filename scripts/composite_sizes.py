@@ -1,12 +1,15 @@
-"""kernel-pair (composite + partial sums) durations per size, forward and backward, through the C ABI only."""
+"""kernel-pair (composite + partial sums) durations per size, forward and backward, through the C ABI only, for both
+lane layouts of the FULL case (strided = sample i in lane i % 64, the default; blocked = lane owns S/64 consecutive samples,
+16-byte vector accesses).  A working set beyond the 256 MB Infinity Cache is what the "HBM" figure needs: 32768 x 256 = 405 / 707 MB,
+65536 x 256 = 810 / 1414 MB (forward / backward algorithmic bytes)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from neuraludf_amd._lib import Composite, CompositeGrad, call, ptr
+from neuraludf_amd._lib import Composite, CompositeGrad, call, lib, ptr
 from neuraludf_amd.models.udf_renderer_blending import _fill_composite
 
 dev = torch.device("cuda:0")
-for (n, s) in [(512, 128), (8192, 256), (32768, 256), (32768, 146)]:
+for (n, s) in [(512, 128), (8192, 256), (32768, 256), (65536, 256), (65536, 128), (16384, 512), (32768, 146)]:
     g = torch.Generator().manual_seed(0)
     z = torch.sort(torch.rand(n, s, generator=g) * 2 + 1.5, -1)[0].to(dev)
     ro = torch.randn(n, 3, generator=g).to(dev)
@@ -40,7 +43,13 @@ for (n, s) in [(512, 128), (8192, 256), (32768, 256), (32768, 146)]:
         for _ in range(reps): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
-    tf = t(lambda: call("nudf_composite_fwd", a))
-    tb = t(lambda: call("nudf_composite_bwd", a, gq))
     bf, bb = 48.0 * n * s + 68.0 * n, 84.0 * n * s + 68.0 * n
-    print(f"{n}x{s}: fwd {tf:.1f} us {bf / tf / 1e6:.2f} TB/s ({bf / tf / 8e6 * 100:.1f}%) | bwd {tb:.1f} us {bb / tb / 1e6:.2f} TB/s ({bb / tb / 8e6 * 100:.1f}%)")
+    for layout in ("blocked", "strided"):
+        lib().nudf_set_composite_blocked(1 if layout == "blocked" else 0)
+        tf = t(lambda: call("nudf_composite_fwd", a))
+        tb = t(lambda: call("nudf_composite_bwd", a, gq))
+        print(f"{n}x{s} {layout:8s}: fwd {tf:7.1f} us {bf / tf / 1e6:.2f} TB/s ({bf / tf / 8e6 * 100:.1f}% of 8 TB/s, {bf / 1e6:.0f} MB) | "
+              f"bwd {tb:7.1f} us {bb / tb / 1e6:.2f} TB/s ({bb / tb / 8e6 * 100:.1f}%, {bb / 1e6:.0f} MB)", flush=True)
+    lib().nudf_set_composite_blocked(0)
+    del z, udf, grad, col, cb, bufs, ups, outs
+    torch.cuda.empty_cache()

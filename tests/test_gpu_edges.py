@@ -117,3 +117,51 @@ def test_kernel_argument_errors_are_loud(dev):
         call("nudf_upsample", a)
     with pytest.raises(NudfError):
         ptr(torch.zeros(3))                       # CPU tensor
+
+
+@pytest.mark.parametrize("S", [128, 256, 512])
+def test_composite_blocked_layout_equals_strided_layout(dev, S):
+    """the FULL-case composite kernels exist in two lane layouts (sample i in lane i % 64 -- the default -- or lane l owns
+    S/64 consecutive samples with 16-byte vector accesses, the bandwidth probe of DESIGN.md section 4.3): same
+    arithmetic, different association of the two product scans.  Forward outputs and every gradient must agree to fp32
+    rounding, with and without cosine annealing / normalised-gradient cosines."""
+    from neuraludf_amd import _lib
+    from neuraludf_amd.models.udf_renderer_blending import _CompositeFn
+    g = torch.Generator().manual_seed(S)
+    N = 67
+    ro = torch.randn(N, 3, generator=g) * 0.3
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    z = torch.sort(torch.rand(N, S, generator=g) * 2 + 1.0, -1)[0]
+    udf = (torch.rand(N, S, generator=g) * 0.2) ** 2
+    udf[:, S // 2] = 1e-4
+    grad = torch.randn(N, S, 3, generator=g) * 0.8
+    col, cb = torch.rand(N, S, 3, generator=g), torch.rand(N, S, 3, generator=g)
+    scal = torch.tensor([40.0, 70.0, 20.0])
+    sd = torch.tensor([2.0 / 64])
+    k = [torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, S, generator=g) * 0.1,
+         torch.randn(N, 1, generator=g), torch.randn(N, 3, generator=g), torch.randn(5, generator=g) * 1e-3]
+    D = lambda t: t.to(dev)
+    res = {}
+    for anneal, use_norm in ((None, False), (0.6, True)):
+        for blocked in (1, 0):
+            _lib.lib().nudf_set_composite_blocked(blocked)
+            try:
+                leaves = [D(t).requires_grad_(True) for t in (udf, grad, col, cb, scal)]
+                c = dict(s_nominal=S, cos_anneal=anneal, flip_saturation=0.9, use_norm_grad=use_norm, sparse_scale=25000.0,
+                         diagnostics=False)
+                out = _CompositeFn.apply(c, D(ro), D(rd), D(z), D(sd), None, leaves[0], leaves[1], leaves[2], leaves[3], None,
+                                         None, None, leaves[4])
+                color, cbo, w, depth, normals, wsum, wall, sums = out[:8]
+                loss = ((color * D(k[0])).sum() + (cbo * D(k[1])).sum() + (w * D(k[2])).sum() + (depth * D(k[3])).sum()
+                        + (normals * D(k[4])).sum() + (sums * D(k[5])).sum() + wsum.sum() * 0.3)
+                loss.backward()
+                res[blocked] = [t.detach().cpu() for t in (color, cbo, w, depth, normals, wsum, wall, sums)] + \
+                               [t.grad.detach().cpu() for t in leaves]
+            finally:
+                _lib.lib().nudf_set_composite_blocked(0)
+        names = ["color", "color_base", "weights", "depth", "normals", "wsum", "wsum_all", "sums", "d_udf", "d_grad",
+                 "d_color", "d_color_base", "d_scal"]
+        for nm, a, b in zip(names, res[1], res[0]):
+            den = float(b.abs().max().clamp(min=1e-6))
+            tol = 2e-4 if nm.startswith("d_") else 2e-5
+            assert float((a - b).abs().max()) / den < tol, (S, anneal, nm, float((a - b).abs().max()) / den)
