@@ -78,20 +78,36 @@ typedef struct NudfGemmTN {
 /* C[NA,NB] += A1^T B1 (+ A2^T B2): weight gradients, reduction over the M points */
 int nudf_gemm_tn(const NudfGemmTN* args, void* stream);
 
-/* up to 12 single-pair problems over the same M points in one launch (all weight gradients of a ReLU chain) */
+/* up to 12 single-pair problems over the same M points in one launch (all weight gradients of a layer chain); at most
+ * 64 output tiles of 128 x 128 in total.  A1 / B1 16-byte aligned, lda1 / ldb1 multiples of 4. */
 #define NUDF_TN_MAX_PROBLEMS 12
 typedef struct NudfGemmTNProblem {
   const float* A1; const float* B1;             /* [M, lda1], [M, ldb1]                   */
   float* C; float* dbias;                       /* [NA, ldc] +=, [NA] += or NULL          */
   int32_t lda1, ldb1, ldc, NA, NB;
-  int32_t tile_start;                           /* filled by the library                  */
+  int32_t tile_start;                           /* unused (kept for layout compatibility) */
 } NudfGemmTNProblem;
 typedef struct NudfGemmTNGroup {
   int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
   int32_t prec;                                 /* as NudfGemmTN.prec                     */
   NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
+  float* workspace;                             /* NULL: partial tiles are accumulated with fp32 atomics.  Otherwise a
+                                                   16-byte aligned scratch of >= nudf_gemm_tn_grouped_workspace()
+                                                   floats: every workgroup stores its partial tile there and a second
+                                                   kernel adds them to C / dbias in a FIXED order (run-to-run identical
+                                                   results).  Must not be shared by launches that can overlap.        */
+  int64_t workspace_floats;
 } NudfGemmTNGroup;
 int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);
+/* floats of workspace this group needs (0 for an empty group, < 0 on an invalid one) */
+int64_t nudf_gemm_tn_grouped_workspace(const NudfGemmTNGroup* args);
+/* tuning / measurement bits, returns the old value: 2 = drop the epilogue (TIMING ONLY: results are discarded), 4 = skip
+ * the bias sums, 8 = ignore the workspace (atomics), 16 = equal row chunks for every tile instead of the cost-weighted
+ * split.  Default 0 (env NUDF_TN_FLAGS). */
+int nudf_set_tn_flags(int flags);
+/* tuning only: device buffer of >= 4 int64 per workgroup receiving {start, end} (wall_clock64, 100 MHz), tile layout * 16
+ * + live sub-tiles per wave, k-steps; NULL switches it off */
+int nudf_set_tn_debug(void* buf);
 
 
 /* ------------------------------------------------------------------------------------

@@ -46,7 +46,7 @@ class GemmTNProblem(C.Structure):
 
 class GemmTNGroup(C.Structure):
     _fields_ = [("n_problems", i32), ("M", i32), ("rows_per_block", i32), ("total_tiles", i32), ("prec", i32),
-                ("prob", GemmTNProblem * TN_MAX_PROBLEMS)]
+                ("prob", GemmTNProblem * TN_MAX_PROBLEMS), ("workspace", c_fp), ("workspace_floats", C.c_int64)]
 
 
 class RayBatch(C.Structure):
@@ -177,7 +177,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_composite_fwd",
+    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_set_tn_flags", "nudf_set_tn_debug", "nudf_composite_fwd",
     "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
@@ -196,6 +196,9 @@ _ARGTYPES = {
     "nudf_gemm_nn": [C.POINTER(GemmNN), _P],
     "nudf_gemm_tn": [C.POINTER(GemmTN), _P],
     "nudf_gemm_tn_grouped": [C.POINTER(GemmTNGroup), _P],
+    "nudf_gemm_tn_grouped_workspace": [C.POINTER(GemmTNGroup)],
+    "nudf_set_tn_flags": [i32],
+    "nudf_set_tn_debug": [_P],
     "nudf_composite_fwd": [C.POINTER(Composite), _P],
     "nudf_composite_bwd": [C.POINTER(Composite), C.POINTER(CompositeGrad), _P],
     "nudf_upsample": [C.POINTER(Upsample), _P],
@@ -266,6 +269,7 @@ def lib():
         _lib.nudf_version.restype = C.c_int
         _lib.nudf_adam_chunk.restype = C.c_int
         _bind(_lib)
+        _lib.nudf_gemm_tn_grouped_workspace.restype = C.c_int64
     return _lib
 
 

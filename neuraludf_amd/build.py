@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libnudf.so")
-SOURCES = ["nudf_api.hip", "gemm_f32_mfma.hip", "rays_embed.hip", "composite.hip", "upsample.hip",
+SOURCES = ["nudf_api.hip", "gemm_f32_mfma.hip", "gemm_tn_f32_mfma.hip", "rays_embed.hip", "composite.hip", "upsample.hip",
            "blend.hip", "optim.hip", "mlp_chain.hip", "mlp_chain_rows.hip", "raybatch.hip"]
 
 

@@ -1,10 +1,10 @@
 // fp32 MFMA GEMMs for the MLP chains of the NeuralUDF hot path (gfx950).
 //
 //   gemm_nn : C[M,N]   = epilogue( A[M,K] * B[K,N] )         A,B row-major, K % 32 == 0
-//   gemm_tn : C[NA,NB] += A1[M,NA]^T B1[M,NB] (+ A2^T B2)     split over M, fp32 atomics
+//   (the weight-gradient contraction gemm_tn lives in gemm_tn_f32_mfma.hip)
 //
-// Both use v_mfma_f32_32x32x2_f32 (exact fp32, == an fmaf chain), 128x128x32 block tiles,
-// 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA tiles, double-buffered LDS.
+// v_mfma_f32_32x32x2_f32 (exact fp32, == an fmaf chain), block tiles up to 128x128x32,
+// 4 waves (2x2), each wave up to a 64x64 sub-tile = 2x2 MFMA tiles, double-buffered LDS.
 // These replace the chains of F.linear / weight_norm / Softplus / ReLU / autograd ops of
 // models/fields.py:192-231 (UDFNetwork), :452-495 (ResidualRenderingNetwork), :599-628 (NeRF)
 // and their (double-)backward.  MFMA peak for this instruction: 157.3 TFLOP/s.
@@ -280,216 +280,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_nn_kernel(NudfGemmNN p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// weight-gradient GEMM: C[NA,NB] += sum_m A[m,:]^T B[m,:]   (two operand pairs, split over M)
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void gemm_tn_body(const NudfGemmTN& p, float* smem, int tile, int chunk) {
-  float* As = smem;
-  float* Bs = smem + 2 * T_TILE;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_j = (p.NB + BN - 1) / BN;
-  const int i0 = (tile / tiles_j) * BM;
-  const int j0 = (tile % tiles_j) * BN;
-  const int mbeg = chunk * p.rows_per_block;
-  int mend = mbeg + p.rows_per_block;
-  if (mend > p.M) mend = p.M;
-  const int nk1 = (mend - mbeg + BK - 1) / BK;
-  const int npairs = p.A2 ? 2 : 1;
-  const int nk = nk1 * npairs;
-
-  const int t_k = tid >> 5;   // 0..7 (+8 per pass)
-  const int t_c4 = tid & 31;  // float4 column
-
-  f32x4 ra[4], rb[4];
-  int ld_rows = 0;
-  // branch-free: column indices are clamped into the buffer (columns past NA / NB only feed outputs that are
-  // never stored), rows are clamped and rows >= mend are zeroed by selects
-  auto gload = [&](int kt) {
-    const int pair = kt / nk1;
-    const int kk = kt - pair * nk1;
-    const float* A = pair ? p.A2 : p.A1;
-    const float* B = pair ? p.B2 : p.B1;
-    const int lda = pair ? p.lda2 : p.lda1;
-    const int ldb = pair ? p.ldb2 : p.ldb1;
-    const int ci = min(i0 + t_c4 * 4, lda - 4);
-    const int cj = min(j0 + t_c4 * 4, ldb - 4);
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int m = mbeg + kk * BK + ps * 8 + t_k;
-      const int mc = min(m, p.M - 1);
-      ra[ps] = *reinterpret_cast<const f32x4*>(A + (size_t)mc * lda + ci);
-      rb[ps] = *reinterpret_cast<const f32x4*>(B + (size_t)mc * ldb + cj);
-    }
-    ld_rows = mend - (mbeg + kk * BK);   // rows of this k-step that exist (zeroed at the LDS store)
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const bool ok = (ps * 8 + t_k) < ld_rows;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(As + buf * T_TILE + (ps * 8 + t_k) * LDT_S + t_c4 * 4) = ok ? ra[ps] : z;
-      *reinterpret_cast<f32x4*>(Bs + buf * T_TILE + (ps * 8 + t_k) * LDT_S + t_c4 * 4) = ok ? rb[ps] : z;
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const bool acti = (i0 + wm * 64) < p.NA;
-  const bool actj0 = (j0 + wn * 64) < p.NB;
-  const bool actj1 = (j0 + wn * 64 + 32) < p.NB;
-  const bool acti1 = (i0 + wm * 64 + 32) < p.NA;
-  // bias gradient = column sums of A: all 256 threads take part (thread -> column tid % 128, row half tid / 128), so
-  // the four waves stay balanced between the barriers (two waves doing all 32 rows held the other two up)
-  const bool do_bias = (p.dbias != nullptr) && (j0 == 0);
-  const int b_col = tid & (BM - 1), b_half = tid / BM;
-  float bsum = 0.0f;
-
-  if (nk > 0) {
-    gload(0);
-    sstore(0);
-  }
-  __syncthreads();
-
-  // straight-line MFMA code for each of the four live-tile shapes of a wave (NI x NJ of its 2 x 2 tiles): a
-  // partially live wave (N ends inside its 64 x 64) does proportionally fewer MFMAs and has no branches inside
-  const int ni = acti ? (acti1 ? 2 : 1) : 0, nj = actj0 ? (actj1 ? 2 : 1) : 0;
-  auto mma_tile = [&](auto NI, auto NJ, int cur) {
-    constexpr int kNI = decltype(NI)::value, kNJ = decltype(NJ)::value;
-    const float* as = As + cur * T_TILE + (lane >> 5) * LDT_S + wm * 64 + (lane & 31);
-    const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT_S + wn * 64 + (lane & 31);
-    float av[2][4][2], bv[2][4][2];
-    auto rd = [&](int set, int c) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int kk = c * 4 + q;
-#pragma unroll
-        for (int i = 0; i < kNI; ++i) av[set][q][i] = as[(2 * kk) * LDT_S + 32 * i];
-#pragma unroll
-        for (int j = 0; j < kNJ; ++j) bv[set][q][j] = bs[(2 * kk) * LDT_S + 32 * j];
-      }
-    };
-    rd(0, 0);
-#pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-      if (c + 1 < BK / 8) rd((c + 1) & 1, c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < kNJ; ++j)
-#pragma unroll
-          for (int i = 0; i < kNI; ++i) acc[i][j] = mfma32(av[c & 1][q][i], bv[c & 1][q][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  // config-5 mode: bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Lane (i, h) of an operand holds the 8
-  // reduction indices 8h .. 8h+7 of its column: 8 strided ds_read_b32 of the SAME fp32 LDS tiles, converted on the fly
-  // (RNE).  16x the fp32 MFMA rate, so this loop is bound by the LDS reads / HBM, not by the matrix pipe.
-  auto mma_tile16 = [&](auto NI, auto NJ, int cur) {
-    constexpr int kNI = decltype(NI)::value, kNJ = decltype(NJ)::value;
-    const float* as = As + cur * T_TILE + (8 * (lane >> 5)) * LDT_S + wm * 64 + (lane & 31);
-    const float* bs = Bs + cur * T_TILE + (8 * (lane >> 5)) * LDT_S + wn * 64 + (lane & 31);
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 a16[2], b16[2];
-#pragma unroll
-      for (int i = 0; i < kNI; ++i) {
-        f32x8 v;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = as[(16 * kk + t) * LDT_S + 32 * i];
-        a16[i] = __builtin_convertvector(v, bf16x8);
-      }
-#pragma unroll
-      for (int j = 0; j < kNJ; ++j) {
-        f32x8 v;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = bs[(16 * kk + t) * LDT_S + 32 * j];
-        b16[j] = __builtin_convertvector(v, bf16x8);
-      }
-#pragma unroll
-      for (int j = 0; j < kNJ; ++j)
-#pragma unroll
-        for (int i = 0; i < kNI; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16[i], b16[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
-    if (p.prec != 0) {
-      if (ni == 2 && nj == 2) mma_tile16(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, cur);
-      else if (ni == 2 && nj == 1) mma_tile16(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cur);
-      else if (ni == 1 && nj == 2) mma_tile16(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, cur);
-      else if (ni == 1 && nj == 1) mma_tile16(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cur);
-    } else
-    if (ni == 2 && nj == 2) mma_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, cur);
-    else if (ni == 2 && nj == 1) mma_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, cur);
-    else if (ni == 1 && nj == 2) mma_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, cur);
-    else if (ni == 1 && nj == 1) mma_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_bias && kt < nk1) {  // column sums of the first pair's A (bias gradient)
-      const float* as = As + cur * T_TILE + b_col + b_half * (BK / 2) * LDT_S;
-#pragma unroll
-      for (int k = 0; k < BK / 2; ++k) bsum += as[k * LDT_S];
-    }
-    if (kt + 1 < nk) sstore(cur ^ 1);
-    __syncthreads();
-  }
-
-  if (do_bias && (i0 + b_col) < p.NA) atomicAdd(p.dbias + i0 + b_col, bsum);
-  if (!(acti && actj0)) return;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i == 1 && !acti1) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !actj1) continue;
-      const int col = j0 + wn * 64 + j * 32 + (lane & 31);
-      if (col >= p.NB) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < p.NA) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][r]);
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(NudfGemmTN p) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
-  const int tiles = ((p.NA + BM - 1) / BM) * ((p.NB + BN - 1) / BN);
-  gemm_tn_body(p, smem, blockIdx.x % tiles, blockIdx.x / tiles);
-}
-
-// several single-pair problems over the same M points in one launch (the weight gradients of a whole ReLU chain):
-// enough tiles to fill the chip with long row chunks, i.e. few atomics per output and one launch instead of 5-12
-__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(NudfGemmTNGroup g) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
-  const int gt = blockIdx.x % g.total_tiles;
-  const int chunk = blockIdx.x / g.total_tiles;
-  int pi = 0;
-  while (pi + 1 < g.n_problems && g.prob[pi + 1].tile_start <= gt) ++pi;
-  const NudfGemmTNProblem& q = g.prob[pi];
-  NudfGemmTN p;
-  p.A1 = q.A1; p.lda1 = q.lda1; p.na1 = q.NA;
-  p.B1 = q.B1; p.ldb1 = q.ldb1;
-  p.A2 = nullptr; p.lda2 = 0; p.na2 = 0; p.B2 = nullptr; p.ldb2 = 0;
-  p.C = q.C; p.ldc = q.ldc; p.dbias = q.dbias;
-  p.M = g.M; p.NA = q.NA; p.NB = q.NB; p.rows_per_block = g.rows_per_block; p.prec = g.prec;
-  gemm_tn_body(p, smem, gt - q.tile_start, chunk);
-}
-
-// ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
 template <int EPI, int WM, int WN, int NBUF, int OCC>
@@ -557,64 +347,4 @@ extern "C" int nudf_gemm_nn(const NudfGemmNN* args, void* stream) {
       nudf_set_error("nudf_gemm_nn: unknown epilogue", hipErrorInvalidValue);
       return (int)hipErrorInvalidValue;
   }
-}
-
-extern "C" int nudf_gemm_tn(const NudfGemmTN* args, void* stream) {
-  NudfGemmTN p = *args;
-  hipStream_t st = (hipStream_t)stream;
-  if (p.M <= 0 || p.NA <= 0 || p.NB <= 0) return 0;
-  if ((p.lda1 % 4) || (p.ldb1 % 4) || (p.A2 && ((p.lda2 % 4) || (p.ldb2 % 4)))) {
-    nudf_set_error("nudf_gemm_tn: leading dimensions must be multiples of 4", hipErrorInvalidValue);
-    return (int)hipErrorInvalidValue;
-  }
-  const int tiles = ((p.NA + BM - 1) / BM) * ((p.NB + BN - 1) / BN);
-  if (p.rows_per_block <= 0) {
-    // one resident wave of workgroups (2 per CU = 512 blocks, never more), at least 8 k-steps per block
-    int chunks = 512 / tiles;
-    if (chunks < 1) chunks = 1;
-    int rpb = (p.M + chunks - 1) / chunks;
-    rpb = ((rpb + BK - 1) / BK) * BK;
-    if (rpb < 8 * BK) rpb = 8 * BK;
-    p.rows_per_block = rpb;
-  }
-  const int chunks = (p.M + p.rows_per_block - 1) / p.rows_per_block;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * chunks), dim3(256), 0, st, p);
-  NUDF_CHECK_LAUNCH("nudf_gemm_tn");
-  return 0;
-}
-
-extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
-  NudfGemmTNGroup g = *args;
-  if (g.n_problems <= 0 || g.M <= 0) return 0;
-  if (g.n_problems > NUDF_TN_MAX_PROBLEMS) {
-    nudf_set_error("nudf_gemm_tn_grouped: too many problems", hipErrorInvalidValue);
-    return (int)hipErrorInvalidValue;
-  }
-  int tiles = 0;
-  for (int i = 0; i < g.n_problems; ++i) {
-    NudfGemmTNProblem& q = g.prob[i];
-    if ((q.lda1 % 4) || (q.ldb1 % 4) || q.NA <= 0 || q.NB <= 0) {
-      nudf_set_error("nudf_gemm_tn_grouped: leading dimensions must be multiples of 4", hipErrorInvalidValue);
-      return (int)hipErrorInvalidValue;
-    }
-    q.tile_start = tiles;
-    tiles += ((q.NA + BM - 1) / BM) * ((q.NB + BN - 1) / BN);
-  }
-  g.total_tiles = tiles;
-  if (g.rows_per_block <= 0) {
-    // exactly one resident wave of workgroups (2 per CU x 256 CUs): 640 blocks measured 348 us where 512 take
-    // 274 us -- a second, partial wave of blocks costs a whole extra pass (NUDF_TNG_BLOCKS: tuning hook)
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
-    int chunks = target / tiles;
-    if (chunks < 1) chunks = 1;
-    int rpb = (g.M + chunks - 1) / chunks;
-    rpb = ((rpb + BK - 1) / BK) * BK;
-    if (rpb < 8 * BK) rpb = 8 * BK;
-    g.rows_per_block = rpb;
-  }
-  const int chunks = (g.M + g.rows_per_block - 1) / g.rows_per_block;
-  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles * chunks), dim3(256), 0, (hipStream_t)stream, g);
-  NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
-  return 0;
 }

@@ -1,0 +1,546 @@
+// Weight-gradient contraction of the MLP chains (gfx950):  C[NA,NB] += A[M,NA]^T B[M,NB]  (+ dbias[NA] += column sums
+// of A), reduction over the M sample points, several problems (all layers of a network) in ONE launch.
+//
+// Replaces the weight / bias gradient halves of autograd's F.linear backward in models/fields.py:192-231 (UDFNetwork,
+// first and second order), :452-495 (ResidualRenderingNetwork), :599-628 (NeRF).
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32 == an fmaf chain; 157.3 TFLOP/s nominal, ~140 sustained) on 128 x 128 x 32 block
+// tiles, 4 waves, double-buffered LDS, 2 workgroups per CU.  What makes this kernel's schedule:
+//   * the reduction (M = 65 536 points) is split over row chunks so that ONE resident wave of ~512 workgroups covers
+//     all tiles of all problems (a second, partial wave of workgroups costs a whole extra pass);
+//   * layer widths are ragged (39, 217, 257 ...): a tile's live 32 x 32 sub-tiles are dealt to the four waves ALONG THE
+//     SHORTER LIVE SIDE (wave w owns column sub-tile w and loops over the n live row sub-tiles, or the transpose), so a
+//     tile costs n in 1..4 units instead of always 4, and the row chunks are sized per tile so that every workgroup
+//     gets the same number of MFMAs (cost-weighted split);
+//   * partial tiles go to a workspace with plain stores and a second kernel adds them up in a fixed order: run-to-run
+//     identical gradients, no fp32 atomics (atomics remain the fallback when the caller passes no workspace).
+#include "nudf_common.h"
+#include "nudf_gemm.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDT (BM + 4)   // both operand tiles are straight [k][column] copies; +4 keeps rows 16-byte aligned
+#define T_TILE (BK * LDT)
+#define TN_MAX_TILES 64
+#define TN_WS_TILE (BM * BN + BM)   // floats per workspace slot: 4 waves x 4 sub-tiles x 64 lanes x 16 accumulators + bias
+#define TNF_NO_EPILOGUE 2           // timing experiments only: results are dropped
+#define TNF_NO_BIAS 4
+#define TNF_ATOMICS 8
+#define TNF_UNIFORM_CHUNKS 16
+#define TNF_NO_QUADRANTS 32
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct TnTile {
+  int blk_start;        // first workgroup of this tile; its row chunks are consecutive workgroups
+  int rows_per_block;
+  short prob, ti, tj;
+  short layout;         // 0: wave w <-> column sub-tile w, n live row sub-tiles; 1: wave w <-> row sub-tile w, n column
+                        // ones; 2 (full tiles): waves 2 x 2, each a 64 x 64 quadrant = 2 x 2 sub-tiles (n = 4)
+  short n;
+  short pad;
+};
+struct TnPlan {
+  NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
+  TnTile tile[TN_MAX_TILES + 1];   // tile[n_tiles].blk_start = total workgroups
+  int n_tiles, M, prec, flags;
+  float* ws;
+  long long* dbg;                  // tuning: per workgroup {start, end} of wall_clock64 (100 MHz), layout, n
+};
+
+// 32 x 32 sub-tile (row index, column index) held by accumulator s of a wave
+__device__ __forceinline__ int tn_isub(int layout, int wave, int s) {
+  return layout == 0 ? s : layout == 1 ? wave : (wave >> 1) * 2 + (s >> 1);
+}
+__device__ __forceinline__ int tn_jsub(int layout, int wave, int s) {
+  return layout == 0 ? wave : layout == 1 ? s : (wave & 1) * 2 + (s & 1);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
+  float* As = smem;
+  float* Bs = smem + 2 * T_TILE;
+
+  const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
+  int t = 0;
+  while (t + 1 < g.n_tiles && g.tile[t + 1].blk_start <= (int)blockIdx.x) ++t;
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const int chunk = blockIdx.x - tl.blk_start;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const int lda = q.lda1, ldb = q.ldb1;
+  const int mbeg = chunk * tl.rows_per_block;
+  const int mend = min(mbeg + tl.rows_per_block, g.M);
+  const int nk = (mend - mbeg + BK - 1) / BK;
+  const int nfull = (mend - mbeg) / BK;
+
+  const int t_k = tid >> 5;   // row of the k-step this thread copies (+8 per pass)
+  const int t_c4 = tid & 31;  // its float4 column
+
+  // column indices are clamped into the buffer (columns past NA / NB only feed outputs that are never stored).  A FULL
+  // k-step (all 32 rows exist -- every step but the last of the last row chunk) is 8 loads off two per-thread base
+  // pointers and 8 plain LDS stores; only the ragged step clamps rows and zeroes rows >= mend with selects.
+  const float* pa = q.A1 + (size_t)(mbeg + t_k) * lda + min(i0 + t_c4 * 4, lda - 4);
+  const float* pb = q.B1 + (size_t)(mbeg + t_k) * ldb + min(j0 + t_c4 * 4, ldb - 4);
+  f32x4 ra[4], rb[4];
+  int ld_rows = 0;
+  auto gload = [&](int kt) {
+    if (kt < nfull) {
+      const float* a = pa + (size_t)kt * BK * lda;
+      const float* b = pb + (size_t)kt * BK * ldb;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        ra[ps] = *reinterpret_cast<const f32x4*>(a + (size_t)(ps * 8) * lda);
+        rb[ps] = *reinterpret_cast<const f32x4*>(b + (size_t)(ps * 8) * ldb);
+      }
+      ld_rows = BK;
+      return;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int mc = min(kt * BK + ps * 8, g.M - 1 - mbeg - t_k);   // clamp the row into the buffer
+      ra[ps] = *reinterpret_cast<const f32x4*>(pa + (ptrdiff_t)mc * lda);
+      rb[ps] = *reinterpret_cast<const f32x4*>(pb + (ptrdiff_t)mc * ldb);
+    }
+    ld_rows = mend - (mbeg + kt * BK);   // rows of this k-step that exist (the others are zeroed at the LDS store)
+  };
+  // bias gradient = column sums of A, taken from the registers on their way to LDS (tiles of the first tile column)
+  const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+  auto sstore = [&](int buf) {
+    float* as = As + buf * T_TILE + t_k * LDT + t_c4 * 4;
+    float* bs = Bs + buf * T_TILE + t_k * LDT + t_c4 * 4;
+    if (ld_rows >= BK) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        *reinterpret_cast<f32x4*>(as + ps * 8 * LDT) = ra[ps];
+        *reinterpret_cast<f32x4*>(bs + ps * 8 * LDT) = rb[ps];
+      }
+      if (do_bias) bacc += (ra[0] + ra[1]) + (ra[2] + ra[3]);
+      return;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const bool ok = (ps * 8 + t_k) < ld_rows;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 va = ok ? ra[ps] : z;
+      *reinterpret_cast<f32x4*>(as + ps * 8 * LDT) = va;
+      *reinterpret_cast<f32x4*>(bs + ps * 8 * LDT) = ok ? rb[ps] : z;
+      if (do_bias) bacc += va;
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+
+  const bool live = tl.layout == 2 ? true : tl.layout == 0 ? (j0 + 32 * wave) < q.NB : (i0 + 32 * wave) < q.NA;
+  const int n_w = live ? tl.n : 0;
+
+  if (nk > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+
+  // one k-step of a wave: its FIXED operand (the sub-tile column it owns) against N sub-tiles of the other operand, two
+  // reduction indices per MFMA, LDS reads software-pipelined four MFMA groups ahead
+  auto mma = [&](auto N, auto LAY, int cur) {
+    constexpr int kN = decltype(N)::value, kLay = decltype(LAY)::value;
+    if constexpr (kLay == 2) {   // 64 x 64 quadrant: 2 + 2 operand reads per 4 MFMAs
+      const float* as = As + cur * T_TILE + (lane >> 5) * LDT + (wave >> 1) * 64 + (lane & 31);
+      const float* bs = Bs + cur * T_TILE + (lane >> 5) * LDT + (wave & 1) * 64 + (lane & 31);
+      float av[2][4][2], bv[2][4][2];
+      auto rd = [&](int set, int c) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int kk = c * 4 + qd;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) av[set][qd][i] = as[(2 * kk) * LDT + 32 * i];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bv[set][qd][j] = bs[(2 * kk) * LDT + 32 * j];
+        }
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        if (c + 1 < BK / 8) rd((c + 1) & 1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][qd][i], bv[c & 1][qd][j], acc[i * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+    const float* fx = (kLay == 0 ? Bs : As) + cur * T_TILE + (lane >> 5) * LDT + 32 * wave + (lane & 31);
+    const float* vr = (kLay == 0 ? As : Bs) + cur * T_TILE + (lane >> 5) * LDT + (lane & 31);
+    float fv[2][4], vv[2][4][4];
+    auto rd = [&](int set, int c) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int kk = c * 4 + qd;
+        fv[set][qd] = fx[(2 * kk) * LDT];
+#pragma unroll
+        for (int s = 0; s < kN; ++s) vv[set][qd][s] = vr[(2 * kk) * LDT + 32 * s];
+      }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      if (c + 1 < BK / 8) rd((c + 1) & 1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int s = 0; s < kN; ++s)
+          acc[s] = kLay == 0 ? __builtin_amdgcn_mfma_f32_32x32x2f32(vv[c & 1][qd][s], fv[c & 1][qd], acc[s], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x2f32(fv[c & 1][qd], vv[c & 1][qd][s], acc[s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // config-5 mode: bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Lane (i, h) of an operand holds the 8
+  // reduction indices 8h .. 8h+7 of its column: 8 strided ds_read_b32 of the SAME fp32 LDS tiles, converted on the fly
+  // (RNE).  16x the fp32 MFMA rate, so this loop is bound by the LDS reads / HBM, not by the matrix pipe.
+  auto mma16 = [&](auto N, auto LAY, int cur) {
+    constexpr int kN = decltype(N)::value, kLay = decltype(LAY)::value;
+    if constexpr (kLay == 2) {
+      const float* as = As + cur * T_TILE + (8 * (lane >> 5)) * LDT + (wave >> 1) * 64 + (lane & 31);
+      const float* bs = Bs + cur * T_TILE + (8 * (lane >> 5)) * LDT + (wave & 1) * 64 + (lane & 31);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 a16[2], b16[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = as[(16 * kk + e) * LDT + 32 * i];
+          a16[i] = __builtin_convertvector(v, bf16x8);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = bs[(16 * kk + e) * LDT + 32 * j];
+          b16[j] = __builtin_convertvector(v, bf16x8);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16[i], b16[j], acc[i * 2 + j], 0, 0, 0);
+      }
+      return;
+    }
+    const float* fx = (kLay == 0 ? Bs : As) + cur * T_TILE + (8 * (lane >> 5)) * LDT + 32 * wave + (lane & 31);
+    const float* vr = (kLay == 0 ? As : Bs) + cur * T_TILE + (8 * (lane >> 5)) * LDT + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      f32x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fx[(16 * kk + e) * LDT];
+      const bf16x8 f16 = __builtin_convertvector(v, bf16x8);
+#pragma unroll
+      for (int s = 0; s < kN; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = vr[(16 * kk + e) * LDT + 32 * s];
+        const bf16x8 v16 = __builtin_convertvector(v, bf16x8);
+        acc[s] = kLay == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(v16, f16, acc[s], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(f16, v16, acc[s], 0, 0, 0);
+      }
+    }
+  };
+  // the k-loop is instantiated ONCE PER (sub-tile count, layout, precision), chosen outside the loop: a shape switch
+  // inside it made the compiler copy all 64 accumulator registers (behind an MFMA drain) on every k-step
+  auto kloop = [&](auto N, auto LAY, auto P16) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+      if constexpr (decltype(N)::value > 0) {
+        if constexpr (decltype(P16)::value != 0) mma16(N, LAY, cur);
+        else mma(N, LAY, cur);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) sstore(cur ^ 1);
+      __syncthreads();
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  auto by_prec = [&](auto N, auto LAY) {
+    if (g.prec != 0) kloop(N, LAY, I1{});
+    else kloop(N, LAY, I0{});
+  };
+  if (n_w == 0) by_prec(I0{}, I0{});
+  else if (tl.layout == 2) by_prec(I4{}, I2{});
+  else if (tl.layout == 0) {
+    if (n_w == 4) by_prec(I4{}, I0{});
+    else if (n_w == 3) by_prec(I3{}, I0{});
+    else if (n_w == 2) by_prec(I2{}, I0{});
+    else by_prec(I1{}, I0{});
+  } else {
+    if (n_w == 3) by_prec(I3{}, I1{});
+    else if (n_w == 2) by_prec(I2{}, I1{});
+    else by_prec(I1{}, I1{});                 // n = 4 never takes this layout (ties go to layout 0)
+  }
+
+  if (g.dbg && tid == 0) {
+    long long* d = g.dbg + 4 * (size_t)blockIdx.x;
+    d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = tl.layout * 16 + tl.n; d[3] = nk;
+  }
+  if (g.flags & TNF_NO_EPILOGUE) return;
+  float* slot = g.ws ? g.ws + (size_t)blockIdx.x * TN_WS_TILE : nullptr;
+  if (do_bias) {   // the loop's last barrier has passed: the operand tiles are free
+    *reinterpret_cast<f32x4*>(smem + t_k * BM + t_c4 * 4) = bacc;
+    __syncthreads();
+    if (tid < BM) {
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += smem[k * BM + tid];
+      if (slot) slot[BM * BN + tid] = s;
+      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, s);
+    }
+  }
+  if (n_w == 0) return;
+  if (slot) {   // accumulator register order, 64 contiguous bytes per lane
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s >= n_w) break;
+      float* w = slot + ((wave * 4 + s) * 64 + lane) * 16;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {acc[s][4 * qd], acc[s][4 * qd + 1], acc[s][4 * qd + 2], acc[s][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s >= n_w) break;
+    const int isub = tn_isub(tl.layout, wave, s), jsub = tn_jsub(tl.layout, wave, s);
+    const int col = j0 + 32 * jsub + (lane & 31);
+    if (col >= q.NB) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = i0 + 32 * isub + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s][r]);
+    }
+  }
+}
+
+// second pass of the workspace path: C[tile] += sum over the tile's row chunks of the partial tiles, in chunk order
+// (fixed association -> run-to-run identical), one float4 of accumulator registers per thread; slice 16 = the bias.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(TnPlan g) {
+  const int t = blockIdx.x / 17, slice = blockIdx.x % 17;
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const int chunks = g.tile[t + 1].blk_start - tl.blk_start;
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const float* ws = g.ws + (size_t)tl.blk_start * TN_WS_TILE;
+  if (slice == 16) {
+    if (!q.dbias || tl.tj != 0 || (g.flags & TNF_NO_BIAS)) return;
+    const int col = threadIdx.x;
+    if (col >= BM || i0 + col >= q.NA) return;
+    float s = 0.0f;
+    for (int c = 0; c < chunks; ++c) s += ws[(size_t)c * TN_WS_TILE + BM * BN + col];
+    q.dbias[i0 + col] += s;
+    return;
+  }
+  const int e = (slice * 256 + threadIdx.x) * 4;            // first of 4 accumulator registers
+  const int r0 = e & 15, lane = (e >> 4) & 63, s = (e >> 10) & 3, wave = e >> 12;
+  const int isub = tn_isub(tl.layout, wave, s), jsub = tn_jsub(tl.layout, wave, s);
+  const int row = i0 + 32 * isub + 8 * (r0 >> 2) + 4 * (lane >> 5);
+  const int col = j0 + 32 * jsub + (lane & 31);
+  // same liveness rule as the producer: sub-tiles wholly past NA / NB were never written
+  if (i0 + 32 * isub >= q.NA || j0 + 32 * jsub >= q.NB || col >= q.NB) return;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int c = 0; c < chunks; ++c) sum += *reinterpret_cast<const f32x4*>(ws + (size_t)c * TN_WS_TILE + e);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (row + k < q.NA) q.C[(size_t)(row + k) * q.ldc + col] += sum[k];
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: the plan (tiles, layouts, cost-weighted row chunks) and the C ABI
+// ---------------------------------------------------------------------------------------
+static int g_tn_flags = -1;   // NUDF_TN_FLAGS / nudf_set_tn_flags
+extern "C" int nudf_set_tn_flags(int f) {
+  const int old = g_tn_flags < 0 ? 0 : g_tn_flags;
+  g_tn_flags = f;
+  return old;
+}
+static long long* g_tn_dbg = nullptr;
+extern "C" int nudf_set_tn_debug(void* buf) {   // device buffer of >= 4 int64 per workgroup (or NULL): tuning only
+  g_tn_dbg = (long long*)buf;
+  return 0;
+}
+static int tn_flags() {
+  if (g_tn_flags < 0) { const char* e = getenv("NUDF_TN_FLAGS"); g_tn_flags = e ? atoi(e) : 0; }
+  return g_tn_flags;
+}
+
+// time of one k-step of a tile with n live sub-tiles per wave, in units where a full tile is 4: MFMA work is n, but
+// every k-step also pays the fixed global-load -> LDS -> barrier latency (NUDF_TN_COSTS="c1,c2,c3,c4": tuning hook)
+static double tn_cost(int n) {
+  static double c[4] = {-1.0, 0, 0, 0};
+  if (c[0] < 0) {
+    double d[4] = {2.0, 3.0, 3.5, 4.0};   // measured (scripts/tn_group_bench.py, profiles/r02_tn_gemm.txt)
+    const char* e = getenv("NUDF_TN_COSTS");
+    if (e) sscanf(e, "%lf,%lf,%lf,%lf", &d[0], &d[1], &d[2], &d[3]);
+    for (int i = 3; i >= 0; --i) c[i] = d[i];
+  }
+  return c[n - 1];
+}
+
+// returns the number of workgroups (0: nothing to do, < 0: invalid arguments, error text set)
+static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
+  if (g.n_problems <= 0 || g.M <= 0) return 0;
+  if (g.n_problems > NUDF_TN_MAX_PROBLEMS) {
+    nudf_set_error("nudf_gemm_tn_grouped: too many problems", hipErrorInvalidValue);
+    return -1;
+  }
+  const int flags = tn_flags();
+  double cost[TN_MAX_TILES];
+  int nt = 0;
+  for (int i = 0; i < g.n_problems; ++i) {
+    const NudfGemmTNProblem& q = g.prob[i];
+    if ((q.lda1 % 4) || (q.ldb1 % 4) || q.NA <= 0 || q.NB <= 0 || q.lda1 < 4 || q.ldb1 < 4 ||
+        (((uintptr_t)q.A1) & 15) || (((uintptr_t)q.B1) & 15)) {
+      nudf_set_error("nudf_gemm_tn_grouped: leading dimensions must be multiples of 4, operands 16-byte aligned",
+                     hipErrorInvalidValue);
+      return -1;
+    }
+    pl.prob[i] = q;
+    const int ti_n = (q.NA + BM - 1) / BM, tj_n = (q.NB + BN - 1) / BN;
+    for (int ti = 0; ti < ti_n; ++ti)
+      for (int tj = 0; tj < tj_n; ++tj) {
+        if (nt >= TN_MAX_TILES) {
+          nudf_set_error("nudf_gemm_tn_grouped: more than 64 output tiles of 128 x 128 in one group",
+                         hipErrorInvalidValue);
+          return -1;
+        }
+        int li = (q.NA - ti * BM + 31) / 32, lj = (q.NB - tj * BN + 31) / 32;   // live 32-wide sub-tiles per side
+        if (li > 4) li = 4;
+        if (lj > 4) lj = 4;
+        TnTile& tl = pl.tile[nt];
+        tl.prob = (short)i; tl.ti = (short)ti; tl.tj = (short)tj; tl.pad = 0;
+        tl.layout = (short)(li <= lj ? 0 : 1);
+        tl.n = (short)(li <= lj ? li : lj);
+        if (li == 4 && lj == 4 && !(flags & TNF_NO_QUADRANTS)) tl.layout = 2;
+        cost[nt++] = tn_cost(tl.n);
+      }
+  }
+  pl.n_tiles = nt;
+  pl.M = g.M;
+  pl.prec = g.prec;
+  pl.flags = flags;
+  const int nkt = (g.M + BK - 1) / BK;                 // k-steps over all points
+  int chunks_of[TN_MAX_TILES];
+  if (g.rows_per_block > 0) {
+    for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = g.rows_per_block;
+  } else {
+    // exactly one resident wave of workgroups (2 per CU x 256 CUs; NUDF_TNG_BLOCKS: tuning hook), at least 8 k-steps
+    // per workgroup.  Tile t costs cost[t] MFMA units per k-step: find the smallest per-workgroup budget T for which
+    // sum_t ceil(cost[t] * nkt / T) fits, i.e. every workgroup does (nearly) the same number of MFMAs.
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
+    const int max_chunks = nkt / 8 > 0 ? nkt / 8 : 1;
+    auto count = [&](double T, bool store) {
+      long total = 0;
+      for (int t = 0; t < nt; ++t) {
+        const double c = (flags & TNF_UNIFORM_CHUNKS) ? 4.0 : cost[t];
+        long n = (long)((c * (double)nkt + T - 1e-9) / T);
+        if (n < 1) n = 1;
+        if (n > max_chunks) n = max_chunks;
+        if (store) chunks_of[t] = (int)n;
+        total += n;
+      }
+      return total;
+    };
+    double lo = 0.0, hi = 4.0 * nkt;                   // hi: one chunk per tile (always fits: nt <= 64 <= target)
+    if (count(hi, false) <= target) {
+      for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (count(mid, false) <= target) hi = mid; else lo = mid;
+      }
+    }
+    count(hi, true);
+    for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = ((nkt + chunks_of[t] - 1) / chunks_of[t]) * BK;
+  }
+  int blocks = 0;
+  for (int t = 0; t < nt; ++t) {
+    pl.tile[t].blk_start = blocks;
+    blocks += (g.M + pl.tile[t].rows_per_block - 1) / pl.tile[t].rows_per_block;
+  }
+  pl.tile[nt].blk_start = blocks;
+  return blocks;
+}
+
+extern "C" int64_t nudf_gemm_tn_grouped_workspace(const NudfGemmTNGroup* args) {
+  TnPlan pl;
+  const int blocks = tn_plan(*args, pl);
+  pl.dbg = nullptr;
+  return blocks <= 0 ? (int64_t)blocks : (int64_t)blocks * TN_WS_TILE;
+}
+
+extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
+  TnPlan pl;
+  const int blocks = tn_plan(*args, pl);
+  if (blocks == 0) return 0;
+  if (blocks < 0) return (int)hipErrorInvalidValue;
+  pl.ws = (pl.flags & TNF_ATOMICS) ? nullptr : args->workspace;
+  pl.dbg = g_tn_dbg;
+  if (pl.ws && ((((uintptr_t)pl.ws) & 15) || args->workspace_floats < (int64_t)blocks * TN_WS_TILE)) {
+    nudf_set_error("nudf_gemm_tn_grouped: workspace too small or not 16-byte aligned "
+                   "(nudf_gemm_tn_grouped_workspace gives the size)", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
+  if (pl.ws && !(pl.flags & TNF_NO_EPILOGUE)) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(pl.n_tiles * 17), dim3(256), 0, (hipStream_t)stream, pl);
+    NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped (reduce)");
+  }
+  return 0;
+}
+
+// the two-pair form (dW = dY^T X + DA^T R of one layer): two problems of a group accumulating into the same C
+extern "C" int nudf_gemm_tn(const NudfGemmTN* args, void* stream) {
+  const NudfGemmTN& p = *args;
+  if (p.M <= 0 || p.NA <= 0 || p.NB <= 0) return 0;
+  NudfGemmTNGroup g;
+  memset(&g, 0, sizeof(g));
+  g.M = p.M; g.rows_per_block = p.rows_per_block; g.prec = p.prec;
+  g.n_problems = p.A2 ? 2 : 1;
+  NudfGemmTNProblem& q0 = g.prob[0];
+  q0.A1 = p.A1; q0.B1 = p.B1; q0.C = p.C; q0.dbias = p.dbias;
+  q0.lda1 = p.lda1; q0.ldb1 = p.ldb1; q0.ldc = p.ldc; q0.NA = p.NA; q0.NB = p.NB;
+  if (p.A2) {
+    NudfGemmTNProblem& q1 = g.prob[1];
+    q1 = q0;
+    q1.A1 = p.A2; q1.B1 = p.B2; q1.lda1 = p.lda2; q1.ldb1 = p.ldb2; q1.dbias = nullptr;
+  }
+  return nudf_gemm_tn_grouped(&g, stream);
+}

@@ -17,6 +17,8 @@ from __future__ import annotations
 import math
 from typing import List, Optional
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -209,6 +211,23 @@ class ChainBuilder:
         self.keep = []
 
 
+# scratch of the weight-gradient GEMMs' deterministic two-pass reduction (every workgroup's partial tile, ~33 MB at the
+# headline size): ONE buffer per device, grown on demand -- all launches of this module go to torch's current stream, so
+# consecutive groups never overlap.  TN_DETERMINISTIC = False falls back to fp32 atomics (A-B measurements).
+TN_DETERMINISTIC = True
+_TN_WS = {}
+
+
+def _tn_workspace(g, dev):
+    need = int(_lib.lib().nudf_gemm_tn_grouped_workspace(C.byref(g)))
+    if need <= 0:
+        return None, 0
+    ws = _TN_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _TN_WS[dev] = torch.empty(need, device=dev)
+    return ws, ws.numel()
+
+
 def gemm_tn_grouped(jobs, M):
     """jobs: [(A1 [M, lda], NA, B1 [M, ldb], NB, C [NA_pad, ldc], dbias | None)] -> one launch per <= 12 problems."""
     for base in range(0, len(jobs), _lib.TN_MAX_PROBLEMS):
@@ -222,6 +241,9 @@ def gemm_tn_grouped(jobs, M):
             q.A1, q.B1, q.C, q.dbias = ptr(A1), ptr(B1), ptr(Cm), ptr(db)
             q.lda1, q.ldb1, q.ldc, q.NA, q.NB = A1.shape[1], B1.shape[1], Cm.shape[1], NA, NB
             flops += 2.0 * M * NA * NB
+        if TN_DETERMINISTIC:
+            ws, n = _tn_workspace(g, chunk[0][0].device)
+            g.workspace, g.workspace_floats = ptr(ws), n
         if PROFILE is not None:
             _timed("gemm_tn", flops, lambda: call("nudf_gemm_tn_grouped", g))
         else:

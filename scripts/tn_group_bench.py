@@ -1,0 +1,122 @@
+"""weight-gradient GEMM group of the UDF network at the headline size (M = 65 536 points, the 10 problems of one
+nudf_gemm_tn_grouped launch): time per launch for the tuning bits of nudf_set_tn_flags, correctness against a float64
+torch contraction, and run-to-run determinism of the workspace (two-pass) path.  GPU box only."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from neuraludf_amd import _lib, mlp
+
+dev = torch.device("cuda:0")
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+# (NA = layer outputs, NB = padded layer inputs): 39 -> 256, 3 x 256 -> 256, 256 -> 217, 3 x 256 -> 256, head 256 + 1
+SHAPES = [(256, 40)] + [(256, 256)] * 3 + [(217, 256)] + [(256, 256)] * 3 + [(256, 256), (1, 256)]
+torch.manual_seed(0)
+jobs = []
+for NA, NB in SHAPES:
+    lda = max(4, (NA + 3) // 4 * 4)
+    A = torch.randn(M, lda, device=dev)
+    B = torch.randn(M, NB, device=dev)
+    Cm = torch.zeros((NA + 31) // 32 * 32, NB, device=dev)
+    db = torch.zeros(Cm.shape[0], device=dev)
+    jobs.append((A, NA, B, NB, Cm, db))
+flops = sum(2.0 * M * NA * NB for NA, NB in SHAPES)
+
+
+def run(reps):
+    for _ in range(reps):
+        mlp.gemm_tn_grouped(jobs, M)
+
+
+def timed(tag, flags, deterministic=True, reps=20):
+    _lib.lib().nudf_set_tn_flags(flags)
+    mlp.TN_DETERMINISTIC = deterministic
+    run(3)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    run(reps)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    print(f"{tag:52s} {us:7.1f} us  {flops / us / 1e6:6.1f} TF", flush=True)
+    _lib.lib().nudf_set_tn_flags(0)
+    mlp.TN_DETERMINISTIC = True
+
+
+def results():
+    for j in jobs:
+        j[4].zero_(); j[5].zero_()
+    run(1)
+    torch.cuda.synchronize()
+    return [(j[4].clone(), j[5].clone()) for j in jobs]
+
+
+print(f"M = {M}, {len(SHAPES)} problems, {flops / 1e9:.1f} GFLOP per launch")
+def timeline(tag, flags):
+    """per-workgroup start / end stamps -> duration by tile kind, and the launch's critical path"""
+    import collections
+    dbg = torch.zeros(1024 * 4, dtype=torch.int64, device=dev)
+    _lib.lib().nudf_set_tn_flags(flags)
+    run(2)
+    _lib.lib().nudf_set_tn_debug(dbg.data_ptr())
+    run(1)
+    torch.cuda.synchronize()
+    _lib.lib().nudf_set_tn_debug(None)
+    _lib.lib().nudf_set_tn_flags(0)
+    d = dbg.cpu().view(-1, 4)
+    d = d[d[:, 1] > 0]
+    t0 = int(d[:, 0].min())
+    kinds = collections.defaultdict(list)
+    for s, e, kind, nk in d.tolist():
+        kinds[(kind >> 4, kind & 15, nk)].append(((s - t0) / 100.0, (e - t0) / 100.0))
+    print(f"{tag}: {len(d)} workgroups, launch span {(int(d[:, 1].max()) - t0) / 100.0:.1f} us")
+    for (lay, n, nk), v in sorted(kinds.items()):
+        dur = [b - a for a, b in v]
+        print(f"   layout {lay} n={n} k-steps={nk:4d}: {len(v):3d} wgs, start {min(a for a, _ in v):6.1f}..{max(a for a, _ in v):6.1f} us,"
+              f" duration {min(dur):6.1f}..{max(dur):6.1f} us (mean {sum(dur) / len(dur):6.1f}), {sum(dur) / len(dur) / nk * 1e3:6.0f} ns/k-step,"
+              f" last end {max(b for _, b in v):6.1f}")
+
+
+if os.environ.get("TN_BENCH_TIMELINE"):
+    timeline("cost-weighted (env costs)", 8)
+    timeline("equal chunks", 24)
+    timeline("equal chunks, no quadrant layout", 56)
+    sys.exit(0)
+if os.environ.get("TN_BENCH_QUICK"):   # one line for the environment's NUDF_TN_COSTS / NUDF_TNG_BLOCKS (sweeps)
+    timed("warm-up", 0)
+    timed("costs=%s blocks=%s" % (os.environ.get("NUDF_TN_COSTS", "default"), os.environ.get("NUDF_TNG_BLOCKS", "512")), 0)
+    timed("  same, fp32 atomics", 8, deterministic=False)
+    sys.exit(0)
+for rnd in range(2):      # twice: the first lines of a fresh process also pay clock ramp-up
+    timed("workspace + reduce, cost-weighted chunks (default)", 0)
+    timed("workspace + reduce, equal chunks", 16)
+    timed("fp32 atomics, cost-weighted chunks", 8, deterministic=False)
+    timed("fp32 atomics, equal chunks", 24, deterministic=False)
+    timed("no epilogue at all (timing only)", 2)
+    timed("no epilogue, no bias sums (timing only)", 6)
+    timed("workspace + reduce, cost-weighted, no 2x2 quadrant layout", 32)
+    timed("workspace + reduce, equal chunks, no 2x2 quadrant layout", 48)
+
+# correctness + determinism
+r1, r2 = results(), results()
+same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(r1, r2))
+print("workspace path run-to-run identical:", same)
+mlp.TN_DETERMINISTIC = False
+r3 = results()
+mlp.TN_DETERMINISTIC = True
+worst = 0.0
+for (A, NA, B, NB, _, _), (Cw, dbw), (Ca, dba) in zip(jobs, r1, r3):
+    ref = (A[:, :NA].double().t() @ B.double())
+    refb = A[:, :NA].double().sum(0)
+    sc = ref.abs().max().item()
+    ew = ((Cw[:NA].double() - ref).abs().max() / sc).item()
+    ea = ((Ca[:NA].double() - ref).abs().max() / sc).item()
+    eb = ((dbw[:NA].double() - refb).abs().max() / refb.abs().max()).item()
+    worst = max(worst, ew, ea, eb)
+    assert Cw[NA:].abs().max().item() == 0.0 if Cw.shape[0] > NA else True
+print(f"worst relative error vs float64 (workspace, atomics, bias): {worst:.2e}")
+assert worst < 1e-5 and same
+print("OK")

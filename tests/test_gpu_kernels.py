@@ -89,6 +89,47 @@ def test_gemm_tn(dev):
         assert rel(db, A[:, :NA].double().sum(0).float()) < 2e-5
 
 
+@pytest.mark.parametrize("M", [65, 1000, 20000])
+def test_gemm_tn_grouped_ragged_layouts(dev, M):
+    """the grouped weight-gradient launch on ragged layer widths: tiles whose live 32 x 32 sub-tiles are dealt along
+    the rows (217 x 256), along the columns (256 x 40), a single live row (1 x 256), both ragged (300 x 100), M not a
+    multiple of the k-step -- workspace (two-pass, run-to-run identical) and atomics paths against float64, every
+    scheduling variant (cost-weighted and equal row chunks)."""
+    from neuraludf_amd import _lib, mlp
+    g = torch.Generator().manual_seed(11)
+    shapes = [(256, 40), (217, 256), (256, 256), (1, 256), (300, 100), (33, 7), (129, 129)]
+    jobs, refs = [], []
+    for NA, NB in shapes:
+        lda, ldb = max(4, (NA + 3) // 4 * 4), max(4, (NB + 3) // 4 * 4)
+        A = torch.randn(M, lda, generator=g)
+        B = torch.randn(M, ldb, generator=g)
+        refs.append((A[:, :NA].double().t() @ B[:, :NB].double(), A[:, :NA].double().sum(0)))
+        jobs.append((A.to(dev), NA, B.to(dev), NB, torch.zeros(mlp.pad32(NA), ldb, device=dev),
+                     torch.zeros(mlp.pad32(NA), device=dev)))
+
+    def run():
+        for j in jobs:
+            j[4].zero_(); j[5].zero_()
+        mlp.gemm_tn_grouped(jobs, M)
+        return [(j[4].clone(), j[5].clone()) for j in jobs]
+
+    try:
+        for flags, det in [(0, True), (0, False), (16, True), (16, False)]:
+            _lib.lib().nudf_set_tn_flags(flags)
+            mlp.TN_DETERMINISTIC = det
+            out = run()
+            for (NA, NB), (C, db), (rC, rb) in zip(shapes, out, refs):
+                assert rel(C[:NA, :NB], rC.float()) < 2e-5, (flags, det, NA, NB)
+                assert rel(db[:NA], rb.float()) < 2e-5, (flags, det, NA, NB)
+                assert float(C[NA:].abs().max()) == 0.0 if C.shape[0] > NA else True
+            if det:
+                again = run()
+                assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(out, again))
+    finally:
+        _lib.lib().nudf_set_tn_flags(0)
+        mlp.TN_DETERMINISTIC = True
+
+
 def test_posenc_and_vjp(dev):
     from neuraludf_amd._lib import call, ptr
     g = torch.Generator().manual_seed(2)
