@@ -398,7 +398,8 @@ typedef struct NudfChain {
   const float* v;                  /* [P,3] tangent (JVP), or NULL                                   */
   const float* seed_sign;          /* [P]                                                            */
   const float* seed_wrow;          /* [k0]                                                           */
-  unsigned long long* dbg;         /* NULL, or [blocks*4 waves][32] timeline: hw_id, t0, per step (t_mma, t_epi) */
+  unsigned long long* dbg;         /* NULL, or [blocks*4 waves][64] timeline: hw_id, t0, per step (K loop end,
+                                      after barrier 1, epilogue end, after barrier 2) in s_memtime ticks */
   NudfChainStep step[NUDF_CH_MAX_STEPS];
 } NudfChain;
 int nudf_mlp_chain(const NudfChain* args, void* stream);

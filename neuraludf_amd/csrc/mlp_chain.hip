@@ -30,16 +30,36 @@ struct ChainSmem {
   float vs[TM * 3];
 };
 
-// write PE(x) (or its JVP) * scale into activation columns [col0, col0 + E) (+ optional global mirror)
+// write PE(x) (or its JVP) * scale into activation columns [col0, col0 + E) (+ optional global mirror).
+// One work item per (point, coordinate, octave): ONE sincosf gives the sin and the cos column of that octave (the
+// per-element form called sinf or cosf once per column: 2.2x the libm calls; the PE of a 64-point tile took 46 k
+// cycles, 6 % of a forward sweep).  Same arguments 2^k x and the same libm kernels as the per-element form.
 template <int TM>
 __device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& p, int m0, int col0, float scale,
                                             float* gdst, int ldg, int gcol0, int zero_to) {
-  const int E = 3 * (2 * p.pe_L + 1);
-  for (int e = threadIdx.x; e < TM * E; e += CH_THREADS) {
-    const int r = e / E, c = e - r * E;
-    const float val = ch_pe(sm.xs + r * 3, sm.vs + r * 3, c, p.pe_L, p.pe_in_scale, p.pe_jvp) * scale;
-    sm.act[r * CH_LD + col0 + c] = val;
-    if (gdst && (m0 + r) < p.P) gdst[(size_t)(m0 + r) * ldg + gcol0 + c] = val;
+  const int L = p.pe_L;
+  const int E = 3 * (2 * L + 1);
+  for (int it = threadIdx.x; it < TM * 3 * (L + 1); it += CH_THREADS) {
+    const int rj = it / (L + 1), k = it - rj * (L + 1) - 1;   // k = -1: the identity column
+    const int r = rj / 3, j = rj - 3 * r;
+    const float xv = sm.xs[rj] * p.pe_in_scale;
+    const float tv = sm.vs[rj] * p.pe_in_scale;
+    float* arow = sm.act + r * CH_LD + col0;
+    float* grow = (gdst && (m0 + r) < p.P) ? gdst + (size_t)(m0 + r) * ldg + gcol0 : nullptr;
+    auto put = [&](int c, float val) {
+      val *= scale;
+      arow[c] = val;
+      if (grow) grow[c] = val;
+    };
+    if (k < 0) {
+      put(j, p.pe_jvp ? tv : xv);
+    } else {
+      const float f = (float)(1 << k);
+      float sn, cs;
+      sincosf(xv * f, &sn, &cs);
+      put(3 + 6 * k + j, p.pe_jvp ? cs * f * tv : sn);
+      put(6 + 6 * k + j, p.pe_jvp ? -sn * f * tv : cs);
+    }
   }
   // zero padding columns [col0 + E, zero_to) so that the K padding of the next GEMM multiplies finite zeros
   const int npad = zero_to - (col0 + E);
@@ -200,9 +220,10 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
 // around whole 16-element loops, the column predicate (N may end inside the tile) is one exec region, rows
 // need no predicate because every output / operand buffer is row-padded to the tile size (see nudf.h).
 // Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
-template <int EPI>
+template <int EPI, bool X2IN = false>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
-                                                 int h, int ln, f32x16 a, float (&x1)[16], bool load_x1) {
+                                                 int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
+                                                 const float* x2in = nullptr) {
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -226,8 +247,11 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
   }
-  if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD || EPI == NUDF_CH_ADDMASK || EPI == NUDF_CH_RELUADD) {
-    if (st.X2) {
+  if (CH_USES_X2(EPI)) {
+    if (X2IN) {   // fetched by the caller one tile ahead (ch_epilogue_seq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[r] = x2in[r];
+    } else if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) x2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
@@ -338,12 +362,51 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
   }
 }
 
+// Epilogues with a SECOND stored operand (X2: tangent, adjoint, ReLU joins), full-height wave blocks: the tiles as
+// straight-line code, the X2 values of tile t+1 requested BEFORE tile t is computed and stored.  The per-tile loop
+// below asked for X2 at the top of each tile, i.e. after the previous tile's 16-32 stores: vmcnt is in order, so the
+// wait for those loads also waited for the stores' acknowledgements -- one full HBM round trip per tile with nothing
+// else in flight (X2 loads + stores were 10 % + 13 % of the tangent sweep, scripts/chain_timeline.py).  Accumulators
+// and the prefetched X1 are read from their home registers (no per-tile copies), which pays for the second buffer.
+template <int EPI, int NRT, int NCT>
+__device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
+                                                int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16]) {
+  float xb[2][16];
+  auto issue = [&](float (&x)[16], int i, int j) {
+    const int col = (ct0 + j) * 32 + ln;
+    const unsigned vo = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx2 + (unsigned)((col < st.N) ? col : 0);
+    if (st.X2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = 0.0f;
+    }
+  };
+  constexpr int NTL = NRT * NCT;
+  issue(xb[0], 0, 0);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (t + 1 < NTL) issue(xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
+    ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT],
+                                px1[t / NCT][t % NCT], false, xb[t & 1]);
+  }
+}
+
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
 template <int EPI>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
                                             const float (&px1)[2][2][16]) {
   constexpr bool PF = CH_USES_X1(EPI);
+  if constexpr (CH_USES_X2(EPI)) {
+    if (st.prec == 0 && nrt == 2) {
+      float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
+      if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1);
+      else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1);
+      return;
+    }
+  }
   const int ntiles = nrt * nct;
 #pragma unroll 1
   for (int t = 0; t < ntiles; ++t) {
@@ -443,7 +506,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
     for (unsigned d = 0; d < k; ++d) __builtin_amdgcn_s_sleep(127);
   }
 
-  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 32 : nullptr;
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 64 : nullptr;
   if (dbg && lane == 0) {
     dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     dbg[1] = __builtin_amdgcn_s_memtime();
@@ -520,8 +583,9 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
         else ch_mma<1, 1, false>(arow, bptr, bstride, G, acc, pf, px1);
       }
     }
-    if (dbg && lane == 0) dbg[2 + 2 * si] = __builtin_amdgcn_s_memtime();
+    if (dbg && lane == 0) dbg[2 + 4 * si] = __builtin_amdgcn_s_memtime();
     __syncthreads();  // every wave is done reading the activation tile
+    if (dbg && lane == 0) dbg[3 + 4 * si] = __builtin_amdgcn_s_memtime();
 
     if (nct > 0) {
       switch (st.epi) {
@@ -538,7 +602,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
         default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
       }
     }
-    if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();
+    if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
     if (st.pe_tail_col >= 0) {
       __syncthreads();
       // zero up to the next multiple of 16 columns: the K padding of the step that consumes [.. | PE] must multiply
@@ -548,6 +612,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
                       min((pe_end + 15) & ~15, 288));
     }
     __syncthreads();
+    if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
   }
 }
 

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfC
   }
   chr_wave_sync();
 
-  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * CHR_WAVES + wave) * 32 : nullptr;
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * CHR_WAVES + wave) * 64 : nullptr;
   if (dbg && lane == 0) {
     dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     dbg[1] = __builtin_amdgcn_s_memtime();
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfC
       default: chr_mma<8>(arow, bptr, bstride, G, bb, acc, tail); break;
     }
     *reinterpret_cast<f32x4*>(sm.bias[wave][(si + 1) & 1] + 4 * lane) = nbias;
-    if (dbg && lane == 0) dbg[2 + 2 * si] = __builtin_amdgcn_s_memtime();
+    if (dbg && lane == 0) dbg[2 + 4 * si] = dbg[3 + 4 * si] = __builtin_amdgcn_s_memtime();
 
     switch (st.epi) {
       case NUDF_CH_SOFTPLUS: chr_epilogue<NUDF_CH_SOFTPLUS, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfC
       case NUDF_CH_RELUADD: if (XCLS >= 2) chr_epilogue<NUDF_CH_RELUADD, W>(st, act, cs, NT, h, ln, acc, px1, px2); break;
       default: break;
     }
-    if (dbg && lane == 0) dbg[3 + 2 * si] = __builtin_amdgcn_s_memtime();
+    if (dbg && lane == 0) dbg[4 + 4 * si] = dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
     chr_wave_sync();
     if (st.pe_tail_col >= 0) {
       const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);

@@ -1,41 +1,91 @@
-"""per-wave timeline of the fused chain kernel (s_memtime stamps): shows how the workgroups sharing a CU interleave."""
-import sys, os
+"""per-wave timelines of the fused chain kernel (s_memtime stamps: K loop end, after barrier 1, epilogue end, after
+barrier 2 of every step) for the UDF sweeps of a train step at P points: where do the cycles of a wave go, and how busy
+is each SIMD's matrix pipe (two waves per SIMD: one of each of the CU's two workgroups)?"""
+import collections
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
 import torch
+
 from common import build_modules, perturb_
 from neuraludf_amd import mlp
 from neuraludf_amd.models import fields
+
 dev = torch.device("cuda:0")
-mods = perturb_(build_modules(fields, seed=0))
-eng = mods["udf"].to(dev).engine()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-x = (torch.rand(P, 3) * 2 - 1).to(dev)
-eng.forward(x, False, udf_only=True)
-nb = (P + 63) // 64
-dbg = torch.zeros(nb * 4, 32, dtype=torch.int64, device=dev)
-mlp.CHAIN_DEBUG = dbg
-eng.forward(x, False, udf_only=True)
+mods = perturb_(build_modules(fields, seed=0))
+udf, col = mods["udf"].to(dev), mods["color"].to(dev)
+eng, ceng = udf.engine(), col.engine()
+g = torch.Generator().manual_seed(0)
+x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+d_udf = torch.randn(P, generator=g).to(dev)
+d_g = torch.randn(P, 3, generator=g).to(dev)
+d_feat = torch.randn(P, ceng.cin_ld, generator=g).to(dev)
+
+launches = []
+orig_launch = mlp.ChainBuilder.launch
+
+
+def launch(self):
+    if mlp.CHAIN_DEBUG is not None:
+        nb = (P + 31) // 32
+        dbg = torch.zeros(nb * 4, 64, dtype=torch.int64, device=dev)
+        mlp.CHAIN_DEBUG = dbg
+        steps = [(int(self.c.step[i].epi), int(self.c.step[i].K), int(self.c.step[i].N)) for i in range(self.n)]
+        launches.append((dbg, steps, self.flops))
+    orig_launch(self)
+
+
+mlp.ChainBuilder.launch = launch
+
+
+def run():
+    st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
+    gr, DA = eng.gradient(x, st)
+    eng.backward(x, st, DA, d_udf, d_feat, ceng.cin_ld, d_g)
+
+
+run()
+torch.cuda.synchronize()
+mlp.CHAIN_DEBUG = torch.zeros(1, dtype=torch.int64, device=dev)
+run()
 torch.cuda.synchronize()
 mlp.CHAIN_DEBUG = None
-d = dbg.cpu().numpy()
-hw = d[:, 0]
-wave_id = hw & 0xf; simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
-t0 = d[:, 1].min()
-import collections
-# group waves by (se, sh, cu, simd) -- XCC id is not in HW_ID, so several XCDs alias; use start-time clustering too
-key = collections.defaultdict(list)
-for i in range(d.shape[0]):
-    key[(int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]))].append(i)
-print("waves", d.shape[0], "distinct (se,sh,cu,simd)", len(key))
-print("wave_id histogram", collections.Counter(wave_id.tolist()))
-k0 = sorted(key)[0]
-for k in [k0]:
-    print("SIMD", k)
-    for i in sorted(key[k], key=lambda i: d[i, 1])[:8]:
-        st = d[i, 1:20]
-        mma = [int(st[1 + 2 * s] - (st[2 * s] if s == 0 else st[2 * s])) for s in range(9)]
-        epi = [int(st[2 + 2 * s] - st[1 + 2 * s]) for s in range(9)]
-        print("blk", i // 4, "w", i % 4, "slot", int(wave_id[i]), "start", int(st[0] - t0), "total", int(st[18] - st[0]))
-        print("    mma+wait", mma)
-        print("    epilogue", epi)
+from neuraludf_amd._lib import CH as _CH
+EPI = {v: k for k, v in _CH.items()}
+
+for li, (dbg, steps, flops) in enumerate(launches):
+    d = dbg.cpu().numpy()
+    d = d[d[:, 1] > 0]
+    n = len(steps)
+    t0 = d[:, 1].min()
+    tend = d[:, 5 + 4 * (n - 1)].max()
+    span = float(tend - t0)
+    # phases per wave
+    k = np.zeros(len(d)); w1 = np.zeros(len(d)); ep = np.zeros(len(d)); w2 = np.zeros(len(d))
+    prev = d[:, 1].astype(np.float64)
+    per_step = []
+    for s in range(n):
+        a, b, c, e = (d[:, 2 + 4 * s + j].astype(np.float64) for j in range(4))
+        k += a - prev; w1 += b - a; ep += c - b; w2 += e - c
+        per_step.append(((a - prev).mean(), (b - a).mean(), (c - b).mean(), (e - c).mean()))
+        prev = e
+    tot = k + w1 + ep + w2
+    mfma_cycles = flops / P * 64 / 4 / (2 * 32 * 32 * 2) * 64     # per wave of a 64-point tile: flops/point * 64 / 4 waves / flops per MFMA * 64
+    print(f"launch {li}: {n} steps, {len(d)} waves, span {span:.0f} ticks, flops/point {flops / P:.0f}")
+    print(f"   per wave (mean ticks): K loop {k.mean():8.0f} ({k.mean() / tot.mean():5.1%})  barrier-1 wait {w1.mean():7.0f} ({w1.mean() / tot.mean():5.1%})"
+          f"  epilogue {ep.mean():7.0f} ({ep.mean() / tot.mean():5.1%})  barrier-2 wait {w2.mean():7.0f} ({w2.mean() / tot.mean():5.1%})  total {tot.mean():8.0f}")
+    print(f"   MFMA ticks needed per wave {mfma_cycles:8.0f}: K-loop efficiency {mfma_cycles / k.mean():5.1%} (2 waves share a SIMD: 50 % = pipe saturated),"
+          f" wave-level MFMA share {mfma_cycles / tot.mean():5.1%}")
+    for s, (epi, K, N) in enumerate(steps):
+        a, b, c, e = per_step[s]
+        print(f"      step {s:2d} epi {EPI.get(epi, epi)!s:9s} K {K:3d} N {N:3d}: K loop {a:7.0f}  wait1 {b:6.0f}  epilogue {c:6.0f}  wait2 {e:6.0f}")
+    # per-SIMD matrix-pipe occupancy: group waves by (hw id without wave slot) and start time
+    hw = d[:, 0]
+    key = collections.defaultdict(list)
+    for i in range(len(d)):
+        key[int(hw[i]) >> 4].append(i)
+    print(f"   distinct (se, sh, cu, simd) keys {len(key)} (XCC id is not part of HW_ID: 8 XCDs alias)")
