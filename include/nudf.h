@@ -380,14 +380,28 @@ typedef struct NudfChainStep {
   float* pe_dst;                   /* ... and at the same columns of pe_dst [P, ld_pe] (or NULL)                */
   float pe_tail_scale;
   float scale, xscale;
+  int32_t layout;                  /* NUDF_CH_BLK_* bits: which of this step's [P, ld] buffers use the BLOCKED layout */
 } NudfChainStep;
+/* Blocked layout of a [P, ld] buffer (P padded to 32 rows, ld % 4 == 0): element (r, c) lives at
+ *   (r / 32) * 32 * ld + (c / 4) * 128 + (r % 32) * 4 + (c % 4)
+ * i.e. inside every 32-row block the four-column quads are stored one after the other, 32 rows x 16 bytes each.  The
+ * transposed-product chain kernel (tile_rows = 66: accumulator lane = point, registers = quads of features) then moves
+ * 1 KB of CONTIGUOUS memory per wave instruction for its stored-state operands and outputs, and a [32 x 128] operand
+ * tile of the weight-gradient GEMM is 16 KB contiguous.  Only that kernel and nudf_gemm_tn_grouped read the layout. */
+#define NUDF_CH_BLK_X1 1
+#define NUDF_CH_BLK_X2 2
+#define NUDF_CH_BLK_C1 4
+#define NUDF_CH_BLK_C2 8
+#define NUDF_CH_BLK_PE 16           /* pe_dst */
 typedef struct NudfChain {
   int32_t P, n_steps;
   int32_t init;                    /* NUDF_CH_INIT_*                                                 */
   int32_t k0;                      /* initial tile width (multiple of 4, <= 288)                     */
   int32_t x_div;                   /* x row of point p is p / x_div (samples per ray for per-ray directions; >= 1) */
-  int32_t tile_rows;               /* 0 = choose; 32 / 64 points per workgroup (shared tile); 128 = prefer the
-                                      wave-private kernel (4 waves x 32 points; fp32 steps, 16-byte aligned rows) */
+  int32_t tile_rows;               /* 0 = choose; 32 / 64 points per workgroup (shared tile); 66 = 64-point shared tile,
+                                      transposed product (16-byte epilogue accesses); 128 = prefer the wave-private
+                                      kernel (4 waves x 32 points); 66 / 128 need fp32 steps and 16-byte aligned rows
+                                      and fall back to 64 otherwise */
   int32_t lda0, ldg0;
   int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */
   float pe_in_scale;

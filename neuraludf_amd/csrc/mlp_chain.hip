@@ -30,44 +30,10 @@ struct ChainSmem {
   float vs[TM * 3];
 };
 
-// write PE(x) (or its JVP) * scale into activation columns [col0, col0 + E) (+ optional global mirror).
-// One work item per (point, coordinate, octave): ONE sincosf gives the sin and the cos column of that octave (the
-// per-element form called sinf or cosf once per column: 2.2x the libm calls; the PE of a 64-point tile took 46 k
-// cycles, 6 % of a forward sweep).  Same arguments 2^k x and the same libm kernels as the per-element form.
 template <int TM>
 __device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& p, int m0, int col0, float scale,
                                             float* gdst, int ldg, int gcol0, int zero_to) {
-  const int L = p.pe_L;
-  const int E = 3 * (2 * L + 1);
-  for (int it = threadIdx.x; it < TM * 3 * (L + 1); it += CH_THREADS) {
-    const int rj = it / (L + 1), k = it - rj * (L + 1) - 1;   // k = -1: the identity column
-    const int r = rj / 3, j = rj - 3 * r;
-    const float xv = sm.xs[rj] * p.pe_in_scale;
-    const float tv = sm.vs[rj] * p.pe_in_scale;
-    float* arow = sm.act + r * CH_LD + col0;
-    float* grow = (gdst && (m0 + r) < p.P) ? gdst + (size_t)(m0 + r) * ldg + gcol0 : nullptr;
-    auto put = [&](int c, float val) {
-      val *= scale;
-      arow[c] = val;
-      if (grow) grow[c] = val;
-    };
-    if (k < 0) {
-      put(j, p.pe_jvp ? tv : xv);
-    } else {
-      const float f = (float)(1 << k);
-      float sn, cs;
-      sincosf(xv * f, &sn, &cs);
-      put(3 + 6 * k + j, p.pe_jvp ? cs * f * tv : sn);
-      put(6 + 6 * k + j, p.pe_jvp ? -sn * f * tv : cs);
-    }
-  }
-  // zero padding columns [col0 + E, zero_to) so that the K padding of the next GEMM multiplies finite zeros
-  const int npad = zero_to - (col0 + E);
-  if (npad > 0)
-    for (int e = threadIdx.x; e < TM * npad; e += CH_THREADS) {
-      const int r = e / npad, c = e - r * npad;
-      sm.act[r * CH_LD + col0 + E + c] = 0.0f;
-    }
+  ch_write_pe_rows<CH_THREADS>(sm.act, sm.xs, sm.vs, TM, threadIdx.x, p, m0, col0, scale, gdst, ldg, gcol0, zero_to);
 }
 
 // K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
@@ -510,6 +476,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
   if (dbg && lane == 0) {
     dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     dbg[1] = __builtin_amdgcn_s_memtime();
+    dbg[62] = wall_clock64();      // 100 MHz reference: (s_memtime span) / (wall span) = the shader clock the sweep ran at
   }
 
   // ---- the layer chain ---------------------------------------------------------------------------
@@ -614,10 +581,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
     __syncthreads();
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
   }
+  if (dbg && lane == 0) dbg[63] = wall_clock64();
 }
 
 int nudf_chain_rows_class(const NudfChain& p);                              // mlp_chain_rows.hip
 int nudf_mlp_chain_rows_launch(const NudfChain& p, int cls, hipStream_t st);
+int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st);
 
 // NUDF_CHAIN_ROWS=1 lets large launches choose the wave-private kernel on their own (measured in round 2: equal to
 // the workgroup-shared tiles on the forward sweeps, 10-20 % slower on the sweeps that stream stored state, see
@@ -628,6 +597,21 @@ static bool nudf_chain_rows_auto() {
     return (e && e[0] == '1') ? 1 : 0;
   }();
   return on != 0;
+}
+
+// The transposed-product form of the 64-point tile (mlp_chain_rows.hip, tile_rows = 66: 16-byte epilogue accesses).
+// Measured at 65 536 points against mlp_chain_kernel<64> (profiles/r02_chain_timeline.txt): per-wave time -8 % / -6 % on
+// the UDF forward / input-gradient sweeps, +9 % / +5 % on the tangent / adjoint sweeps (two stored operands and two
+// outputs per layer: with row-major buffers each 16-byte-per-lane access touches 32 different 128-byte lines); with the
+// BLOCKED layout of nudf.h addressed instead (timing only) -8 / -10 / -7 / -4 %.  Over a whole train step the
+// forward / gradient gain is inside the noise (3.95 vs 3.98 ms of chain time), so the default stays mlp_chain_kernel:
+// NUDF_CHAIN_QUAD=1 uses the transposed form for launches with at most one stored operand, =2 for every launch.
+static int nudf_chain_quad_mode() {
+  static const int mode = [] {
+    const char* e = getenv("NUDF_CHAIN_QUAD");
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
 }
 
 extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
@@ -656,6 +640,10 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0) return nudf_mlp_chain_rows_launch(p, cls, st);
     // contract of the wave-private kernel not met (16-bit operands, unaligned row buffers): workgroup-shared tiles
+  }
+  if (p.tile_rows == 66 || (p.tile_rows == 0 && p.P > 256 * 64 && nudf_chain_quad_mode() > 0)) {
+    const int cls = nudf_chain_rows_class(p);
+    if (cls >= 0 && (p.tile_rows == 66 || cls <= 1 || nudf_chain_quad_mode() >= 2)) return nudf_mlp_chain_tq_launch(p, cls, st);
   }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {

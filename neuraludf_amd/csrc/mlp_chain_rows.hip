@@ -19,6 +19,7 @@
 //  * the 4 waves of a workgroup read the same weight fragments; re-aligning them with a barrier per step
 //    (CHR_STEP_SYNC) so that three of the four reads hit the CU's vector L1 measured 3 % SLOWER and is off.
 #include "mlp_chain_shared.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #define CHR_WAVES 4
@@ -77,7 +78,9 @@ typedef const float __attribute__((address_space(1)))* chr_gcp;
 typedef float __attribute__((address_space(1)))* chr_gp;
 
 struct ChrStep {
-  unsigned row, x1, x2, c1, c2;          // per lane: row and row * ld of the step's buffers
+  unsigned row, x1, x2, c1, c2;          // per lane: row and the offset of its first feature in the step's buffers
+  unsigned m1, m2, mc1, mc2;             // offset of feature f = base + f * m: 1 (row-major) or 32 (blocked layout,
+                                         // f % 4 == 0: quads of a 32-row block are 512 contiguous bytes, see nudf.h)
   chr_gcp X1, X2;
   chr_gp C1, C2;
   int N, nq, iparam, act_col0, act_write, lim1, lim2;
@@ -89,16 +92,19 @@ struct ChrStep {
 // used, so the loads carry no predicate.
 typedef const f32x4 __attribute__((address_space(1)))* chr_gcp4;
 typedef f32x4 __attribute__((address_space(1)))* chr_gp4;
-__device__ __forceinline__ f32x4 chr_load_quad(chr_gcp X, unsigned rowoff, int f0, int nq) {
-  return *(chr_gcp4)(X + (rowoff + (unsigned)min(f0, nq)));
+__device__ __forceinline__ f32x4 chr_load_quad(chr_gcp X, unsigned base, int f0, int nq, unsigned mult = 1u) {
+  return *(chr_gcp4)(X + (base + (unsigned)min(f0, nq) * mult));
 }
 
 // features [lo, hi) -> C[row, f - shift], element-wise (heads, split outputs)
-__device__ __forceinline__ void chr_store_range(chr_gp C, unsigned rowoff, int f0, int lo, int hi, int shift,
-                                                const f32x4& v) {
+__device__ __forceinline__ void chr_store_range(chr_gp C, unsigned base, int f0, int lo, int hi, int shift,
+                                                const f32x4& v, unsigned mult = 1u) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (f0 + i >= lo && f0 + i < hi) C[rowoff + (unsigned)(f0 + i - shift)] = v[i];
+    if (f0 + i >= lo && f0 + i < hi) {
+      const unsigned c = (unsigned)(f0 + i - shift);
+      C[base + (mult == 1u ? c : (c & ~3u) * 32u + (c & 3u))] = v[i];
+    }
 }
 
 // Epilogue of one [32 points x 32 features] accumulator tile (bias already inside the accumulator), streamed as four
@@ -172,12 +178,12 @@ __device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act
     // this quad of the window is consumed: request it for tile t_next (in place)
     if (reload) {
       if (U1) {
-        const f32x4 nv = chr_load_quad(cs.X1, cs.x1, 32 * t_next + 4 * h + 8 * q, cs.nq);
+        const f32x4 nv = chr_load_quad(cs.X1, cs.x1, 32 * t_next + 4 * h + 8 * q, cs.nq, cs.m1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w1[4 * q + i] = nv[i];
       }
       if (U2 && cs.X2) {
-        const f32x4 nv = chr_load_quad(cs.X2, cs.x2, 32 * t_next + 4 * h + 8 * q, cs.nq);
+        const f32x4 nv = chr_load_quad(cs.X2, cs.x2, 32 * t_next + 4 * h + 8 * q, cs.nq, cs.m2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w2[4 * q + i] = nv[i];
       }
@@ -191,18 +197,18 @@ __device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act
       continue;
     }
     if (EPI == NUDF_CH_SIGMOIDN) {
-      if (cs.C1) chr_store_range(cs.C1, cs.c1, f0, 0, min(N, cs.iparam), 0, o);
+      if (cs.C1) chr_store_range(cs.C1, cs.c1, f0, 0, min(N, cs.iparam), 0, o, cs.mc1);
       if (cs.C2) {
-        if (N <= cs.iparam) chr_store_range(cs.C2, cs.c2, f0, 0, N, 0, o);             // C2 mirrors the sigmoid outputs
-        else chr_store_range(cs.C2, cs.c2, f0, cs.iparam, N, cs.iparam, o2);           // raw columns
+        if (N <= cs.iparam) chr_store_range(cs.C2, cs.c2, f0, 0, N, 0, o, cs.mc2);             // C2 mirrors the sigmoid outputs
+        else chr_store_range(cs.C2, cs.c2, f0, cs.iparam, N, cs.iparam, o2, cs.mc2);   // raw columns
       }
     } else {
       // whole quads; lim1 / lim2 = columns the row holds (the tail of the last quad lands in pad columns)
-      if (cs.C1 && f0 < cs.lim1) *(chr_gp4)(cs.C1 + (cs.c1 + (unsigned)f0)) = o;
+      if (cs.C1 && f0 < cs.lim1) *(chr_gp4)(cs.C1 + (cs.c1 + (unsigned)f0 * cs.mc1)) = o;
       if (EPI == NUDF_CH_MULSP) {
-        if (cs.iparam > 0 && cs.C2) chr_store_range(cs.C2, cs.c2, f0, cs.iparam, N, cs.iparam, o2);   // embedding branch
+        if (cs.iparam > 0 && cs.C2) chr_store_range(cs.C2, cs.c2, f0, cs.iparam, N, cs.iparam, o2, cs.mc2);   // embedding branch
       } else if (EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_RELU) {
-        if (cs.C2 && f0 < cs.lim2) *(chr_gp4)(cs.C2 + (cs.c2 + (unsigned)f0)) = o2;
+        if (cs.C2 && f0 < cs.lim2) *(chr_gp4)(cs.C2 + (cs.c2 + (unsigned)f0 * cs.mc2)) = o2;
       }
     }
     if (cs.act_write) {
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfC
   const float* arow = act + ln * CH_LD + 4 * h;
   ChrStep cs;
   cs.row = (unsigned)(m0 + ln);
+  cs.m1 = cs.m2 = cs.mc1 = cs.mc2 = 1u;
 
   // ---- the layer chain ---------------------------------------------------------------------------
   for (int si = 0; si < p.n_steps; ++si) {
@@ -467,6 +474,326 @@ __global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfC
       chr_wave_sync();
     }
   }
+}
+
+// =====================================================================================================
+// Workgroup-SHARED 64-point tile with the transposed product ("tq"): the tile geometry, barriers and occupancy of
+// mlp_chain_kernel<64> (4 waves, each up to 2 x 2 tiles of 32 x 32, two workgroups per CU, one wave of each per
+// SIMD) with this file's accumulator orientation -- lane = point, registers = 4 quads of consecutive features -- so
+// that every epilogue access is 16 bytes per lane: 4 instead of 16 VMEM instructions per tile and operand.  A wave
+// can have 64 VMEM operations in flight (6-bit vmcnt); mlp_chain_kernel issues ~256 b32 loads / stores per layer
+// and wave, i.e. at least four HBM round trips per layer spent purely on that limit (scripts/chain_timeline.py:
+// the epilogues' memory operations are 4 / 11 / 28 / 18 % of the four UDF sweeps).  Same contract as the wave-private
+// kernel above (nudf_chain_rows_class), same step tables, bias-first summation.
+// =====================================================================================================
+struct ChainTqSmem {
+  float act[64 * CH_LD];   // 74 752 B
+  float bias[2][256];      //  2 048 B (step s reads [s & 1], stages [~s & 1])
+  float xs[64 * 3];
+  float vs[64 * 3];
+};
+
+template <int NRT, int NCT, class Tail>
+__device__ __forceinline__ void tq_mma(const float* __restrict__ arow, const f32x4* __restrict__ bptr, size_t bstride,
+                                       int G, const float* bb, f32x16 (&acc)[2][2], Tail&& tail) {
+  f32x4 a0[NRT], a1[NRT], b0[NCT], b1[NCT];
+#pragma unroll
+  for (int j = 0; j < NCT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bb + 32 * j + 8 * q);
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[e];
+    }
+#pragma unroll
+  for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD);
+#pragma unroll
+  for (int j = 0; j < NCT; ++j) b0[j] = bptr[j * 64];
+#pragma unroll 1
+  for (int g = 0; g < G - 2; g += 2) {
+    {
+      const f32x4* bq = bptr + (size_t)(g + 1) * bstride;
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) b1[j] = bq[j * 64];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) a1[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + (g + 1) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(b0[j][jj], a0[i][jj], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const f32x4* bq = bptr + (size_t)(g + 2) * bstride;
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) b0[j] = bq[j * 64];
+#pragma unroll
+      for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + (g + 2) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(b1[j][jj], a1[i][jj], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    const f32x4* bq = bptr + (size_t)(G - 1) * bstride;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) b1[j] = bq[j * 64];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) a1[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + (G - 1) * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(b0[j][jj], a0[i][jj], acc[i][j]);
+  __builtin_amdgcn_sched_barrier(0);
+  tail();      // b0 / a0 are dead here
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(b1[j][jj], a1[i][jj], acc[i][j]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// the wave's tiles as straight-line code; X2 of tile t + 1 is requested before tile t is computed and stored
+template <int EPI, int NRT, int NCT>
+__device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
+                                            int h, int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16]) {
+  constexpr bool U2 = CH_USES_X2(EPI);
+  constexpr int NTL = NRT * NCT;
+  float xb[2][16];
+  auto issue = [&](float (&x)[16], int i, int j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (cs[i].X2) v = chr_load_quad(cs[i].X2, cs[i].x2, 32 * (ct0 + j) + 4 * h + 8 * q, cs[i].nq, cs[i].m2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[4 * q + e] = v[e];
+    }
+  };
+  if (U2) issue(xb[0], 0, 0);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (U2 && t + 1 < NTL) issue(xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
+    const int i = t / NCT, j = t % NCT;
+    chr_epi_tile<EPI>(st, act + (rt0 + i) * 32 * CH_LD, cs[i], ct0 + j, h, ln, acc[i][j], px1[i][j], xb[t & 1], false, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void tq_epilogue_any(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
+                                                int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
+                                                float (&px1)[2][2][16]) {
+  if (nrt == 2 && nct == 2) tq_epilogue<EPI, 2, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1);
+  else if (nrt == 2) tq_epilogue<EPI, 2, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1);
+  else if (nct == 2) tq_epilogue<EPI, 1, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1);
+  else tq_epilogue<EPI, 1, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1);
+}
+
+template <int XCLS>
+__global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
+  __shared__ __attribute__((aligned(16))) ChainTqSmem sm;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ln = lane & 31;
+  const int m0 = blockIdx.x * 64;
+
+  // ---- tile initialisation (as mlp_chain_kernel) ---------------------------------------------------
+  if (p.x) {
+    for (int e = tid; e < 64 * 3; e += 256) {
+      int r = m0 + e / 3;
+      if (r > p.P - 1) r = p.P - 1;
+      sm.xs[e] = p.x[(size_t)(r / p.x_div) * 3 + (e % 3)];
+      sm.vs[e] = p.v ? p.v[(size_t)r * 3 + (e % 3)] : 0.0f;
+    }
+  }
+  {
+    const NudfChainStep& s0 = p.step[0];
+    sm.bias[0][tid] = (s0.bias && tid < s0.N) ? s0.bias[tid] : 0.0f;
+  }
+  __syncthreads();
+  if (p.init == NUDF_CH_INIT_LOAD) {
+    const int k4 = p.k0 >> 2;
+    for (int e = tid; e < 64 * k4; e += 256) {
+      const int r = e / k4, c4 = e - r * k4;
+      int gr = m0 + r;
+      if (gr > p.P - 1) gr = p.P - 1;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(p.A0 + (size_t)gr * p.lda0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(sm.act + r * CH_LD + c4 * 4) = val;
+    }
+  } else if (p.init == NUDF_CH_INIT_POSENC) {
+    ch_write_pe_rows<256>(sm.act, sm.xs, sm.vs, 64, tid, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0);
+  } else if (p.init == NUDF_CH_INIT_SEED) {
+    const int C = p.k0;
+    for (int e = tid; e < 64 * C; e += 256) {
+      const int r = e / C, c = e - r * C;
+      int gr = m0 + r;
+      const bool live = gr < p.P;
+      if (!live) gr = p.P - 1;
+      float s, om;
+      ch_sp_derivs(p.A0[(size_t)gr * p.lda0 + c], p.seed_xscale, s, om);
+      const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
+      sm.act[r * CH_LD + c] = val;
+      if (p.G0 && live) p.G0[(size_t)gr * p.ldg0 + c] = val;
+    }
+  }
+  __syncthreads();
+
+  // de-phase the two workgroups of a CU once (see mlp_chain_kernel)
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
+  if (gridDim.x > 256)
+    for (unsigned d = 0; d < (slot & 1u) * 2u; ++d) __builtin_amdgcn_s_sleep(127);
+
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 64 : nullptr;
+  if (dbg && lane == 0) {
+    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    dbg[1] = __builtin_amdgcn_s_memtime();
+  }
+
+  for (int si = 0; si < p.n_steps; ++si) {
+    const NudfChainStep& st = p.step[si];
+    if ((si + slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    const int G = st.K >> 3;
+    const int NT = (st.N + 31) >> 5;
+    int rt0, ct0, nrt, nct;
+    if (NT <= 2) { rt0 = wave >> 1; ct0 = wave & 1; nrt = 1; nct = (ct0 < NT) ? 1 : 0; }
+    else if (NT <= 4) { rt0 = wave >> 1; ct0 = 2 * (wave & 1); nrt = 1; nct = min(2, max(0, NT - ct0)); }
+    else { rt0 = 0; ct0 = 2 * wave; nrt = 2; nct = min(2, max(0, NT - ct0)); }
+
+    ChrStep cs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ChrStep& c = cs[i];
+      c.row = (unsigned)(m0 + (rt0 + i) * 32 + ln);
+      const int lay = chr_pin(st.layout);
+      auto base = [&](int ld, bool blk) {   // blocked: [32-row block][quad of features][row in block][4]
+        return blk ? (c.row - (unsigned)ln) * (unsigned)ld + 4u * (unsigned)ln : c.row * (unsigned)ld;
+      };
+      c.x1 = base(st.ldx1, lay & NUDF_CH_BLK_X1); c.m1 = (lay & NUDF_CH_BLK_X1) ? 32u : 1u;
+      c.x2 = base(st.ldx2, lay & NUDF_CH_BLK_X2); c.m2 = (lay & NUDF_CH_BLK_X2) ? 32u : 1u;
+      c.c1 = base(st.ldc1, lay & NUDF_CH_BLK_C1); c.mc1 = (lay & NUDF_CH_BLK_C1) ? 32u : 1u;
+      c.c2 = base(st.ldc2, lay & NUDF_CH_BLK_C2); c.mc2 = (lay & NUDF_CH_BLK_C2) ? 32u : 1u;
+      c.X1 = (chr_gcp)chr_pin(st.X1);
+      c.X2 = (chr_gcp)chr_pin(st.X2);
+      c.C1 = (chr_gp)chr_pin(st.C1);
+      c.C2 = (chr_gp)chr_pin(st.C2);
+      c.N = chr_pin(st.N);
+      c.nq = chr_pin(((st.N + 3) & ~3) - 4);
+      c.iparam = chr_pin(st.iparam);
+      c.act_col0 = chr_pin(st.act_col0);
+      c.act_write = chr_pin(st.act_write);
+      const int flim = (st.epi == NUDF_CH_MULSP && st.iparam > 0) ? min(st.N, st.iparam) : st.N;
+      c.lim1 = chr_pin(min((flim + 3) & ~3, st.ldc1));
+      c.lim2 = chr_pin(min((st.N + 3) & ~3, st.ldc2));
+      c.scale = chr_pin(st.scale);
+      c.xscale = chr_pin(st.xscale);
+    }
+
+    f32x16 acc[2][2];
+    float px1[2][2][16];
+    // next step's bias: requested now, staged into LDS after the K loop (thread t <-> feature t)
+    float nbias = 0.0f;
+    if (si + 1 < p.n_steps) {
+      const NudfChainStep& sn = p.step[si + 1];
+      if (sn.bias && tid < sn.N) nbias = sn.bias[tid];
+    }
+    if (nct > 0) {
+      const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
+      const f32x4* bptr = reinterpret_cast<const f32x4*>(st.Bp) + (size_t)ct0 * 64 + lane;
+      const size_t bstride = (size_t)NT * 64;
+      const float* bb = sm.bias[si & 1] + 32 * ct0 + 4 * h;
+      const bool u1 = XCLS >= 1 && CH_USES_X1(st.epi);
+      auto tail = [&]() {
+        if (XCLS == 0) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+              if (u1 && i < nrt && j < nct) v = chr_load_quad(cs[i].X1, cs[i].x1, 32 * (ct0 + j) + 4 * h + 8 * q, cs[i].nq, cs[i].m1);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) px1[i][j][4 * q + e] = v[e];
+            }
+      };
+      if (nrt == 2 && nct == 2) tq_mma<2, 2>(arow, bptr, bstride, G, bb, acc, tail);
+      else if (nrt == 2) tq_mma<2, 1>(arow, bptr, bstride, G, bb, acc, tail);
+      else if (nct == 2) tq_mma<1, 2>(arow, bptr, bstride, G, bb, acc, tail);
+      else tq_mma<1, 1>(arow, bptr, bstride, G, bb, acc, tail);
+    }
+    sm.bias[(si + 1) & 1][tid] = nbias;
+    if (dbg && lane == 0) dbg[2 + 4 * si] = __builtin_amdgcn_s_memtime();
+    __syncthreads();  // every wave is done reading the activation tile
+    if (dbg && lane == 0) dbg[3 + 4 * si] = __builtin_amdgcn_s_memtime();
+
+    if (nct > 0) {
+      switch (st.epi) {
+        case NUDF_CH_SOFTPLUS: tq_epilogue_any<NUDF_CH_SOFTPLUS>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_NONE: tq_epilogue_any<NUDF_CH_NONE>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELU: tq_epilogue_any<NUDF_CH_RELU>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SIGMOIDN: tq_epilogue_any<NUDF_CH_SIGMOIDN>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_UDFHEAD: tq_epilogue_any<NUDF_CH_UDFHEAD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULSP: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULSP>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULMASK: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_TANGENT: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_TANGENT>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_BWD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_BWD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_ADDMASK: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_ADDMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELUADD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_RELUADD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        default: break;
+      }
+    }
+    if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
+    if (st.pe_tail_col >= 0) {
+      __syncthreads();
+      const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
+      ch_write_pe_rows<256>(sm.act, sm.xs, sm.vs, 64, tid, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe,
+                            st.pe_tail_col, min((pe_end + 15) & ~15, 288));
+    }
+    __syncthreads();
+    if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+int nudf_mlp_chain_tq_launch(const NudfChain& p0, int cls, hipStream_t st) {
+  NudfChain p = p0;
+  {
+    // TIMING EXPERIMENT ONLY (NUDF_TQ_FAKE_BLOCKED=1): address every quad-accessed buffer as if it were blocked
+    // (same footprint, wrong elements -> wrong results)
+    static const int fake = [] {
+      const char* e = getenv("NUDF_TQ_FAKE_BLOCKED");
+      const int on = (e && e[0] == '1') ? 1 : 0;
+      if (on) fprintf(stderr, "nudf: NUDF_TQ_FAKE_BLOCKED=1 -- chain results are WRONG on purpose (timing experiment)\n");
+      return on;
+    }();
+    if (fake)
+      for (int i = 0; i < p.n_steps; ++i)
+        if (p.step[i].epi != NUDF_CH_UDFHEAD && p.step[i].epi != NUDF_CH_SIGMOIDN)
+          p.step[i].layout = NUDF_CH_BLK_X1 | NUDF_CH_BLK_X2 | NUDF_CH_BLK_C1 | (p.step[i].epi == NUDF_CH_TANGENT ? NUDF_CH_BLK_C2 : 0);
+  }
+  const dim3 grid((p.P + 63) / 64), block(256);
+  if (cls == 0) hipLaunchKernelGGL((mlp_chain_tq_kernel<0>), grid, block, 0, st, p);
+  else if (cls == 1) hipLaunchKernelGGL((mlp_chain_tq_kernel<1>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((mlp_chain_tq_kernel<2>), grid, block, 0, st, p);
+  NUDF_CHECK_LAUNCH("nudf_mlp_chain(tq)");
+  return 0;
 }
 
 // The launch-time contract above; also picks the operand class.  Returns -1 when the workgroup-shared kernel must run.

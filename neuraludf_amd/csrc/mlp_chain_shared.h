@@ -42,6 +42,46 @@ __device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, 
   return (is_sin ? cosf(a) : -sinf(a)) * f * v3[j] * in_scale;
 }
 
+// write PE(x) (or its JVP) * scale into activation columns [col0, col0 + E) of a `rows`-point LDS tile (+ optional
+// global mirror), NTHR cooperating threads.  One work item per (point, coordinate, octave): ONE sincosf gives the sin
+// and the cos column of that octave (the per-element form called sinf or cosf once per column: 2.2x the libm calls;
+// the PE of a 64-point tile took 46 k cycles, 6 % of a forward sweep).  Same arguments 2^k x, same libm kernels.
+template <int NTHR>
+__device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, const float* vs, int rows, int tid,
+                                                 const NudfChain& p, int m0, int col0, float scale, float* gdst,
+                                                 int ldg, int gcol0, int zero_to) {
+  const int L = p.pe_L;
+  const int E = 3 * (2 * L + 1);
+  for (int it = tid; it < rows * 3 * (L + 1); it += NTHR) {
+    const int rj = it / (L + 1), k = it - rj * (L + 1) - 1;   // k = -1: the identity column
+    const int r = rj / 3, j = rj - 3 * r;
+    const float xv = xs[rj] * p.pe_in_scale;
+    const float tv = vs[rj] * p.pe_in_scale;
+    float* arow = act + r * CH_LD + col0;
+    float* grow = (gdst && (m0 + r) < p.P) ? gdst + (size_t)(m0 + r) * ldg + gcol0 : nullptr;
+    auto put = [&](int c, float val) {
+      val *= scale;
+      arow[c] = val;
+      if (grow) grow[c] = val;
+    };
+    if (k < 0) {
+      put(j, p.pe_jvp ? tv : xv);
+    } else {
+      const float f = (float)(1 << k);
+      float sn, cs;
+      sincosf(xv * f, &sn, &cs);
+      put(3 + 6 * k + j, p.pe_jvp ? cs * f * tv : sn);
+      put(6 + 6 * k + j, p.pe_jvp ? -sn * f * tv : cs);
+    }
+  }
+  // zero padding columns [col0 + E, zero_to) so that the K padding of the next GEMM multiplies finite zeros
+  const int npad = zero_to - (col0 + E);
+  if (npad > 0)
+    for (int e = tid; e < rows * npad; e += NTHR) {
+      const int r = e / npad, c = e - r * npad;
+      act[r * CH_LD + col0 + E + c] = 0.0f;
+    }
+}
 
 // accumulator register r of a 32x32 MFMA tile holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #define CH_KOFF(r) (((r) & 3) + 8 * ((r) >> 2))

@@ -75,7 +75,13 @@ for li, (dbg, steps, flops) in enumerate(launches):
         prev = e
     tot = k + w1 + ep + w2
     mfma_cycles = flops / P * 64 / 4 / (2 * 32 * 32 * 2) * 64     # per wave of a 64-point tile: flops/point * 64 / 4 waves / flops per MFMA * 64
-    print(f"launch {li}: {n} steps, {len(d)} waves, span {span:.0f} ticks, flops/point {flops / P:.0f}")
+    wall = (d[:, 63] - d[:, 62]).astype(np.float64)            # 100 MHz ticks
+    mem = (d[:, 5 + 4 * (n - 1)] - d[:, 1]).astype(np.float64)
+    ok = wall > 0
+    mhz = float((mem[ok] / wall[ok]).mean() * 100.0) if ok.any() else float("nan")
+    launch_us = float(d[:, 63].max() - d[:, 62].min()) / 100.0 if ok.any() else float("nan")
+    print(f"launch {li}: {n} steps, {len(d)} waves, flops/point {flops / P:.0f}; s_memtime runs at {mhz:.0f} MHz; first start -> last end {launch_us:.1f} us"
+          f" = {flops / launch_us / 1e6 if launch_us == launch_us else float('nan'):.1f} TF")
     print(f"   per wave (mean ticks): K loop {k.mean():8.0f} ({k.mean() / tot.mean():5.1%})  barrier-1 wait {w1.mean():7.0f} ({w1.mean() / tot.mean():5.1%})"
           f"  epilogue {ep.mean():7.0f} ({ep.mean() / tot.mean():5.1%})  barrier-2 wait {w2.mean():7.0f} ({w2.mean() / tot.mean():5.1%})  total {tot.mean():8.0f}")
     print(f"   MFMA ticks needed per wave {mfma_cycles:8.0f}: K-loop efficiency {mfma_cycles / k.mean():5.1%} (2 waves share a SIMD: 50 % = pipe saturated),"

@@ -51,3 +51,27 @@ def test_rows_kernel_is_the_one_that_ran(dev):
     b = sweeps(dev, 4096, 128, seed=9)
     assert not torch.equal(a["feat"], b["feat"])
     assert float((a["feat"] - b["feat"]).abs().max()) < 2e-5 * float(a["feat"].abs().max())
+
+
+# ---- the workgroup-shared 64-point tile with the transposed product (tile_rows = 66, mlp_chain_tq_kernel) ---------------
+@pytest.mark.parametrize("P", [1, 63, 65, 129, 1000, 4133])
+def test_tq_kernel_matches_shared_kernel_ragged_sizes(dev, P):
+    a = sweeps(dev, P, 64, seed=P)
+    b = sweeps(dev, P, 66, seed=P)
+    assert set(a) == set(b)
+    bad, nbit, worst, worst_l2 = compare(a, b, f"P={P}", verbose=False, l2_tol=max(3e-3, 10.0 / P))
+    assert not bad, bad
+    for k in a:
+        assert bool(torch.isfinite(b[k]).all()), k
+
+
+def test_tq_kernel_full_size_is_the_one_that_ran_and_deterministic(dev):
+    P = 64 * 700 + 13
+    a = sweeps(dev, P, 64, seed=5)
+    b = sweeps(dev, P, 66, seed=5)
+    c = sweeps(dev, P, 66, seed=5)
+    bad, _, worst, worst_l2 = compare(a, b, f"P={P} shared vs tq", verbose=True)
+    assert not bad, bad
+    assert not torch.equal(a["feat"], b["feat"])          # bias-first summation: a silent fall-back would be bit-equal
+    for k in ("udf", "feat", "X8", "g", "DA0", "uo", "cb", "cc", "dCIN", "nsig", "nrgb"):
+        assert torch.equal(b[k], c[k]), k
