@@ -15,7 +15,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                   algorithmic FLOPs of its launches / their summed duration, measured with HIP
                   events on the launch stream during one extra instrumented step; peak = 157.3 TFLOP/s
                   (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); traffic = HBM bytes per launch from the
-                  committed rocprofv3 PMC passes over this command (profiles/r01_traffic_mlp_chain.json).
+                  committed rocprofv3 PMC passes over this command (profiles/r02_traffic_mlp_chain.json).
   roofline_composite -- the fused sample+composite kernels against the 8 TB/s HBM roof
                   (48 B/sample + 68 B/ray forward, 84 B/sample + 68 B/ray backward).
   cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path) timed on this host's
