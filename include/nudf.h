@@ -86,7 +86,11 @@ typedef struct NudfGemmTNProblem {
   float* C; float* dbias;                       /* [NA, ldc] +=, [NA] += or NULL          */
   int32_t lda1, ldb1, ldc, NA, NB;
   int32_t tile_start;                           /* unused (kept for layout compatibility) */
+  int32_t flags;                                /* NUDF_TN_A16 / NUDF_TN_B16: that operand is stored as bf16 (leading
+                                                   dimension in elements, a multiple of 8); widened to fp32 on chip    */
 } NudfGemmTNProblem;
+#define NUDF_TN_A16 1
+#define NUDF_TN_B16 2
 typedef struct NudfGemmTNGroup {
   int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
   int32_t prec;                                 /* as NudfGemmTN.prec                     */
@@ -393,6 +397,10 @@ typedef struct NudfChainStep {
 #define NUDF_CH_BLK_C1 4
 #define NUDF_CH_BLK_C2 8
 #define NUDF_CH_BLK_PE 16           /* pe_dst */
+/* config-5 mode: this step's stored-state arrays -- X1, X2, C1, the TANGENT mirror C2 and pe_dst -- hold bf16 (ld in
+ * elements); SOFTPLUS / MULSP / TANGENT / BWD steps of the workgroup-shared kernels only.  Values are rounded to
+ * nearest even when stored; everything on chip stays fp32. */
+#define NUDF_CH_STATE16 32
 typedef struct NudfChain {
   int32_t P, n_steps;
   int32_t init;                    /* NUDF_CH_INIT_*                                                 */
@@ -404,6 +412,7 @@ typedef struct NudfChain {
                                       and fall back to 64 otherwise */
   int32_t lda0, ldg0;
   int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */
+  int32_t init_state16;            /* INIT_SEED: bit 0 = A0 holds bf16, bit 1 = G0 receives bf16                 */
   float pe_in_scale;
   float seed_scale, seed_xscale;
   const float* A0;                 /* INIT_LOAD source / INIT_SEED stored activation                 */

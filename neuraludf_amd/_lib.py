@@ -41,7 +41,7 @@ TN_MAX_PROBLEMS = 12
 
 class GemmTNProblem(C.Structure):
     _fields_ = [("A1", c_fp), ("B1", c_fp), ("C", c_fp), ("dbias", c_fp), ("lda1", i32), ("ldb1", i32), ("ldc", i32),
-                ("NA", i32), ("NB", i32), ("tile_start", i32)]
+                ("NA", i32), ("NB", i32), ("tile_start", i32), ("flags", i32)]
 
 
 class GemmTNGroup(C.Structure):
@@ -126,6 +126,7 @@ class Adam(C.Structure):
 
 
 CH_MAX_STEPS = 14
+CH_STATE16 = 32     # NudfChainStep.layout: the step's stored-state arrays hold bf16
 CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5, RELU=6, SIGMOIDN=7, MULMASK=8, ADDMASK=9, RELUADD=10)
 CH_INIT = dict(LOAD=0, POSENC=1, SEED=2)
 
@@ -140,7 +141,7 @@ class ChainStep(C.Structure):
 
 class Chain(C.Structure):
     _fields_ = [("P", i32), ("n_steps", i32), ("init", i32), ("k0", i32), ("x_div", i32), ("tile_rows", i32), ("lda0", i32),
-                ("ldg0", i32), ("pe_L", i32), ("pe_jvp", i32), ("pe_in_scale", f32), ("seed_scale", f32),
+                ("ldg0", i32), ("pe_L", i32), ("pe_jvp", i32), ("init_state16", i32), ("pe_in_scale", f32), ("seed_scale", f32),
                 ("seed_xscale", f32), ("A0", c_fp), ("G0", c_fp), ("x", c_fp), ("v", c_fp), ("seed_sign", c_fp),
                 ("seed_wrow", c_fp), ("dbg", c_fp), ("step", ChainStep * CH_MAX_STEPS)]
 
@@ -274,7 +275,7 @@ def lib():
 
 
 def ptr(t):
-    """raw device pointer of a contiguous fp32/int32 CUDA(HIP) tensor (None -> NULL)."""
+    """raw device pointer of a contiguous fp32 / int32 / bf16 CUDA(HIP) tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:

@@ -84,59 +84,80 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   const int nk = (mend - mbeg + BK - 1) / BK;
   const int nfull = (mend - mbeg) / BK;
 
-  const int t_k = tid >> 5;   // row of the k-step this thread copies (+8 per pass)
-  const int t_c4 = tid & 31;  // its float4 column
-
-  // column indices are clamped into the buffer (columns past NA / NB only feed outputs that are never stored).  A FULL
-  // k-step (all 32 rows exist -- every step but the last of the last row chunk) is 8 loads off two per-thread base
-  // pointers and 8 plain LDS stores; only the ragged step clamps rows and zeroes rows >= mend with selects.
-  const float* pa = q.A1 + (size_t)(mbeg + t_k) * lda + min(i0 + t_c4 * 4, lda - 4);
-  const float* pb = q.B1 + (size_t)(mbeg + t_k) * ldb + min(j0 + t_c4 * 4, ldb - 4);
+  // An operand stored as fp32: thread (t_k = tid / 32, t_c = 4 (tid % 32)) copies rows t_k + 8 ps (4 passes), 4 columns
+  // each; stored as bf16 (config-5 mode, NUDF_TN_A16 / _B16): thread (tid / 16, 8 (tid % 16)) copies rows t_k + 16 ps
+  // (2 passes), 8 columns each -- half the HBM bytes, widened to fp32 on the way into the same LDS tile.
+  // Column indices are clamped into the buffer (columns past NA / NB only feed outputs that are never stored).  A FULL
+  // k-step (all 32 rows exist -- every step but the last of the last row chunk) is plain loads off per-thread base
+  // pointers and plain LDS stores; only the ragged step clamps rows and zeroes rows >= mend with selects.
+  const bool a16 = (q.flags & NUDF_TN_A16) != 0, b16 = (q.flags & NUDF_TN_B16) != 0;
+  struct Op { const char* p; size_t rowb; int tk, tc; };      // base pointer (bytes), row stride (bytes), thread row / column
+  auto mk = [&](const float* base, int ld, int c0, bool h) {
+    Op o;
+    o.tk = h ? tid >> 4 : tid >> 5;
+    o.tc = h ? (tid & 15) * 8 : (tid & 31) * 4;
+    const int esz = h ? 2 : 4;
+    o.rowb = (size_t)ld * esz;
+    o.p = reinterpret_cast<const char*>(base) + (size_t)(mbeg + o.tk) * o.rowb + (size_t)min(c0 + o.tc, ld - (h ? 8 : 4)) * esz;
+    return o;
+  };
+  const Op oa = mk(q.A1, lda, i0, a16), ob = mk(q.B1, ldb, j0, b16);
   f32x4 ra[4], rb[4];
   int ld_rows = 0;
-  auto gload = [&](int kt) {
-    if (kt < nfull) {
-      const float* a = pa + (size_t)kt * BK * lda;
-      const float* b = pb + (size_t)kt * BK * ldb;
+  // the operand kind is a COMPILE-TIME parameter of these (dispatched once per workgroup below): with run-time kinds the
+  // compiler put every load into its own branch and waited vmcnt(0) right behind it (1821 us instead of 650)
+  auto load_op = [&](const Op& o, auto H, f32x4 (&r)[4], int kt, bool full) {
+    constexpr bool h = decltype(H)::value;
+    constexpr int np = h ? 2 : 4, rs = h ? 16 : 8;
+    if (full) {
+      const char* b = o.p + (size_t)kt * BK * o.rowb;
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        ra[ps] = *reinterpret_cast<const f32x4*>(a + (size_t)(ps * 8) * lda);
-        rb[ps] = *reinterpret_cast<const f32x4*>(b + (size_t)(ps * 8) * ldb);
+      for (int ps = 0; ps < np; ++ps) r[ps] = *reinterpret_cast<const f32x4*>(b + (size_t)(ps * rs) * o.rowb);
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < np; ++ps) {
+        const ptrdiff_t row = min((ptrdiff_t)kt * BK + ps * rs, (ptrdiff_t)(g.M - 1 - mbeg - o.tk));   // clamp into the buffer
+        r[ps] = *reinterpret_cast<const f32x4*>(o.p + row * (ptrdiff_t)o.rowb);
       }
-      ld_rows = BK;
-      return;
     }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int mc = min(kt * BK + ps * 8, g.M - 1 - mbeg - t_k);   // clamp the row into the buffer
-      ra[ps] = *reinterpret_cast<const f32x4*>(pa + (ptrdiff_t)mc * lda);
-      rb[ps] = *reinterpret_cast<const f32x4*>(pb + (ptrdiff_t)mc * ldb);
-    }
-    ld_rows = mend - (mbeg + kt * BK);   // rows of this k-step that exist (the others are zeroed at the LDS store)
   };
   // bias gradient = column sums of A, taken from the registers on their way to LDS (tiles of the first tile column)
   const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
-  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
-  auto sstore = [&](int buf) {
-    float* as = As + buf * T_TILE + t_k * LDT + t_c4 * 4;
-    float* bs = Bs + buf * T_TILE + t_k * LDT + t_c4 * 4;
-    if (ld_rows >= BK) {
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f}, bacc2 = {0.f, 0.f, 0.f, 0.f};   // bacc2: columns 4..7 of a bf16 operand's 8
+  auto widen = [](const f32x4& raw, f32x4& lo, f32x4& hi) {   // 8 bf16 -> 8 fp32 (memory order)
+    const uint4 u = __builtin_bit_cast(uint4, raw);
+    lo = f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+               __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    hi = f32x4{__builtin_bit_cast(float, u.z << 16), __builtin_bit_cast(float, u.z & 0xffff0000u),
+               __builtin_bit_cast(float, u.w << 16), __builtin_bit_cast(float, u.w & 0xffff0000u)};
+  };
+  auto store_op = [&](const Op& o, auto H, const f32x4 (&r)[4], float* tile, bool bias) {
+    constexpr bool h = decltype(H)::value;
+    float* dst = tile + o.tk * LDT + o.tc;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!h) {
+      if (ld_rows >= BK) {   // the common case: no selects
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(dst + ps * 8 * LDT) = r[ps];
+        if (bias) bacc += (r[0] + r[1]) + (r[2] + r[3]);
+        return;
+      }
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
-        *reinterpret_cast<f32x4*>(as + ps * 8 * LDT) = ra[ps];
-        *reinterpret_cast<f32x4*>(bs + ps * 8 * LDT) = rb[ps];
+        const f32x4 v = ((ps * 8 + o.tk) < ld_rows) ? r[ps] : z;
+        *reinterpret_cast<f32x4*>(dst + ps * 8 * LDT) = v;
+        if (bias) bacc += v;
       }
-      if (do_bias) bacc += (ra[0] + ra[1]) + (ra[2] + ra[3]);
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const bool ok = (ps * 8 + t_k) < ld_rows;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 va = ok ? ra[ps] : z;
-      *reinterpret_cast<f32x4*>(as + ps * 8 * LDT) = va;
-      *reinterpret_cast<f32x4*>(bs + ps * 8 * LDT) = ok ? rb[ps] : z;
-      if (do_bias) bacc += va;
+      for (int ps = 0; ps < 2; ++ps) {
+        f32x4 lo, hi;
+        widen(r[ps], lo, hi);
+        if (ld_rows < BK && (ps * 16 + o.tk) >= ld_rows) lo = hi = z;
+        *reinterpret_cast<f32x4*>(dst + ps * 16 * LDT) = lo;
+        *reinterpret_cast<f32x4*>(dst + ps * 16 * LDT + 4) = hi;
+        if (bias) { bacc += lo; bacc2 += hi; }
+      }
     }
   };
 
@@ -148,12 +169,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
 
   const bool live = tl.layout == 2 ? true : tl.layout == 0 ? (j0 + 32 * wave) < q.NB : (i0 + 32 * wave) < q.NA;
   const int n_w = live ? tl.n : 0;
-
-  if (nk > 0) {
-    gload(0);
-    sstore(0);
-  }
-  __syncthreads();
 
   // one k-step of a wave: its FIXED operand (the sub-tile column it owns) against N sub-tiles of the other operand, two
   // reduction indices per MFMA, LDS reads software-pipelined four MFMA groups ahead
@@ -266,43 +281,69 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
       }
     }
   };
-  // the k-loop is instantiated ONCE PER (sub-tile count, layout, precision), chosen outside the loop: a shape switch
-  // inside it made the compiler copy all 64 accumulator registers (behind an MFMA drain) on every k-step
-  auto kloop = [&](auto N, auto LAY, auto P16) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) gload(kt + 1);
-      __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
-      if constexpr (decltype(N)::value > 0) {
-        if constexpr (decltype(P16)::value != 0) mma16(N, LAY, cur);
-        else mma(N, LAY, cur);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk) sstore(cur ^ 1);
-      __syncthreads();
-    }
-  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
   using I4 = std::integral_constant<int, 4>;
-  auto by_prec = [&](auto N, auto LAY) {
-    if (g.prec != 0) kloop(N, LAY, I1{});
-    else kloop(N, LAY, I0{});
+  // Everything from the first operand load to the last k-step, for one (A kind, B kind).  The k-loop inside is
+  // instantiated ONCE PER (sub-tile count, layout, precision), chosen outside the loop: a shape switch inside it made
+  // the compiler copy all 64 accumulator registers (behind an MFMA drain) on every k-step.  bf16 operands and the 16-bit
+  // MFMAs only ever meet the quadrant layout (tn_plan), so those kinds instantiate two loops each.
+  auto run_kind = [&](auto KA, auto KB) {
+    constexpr bool kA = decltype(KA)::value, kB = decltype(KB)::value;
+    auto gload = [&](int kt) {
+      const bool full = kt < nfull;
+      load_op(oa, KA, ra, kt, full);
+      load_op(ob, KB, rb, kt, full);
+      ld_rows = full ? BK : mend - (mbeg + kt * BK);   // rows of this k-step that exist (the others are zeroed at the LDS store)
+    };
+    auto sstore = [&](int buf) {
+      store_op(oa, KA, ra, As + buf * T_TILE, do_bias);
+      store_op(ob, KB, rb, Bs + buf * T_TILE, false);
+    };
+    if (nk > 0) {
+      gload(0);
+      sstore(0);
+    }
+    __syncthreads();
+    auto kloop = [&](auto N, auto LAY, auto P16) {
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+        if constexpr (decltype(N)::value > 0) {
+          if constexpr (decltype(P16)::value != 0) mma16(N, LAY, cur);
+          else mma(N, LAY, cur);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+      }
+    };
+    auto by_prec = [&](auto N, auto LAY) {
+      if (g.prec != 0) kloop(N, LAY, I1{});
+      else kloop(N, LAY, I0{});
+    };
+    if (n_w == 0) { by_prec(I0{}, I0{}); return; }
+    if (tl.layout == 2) { by_prec(I4{}, I2{}); return; }
+    if constexpr (!kA && !kB) {
+      if (tl.layout == 0) {
+        if (n_w == 4) kloop(I4{}, I0{}, I0{});
+        else if (n_w == 3) kloop(I3{}, I0{}, I0{});
+        else if (n_w == 2) kloop(I2{}, I0{}, I0{});
+        else kloop(I1{}, I0{}, I0{});
+      } else {
+        if (n_w == 3) kloop(I3{}, I1{}, I0{});
+        else if (n_w == 2) kloop(I2{}, I1{}, I0{});
+        else kloop(I1{}, I1{}, I0{});                 // n = 4 never takes this layout (ties go to layout 0)
+      }
+    }
   };
-  if (n_w == 0) by_prec(I0{}, I0{});
-  else if (tl.layout == 2) by_prec(I4{}, I2{});
-  else if (tl.layout == 0) {
-    if (n_w == 4) by_prec(I4{}, I0{});
-    else if (n_w == 3) by_prec(I3{}, I0{});
-    else if (n_w == 2) by_prec(I2{}, I0{});
-    else by_prec(I1{}, I0{});
-  } else {
-    if (n_w == 3) by_prec(I3{}, I1{});
-    else if (n_w == 2) by_prec(I2{}, I1{});
-    else by_prec(I1{}, I1{});                 // n = 4 never takes this layout (ties go to layout 0)
-  }
+  if (!a16 && !b16) run_kind(std::false_type{}, std::false_type{});
+  else if (a16 && b16) run_kind(std::true_type{}, std::true_type{});
+  else if (a16) run_kind(std::true_type{}, std::false_type{});
+  else run_kind(std::false_type{}, std::true_type{});
 
   if (g.dbg && tid == 0) {
     long long* d = g.dbg + 4 * (size_t)blockIdx.x;
@@ -311,12 +352,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   if (g.flags & TNF_NO_EPILOGUE) return;
   float* slot = g.ws ? g.ws + (size_t)blockIdx.x * TN_WS_TILE : nullptr;
   if (do_bias) {   // the loop's last barrier has passed: the operand tiles are free
-    *reinterpret_cast<f32x4*>(smem + t_k * BM + t_c4 * 4) = bacc;
+    *reinterpret_cast<f32x4*>(smem + oa.tk * BM + oa.tc) = bacc;
+    if (a16) *reinterpret_cast<f32x4*>(smem + oa.tk * BM + oa.tc + 4) = bacc2;
     __syncthreads();
     if (tid < BM) {
       float s = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s += smem[k * BM + tid];
+      const int ngroups = a16 ? 16 : 8;
+      for (int k = 0; k < ngroups; ++k) s += smem[k * BM + tid];
       if (slot) slot[BM * BN + tid] = s;
       else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, s);
     }
@@ -426,7 +468,8 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   int nt = 0;
   for (int i = 0; i < g.n_problems; ++i) {
     const NudfGemmTNProblem& q = g.prob[i];
-    if ((q.lda1 % 4) || (q.ldb1 % 4) || q.NA <= 0 || q.NB <= 0 || q.lda1 < 4 || q.ldb1 < 4 ||
+    const int ma = (q.flags & NUDF_TN_A16) ? 8 : 4, mb = (q.flags & NUDF_TN_B16) ? 8 : 4;
+    if ((q.lda1 % ma) || (q.ldb1 % mb) || q.NA <= 0 || q.NB <= 0 || q.lda1 < ma || q.ldb1 < mb ||
         (((uintptr_t)q.A1) & 15) || (((uintptr_t)q.B1) & 15)) {
       nudf_set_error("nudf_gemm_tn_grouped: leading dimensions must be multiples of 4, operands 16-byte aligned",
                      hipErrorInvalidValue);
@@ -449,6 +492,10 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
         tl.layout = (short)(li <= lj ? 0 : 1);
         tl.n = (short)(li <= lj ? li : lj);
         if (li == 4 && lj == 4 && !(flags & TNF_NO_QUADRANTS)) tl.layout = 2;
+        if (g.prec != 0 || (q.flags & (NUDF_TN_A16 | NUDF_TN_B16))) {   // 16-bit MFMAs / bf16 operands: load-bound k-steps,
+          tl.layout = 2;                                                // one loop shape (whole quadrants; zero-padded
+          tl.n = 4;                                                     // operand columns make the dead sub-tiles exact 0)
+        }
         cost[nt++] = tn_cost(tl.n);
       }
   }
@@ -470,7 +517,9 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
     auto count = [&](double T, bool store) {
       long total = 0;
       for (int t = 0; t < nt; ++t) {
-        const double c = (flags & TNF_UNIFORM_CHUNKS) ? 4.0 : cost[t];
+        // 16-bit operands: the k-step is bound by the loads / LDS traffic of the (always full-size) operand tiles, not by
+        // the live MFMAs -- every tile costs the same
+        const double c = ((flags & TNF_UNIFORM_CHUNKS) || g.prec != 0) ? 4.0 : cost[t];
         long n = (long)((c * (double)nkt + T - 1e-9) / T);
         if (n < 1) n = 1;
         if (n > max_chunks) n = max_chunks;

@@ -32,8 +32,8 @@ struct ChainSmem {
 
 template <int TM>
 __device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& p, int m0, int col0, float scale,
-                                            float* gdst, int ldg, int gcol0, int zero_to) {
-  ch_write_pe_rows<CH_THREADS>(sm.act, sm.xs, sm.vs, TM, threadIdx.x, p, m0, col0, scale, gdst, ldg, gcol0, zero_to);
+                                            float* gdst, int ldg, int gcol0, int zero_to, bool dst16 = false) {
+  ch_write_pe_rows<CH_THREADS>(sm.act, sm.xs, sm.vs, TM, threadIdx.x, p, m0, col0, scale, gdst, ldg, gcol0, zero_to, dst16);
 }
 
 // K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
@@ -132,6 +132,8 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
 template <int NRT, int NCT, bool BF>
 __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride,
                                          int G16, f32x16 (&acc)[2][2]) {
+  // (requesting the epilogue's stored-state operands under this loop, as the fp32 loop does, was measured in round 2:
+  // 64 more live registers next to the conversions -> 185-511 spilled registers, chains 7.2 -> 17.8 ms at config 5)
   f32x4 a0[NRT][2], a1[NRT][2];
   uint4 b0[NCT], b1[NCT];
   auto lda = [&](f32x4 (&a)[NRT][2], int g) {
@@ -186,7 +188,8 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
 // around whole 16-element loops, the column predicate (N may end inside the tile) is one exec region, rows
 // need no predicate because every output / operand buffer is row-padded to the tile size (see nudf.h).
 // Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
-template <int EPI, bool X2IN = false>
+// S16: the step's stored-state arrays (X1, X2, C1, and the TANGENT mirror C2) hold bf16 (config-5 mode, NUDF_CH_STATE16)
+template <int EPI, bool X2IN = false, bool S16 = false>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
                                                  const float* x2in = nullptr) {
@@ -210,8 +213,14 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
   float x2[16];   // x1 (the stored activation) was prefetched under the fp32 K loop; the short 16-bit loops load it here
   if (CH_USES_X1(EPI) && load_x1) {
     const unsigned vo = grow0 * (unsigned)st.ldx1 + colc;
+    if (S16) {
+      const unsigned short* X1h = reinterpret_cast<const unsigned short*>(st.X1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
+      for (int r = 0; r < 16; ++r) x1[r] = ch_bf2f((X1h + (size_t)CH_KOFF(r) * st.ldx1)[vo]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
+    }
   }
   if (CH_USES_X2(EPI)) {
     if (X2IN) {   // fetched by the caller one tile ahead (ch_epilogue_seq)
@@ -219,8 +228,14 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       for (int r = 0; r < 16; ++r) x2[r] = x2in[r];
     } else if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
+      if (S16) {
+        const unsigned short* X2h = reinterpret_cast<const unsigned short*>(st.X2);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+        for (int r = 0; r < 16; ++r) x2[r] = ch_bf2f((X2h + (size_t)CH_KOFF(r) * st.ldx2)[vo]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
@@ -312,13 +327,25 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       }
     } else if (st.C1) {
       const unsigned vo = grow0 * (unsigned)st.ldc1 + col;
+      if (S16) {
+        unsigned short* C1h = reinterpret_cast<unsigned short*>(st.C1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+        for (int r = 0; r < 16; ++r) (C1h + (size_t)CH_KOFF(r) * st.ldc1)[vo] = ch_f2bf(out[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+      }
     }
     if (EPI == NUDF_CH_TANGENT || (EPI == NUDF_CH_RELU && st.C2)) {
       const unsigned vo = grow0 * (unsigned)st.ldc2 + col;
+      if (S16 && EPI == NUDF_CH_TANGENT) {
+        unsigned short* C2h = reinterpret_cast<unsigned short*>(st.C2);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+        for (int r = 0; r < 16; ++r) (C2h + (size_t)CH_KOFF(r) * st.ldc2)[vo] = ch_f2bf(out2[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+      }
     }
   }
   if (st.act_write) {
@@ -360,13 +387,13 @@ __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* 
 }
 
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
-template <int EPI>
+template <int EPI, bool ANY16>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
                                             const float (&px1)[2][2][16]) {
   constexpr bool PF = CH_USES_X1(EPI);
   if constexpr (CH_USES_X2(EPI)) {
-    if (st.prec == 0 && nrt == 2) {
+    if (st.prec == 0 && nrt == 2 && !(ANY16 && (st.layout & NUDF_CH_STATE16))) {
       float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
       if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1);
       else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1);
@@ -411,11 +438,19 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
         }
         break;
     }
-    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, st.prec != 0);
+    if constexpr (ANY16 && (EPI == NUDF_CH_SOFTPLUS || EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
+      if (st.layout & NUDF_CH_STATE16) {
+        ch_epilogue_tile<EPI, false, true>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true);
+        continue;
+      }
+    }
+    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 && st.prec != 0);
   }
 }
 
-template <int TM>
+// ANY16: some step of the chain uses 16-bit MFMA operands (config-5 mode).  The fp32 chains get a kernel without any of
+// the 16-bit code: its register pressure (conversions, raw-bf16 operand prefetch) would otherwise spill into them.
+template <int TM, bool ANY16>
 __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
   constexpr int WMT = TM / 32;  // row tiles per wave in the wide layout
   __shared__ __attribute__((aligned(16))) ChainSmem<TM> sm;
@@ -455,10 +490,15 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
       const bool live = gr < p.P;
       if (!live) gr = p.P - 1;
       float s, om;
-      ch_sp_derivs(p.A0[(size_t)gr * p.lda0 + c], p.seed_xscale, s, om);
+      const float hst = (p.init_state16 & 1) ? ch_bf2f(reinterpret_cast<const unsigned short*>(p.A0)[(size_t)gr * p.lda0 + c])
+                                             : p.A0[(size_t)gr * p.lda0 + c];
+      ch_sp_derivs(hst, p.seed_xscale, s, om);
       const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
       sm.act[r * CH_LD + c] = val;
-      if (p.G0 && live) p.G0[(size_t)gr * p.ldg0 + c] = val;
+      if (p.G0 && live) {
+        if (p.init_state16 & 2) reinterpret_cast<unsigned short*>(p.G0)[(size_t)gr * p.ldg0 + c] = ch_f2bf(val);
+        else p.G0[(size_t)gr * p.ldg0 + c] = val;
+      }
     }
   }
   __syncthreads();
@@ -529,7 +569,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
           const int col = (ct0 + j) * 32 + ln;
           pf.vo[i][j] = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx1 + (unsigned)((col < st.N) ? col : 0);
         }
-      if (st.prec != 0) {
+      if (ANY16 && st.prec != 0) {
         const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
         const uint4* bp16 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 64 + lane;
         const int G16 = st.K >> 4;
@@ -556,17 +596,17 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        default: ch_epilogue<NUDF_CH_UDFHEAD>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
       }
     }
     if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -576,7 +616,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
       // finite zeros (columns never written before hold arbitrary LDS contents)
       const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
       ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col,
-                      min((pe_end + 15) & ~15, 288));
+                      min((pe_end + 15) & ~15, 288), (st.layout & NUDF_CH_STATE16) != 0);
     }
     __syncthreads();
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -621,13 +661,17 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   for (int i = 0; i < p.n_steps && !bad; ++i) {
     const NudfChainStep& s = p.step[i];
     bad = (s.K & 15) || s.K <= 0 || s.K > 288 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
-          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 2;
+          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 2 ||
+          ((s.layout & NUDF_CH_STATE16) && s.epi != NUDF_CH_SOFTPLUS && s.epi != NUDF_CH_MULSP &&
+           s.epi != NUDF_CH_TANGENT && s.epi != NUDF_CH_BWD);
   }
   if (bad) {
     nudf_set_error("nudf_mlp_chain: K%16, K<=288, N<=256, x_div>=1, 16-byte aligned packed weights required", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
   hipStream_t st = (hipStream_t)stream;
+  bool any16 = false;
+  for (int i = 0; i < p.n_steps; ++i) any16 = any16 || p.step[i].prec != 0 || (p.step[i].layout & NUDF_CH_STATE16);
   // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of
   // that kernel is 1024 waves = 32 768 points, so it is chosen when the last round is at least ~80 % full; the
   // up-sampling rounds (5-8 k points) and awkward sizes keep the workgroup-shared tiles below.
@@ -647,9 +691,11 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {
-    hipLaunchKernelGGL(mlp_chain_kernel<32>, dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
+    if (any16) hipLaunchKernelGGL((mlp_chain_kernel<32, true>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((mlp_chain_kernel<32, false>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
   } else {
-    hipLaunchKernelGGL(mlp_chain_kernel<64>, dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    if (any16) hipLaunchKernelGGL((mlp_chain_kernel<64, true>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((mlp_chain_kernel<64, false>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
   }
   NUDF_CHECK_LAUNCH("nudf_mlp_chain");
   return 0;

@@ -802,7 +802,7 @@ int nudf_chain_rows_class(const NudfChain& p) {
   auto vec_ok = [](const void* q, int ld) { return ((((uintptr_t)q) | ((unsigned)ld << 2)) & 15) == 0; };
   for (int i = 0; i < p.n_steps; ++i) {
     const NudfChainStep& s = p.step[i];
-    if (s.prec != 0) return -1;
+    if (s.prec != 0 || (s.layout & NUDF_CH_STATE16)) return -1;
     const int e = s.epi;
     if (CH_USES_X1(e)) {
       if (!s.X1 || !vec_ok(s.X1, s.ldx1)) return -1;

@@ -12,6 +12,10 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// bf16 <-> fp32 of the 16-bit stored state (round to nearest even on the way out)
+__device__ __forceinline__ float ch_bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ unsigned short ch_f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+
 __device__ __forceinline__ f32x16 ch_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -49,7 +53,7 @@ __device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, 
 template <int NTHR>
 __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, const float* vs, int rows, int tid,
                                                  const NudfChain& p, int m0, int col0, float scale, float* gdst,
-                                                 int ldg, int gcol0, int zero_to) {
+                                                 int ldg, int gcol0, int zero_to, bool dst16 = false) {
   const int L = p.pe_L;
   const int E = 3 * (2 * L + 1);
   for (int it = tid; it < rows * 3 * (L + 1); it += NTHR) {
@@ -58,11 +62,15 @@ __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, co
     const float xv = xs[rj] * p.pe_in_scale;
     const float tv = vs[rj] * p.pe_in_scale;
     float* arow = act + r * CH_LD + col0;
-    float* grow = (gdst && (m0 + r) < p.P) ? gdst + (size_t)(m0 + r) * ldg + gcol0 : nullptr;
+    const bool mirror = gdst && (m0 + r) < p.P;
+    const size_t goff = (size_t)(m0 + r) * ldg + gcol0;
     auto put = [&](int c, float val) {
       val *= scale;
       arow[c] = val;
-      if (grow) grow[c] = val;
+      if (mirror) {
+        if (dst16) reinterpret_cast<unsigned short*>(gdst)[goff + c] = ch_f2bf(val);
+        else gdst[goff + c] = val;
+      }
     };
     if (k < 0) {
       put(j, p.pe_jvp ? tv : xv);

@@ -36,16 +36,20 @@ def pad_rows(P: int) -> int:
     return (P + 63) // 64 * 64
 
 
-def _buf(P, width, dev, zero=None):
+def _buf(P, width, dev, zero=None, dtype=torch.float32):
     """[pad_rows(P), pad32(width)] fp32 (rows >= P are scratch for the tile kernels); pad columns zeroed (default),
-    everything zeroed (zero=True) or nothing (zero=False)."""
+    everything zeroed (zero=True) or nothing (zero=False).  dtype = bfloat16: stored state of the 16-bit mode."""
     ld = pad32(width)
     if zero is None:          # only the pad COLUMNS must be finite zeros (they meet zero weight rows / unread dW columns);
-        t = torch.empty((pad_rows(P), ld), device=dev, dtype=torch.float32)   # a full fill of a [65536, 224] buffer
+        t = torch.empty((pad_rows(P), ld), device=dev, dtype=dtype)            # a full fill of a [65536, 224] buffer
         if ld != width:                                                        # costs 15 us, the 7 pad columns 3 us
             t[:, width:].zero_()
         return t
-    return (torch.zeros if zero else torch.empty)((pad_rows(P), ld), device=dev, dtype=torch.float32)
+    return (torch.zeros if zero else torch.empty)((pad_rows(P), ld), device=dev, dtype=dtype)
+
+
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
 
 
 def _zero_cols(t, c0):
@@ -159,7 +163,7 @@ class ChainBuilder:
         if t is None:
             return None
         self.keep.append(t)
-        return ptr(t) + 4 * off
+        return ptr(t) + t.element_size() * off
 
     def posenc(self, x, L, in_scale, tangent=None, x_div=1):
         """source of the positional encodings: x [P / x_div, 3] (x_div = samples per ray for per-ray directions)."""
@@ -170,12 +174,18 @@ class ChainBuilder:
     def init_store(self, G0):
         if G0 is not None:
             self.c.G0, self.c.ldg0 = self._p(G0), G0.shape[1]
+            if _is16(G0):
+                if self.c.init != CH_INIT["SEED"]:
+                    raise _lib.NudfError("a bf16 copy of the initial tile exists for the SEED initialisation only")
+                self.c.init_state16 |= 2
 
     def init_load(self, A0, lda0):
         self.c.A0, self.c.lda0 = self._p(A0), lda0
 
     def init_seed(self, A0, lda0, sign, wrow, scale, xscale):
         self.c.A0, self.c.lda0 = self._p(A0), lda0
+        if _is16(A0):
+            self.c.init_state16 |= 1
         self.c.seed_sign, self.c.seed_wrow = self._p(sign), self._p(wrow)
         self.c.seed_scale, self.c.seed_xscale = scale, xscale
 
@@ -195,6 +205,15 @@ class ChainBuilder:
         s.r1_row, s.ldr1, s.r1_col = self._p(r1_row), ldr1, self._p(r1_col)
         s.K, s.N, s.epi, s.iparam = K, N, CH[epi], iparam
         s.prec = getattr(Bp, "prec", 0)
+        # 16-bit stored state (config-5 mode): X1, X2, C1, the TANGENT mirror C2 and pe_dst of a step are bf16 TOGETHER
+        state = [t for t in (X1, X2, C1, C2 if epi == "TANGENT" else None, pe_dst) if t is not None]
+        if any(_is16(t) for t in state):
+            if not all(_is16(t) for t in state) or epi not in ("SOFTPLUS", "MULSP", "TANGENT", "BWD") or s.prec == 0:
+                raise _lib.NudfError("bf16 stored state: every state array of a SOFTPLUS / MULSP / TANGENT / BWD step of "
+                                     "the 16-bit mode, or none")
+            s.layout = _lib.CH_STATE16
+        else:
+            s.layout = 0
         s.act_write, s.act_col0, s.pe_tail_col, s.pe_tail_scale = act_write, act_col0, pe_tail_col, pe_tail_scale
         s.scale, s.xscale = scale, xscale
         self.n += 1
@@ -239,6 +258,7 @@ def gemm_tn_grouped(jobs, M):
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
             q.A1, q.B1, q.C, q.dbias = ptr(A1), ptr(B1), ptr(Cm), ptr(db)
+            q.flags = (1 if _is16(A1) else 0) | (2 if _is16(B1) else 0)
             q.lda1, q.ldb1, q.ldc, q.NA, q.NB = A1.shape[1], B1.shape[1], Cm.shape[1], NA, NB
             flops += 2.0 * M * NA * NB
         if TN_DETERMINISTIC:
@@ -370,6 +390,15 @@ class PackedLinear:
 # (the UDF value itself) stays in fp32.
 PRECISION = os.environ.get("NUDF_PRECISION", "fp32")
 _PREC = {"f32": 0, "f16": 1, "bf16": 2}
+
+
+# 16-bit mode: the UDF engine's saved-for-backward arrays (X, DA, R, EX, ABAR) are stored as bf16 -- half the HBM
+# traffic of the sweeps and of the weight-gradient GEMMs that read them.  STATE16 = False keeps them fp32 (A-B).
+STATE16 = os.environ.get("NUDF_STATE16", "1") != "0"
+
+
+def _state_dtype():
+    return torch.bfloat16 if (PRECISION != "fp32" and STATE16) else torch.float32
 
 
 def set_precision(name):
@@ -609,7 +638,9 @@ class UDFEngine:
         P, dev, L = x.shape[0], x.device, self.L
         net = self.net
         pack_group(self.layers, self._frag_kinds())
-        X = [_buf(P, pl.inp, dev, zero=False) for pl in self.layers] if need_grad_state else None
+        sd = _state_dtype()     # X[0] (the encoding, written by the tile initialisation) stays fp32
+        X = ([_buf(P, self.layers[0].inp, dev, zero=False)] +
+             [_buf(P, pl.inp, dev, zero=False, dtype=sd) for pl in self.layers[1:]]) if need_grad_state else None
         cb = ChainBuilder(P, "POSENC", k8(self.E))
         cb.posenc(x, net.multires, float(net.scale))
         if need_grad_state:
@@ -649,7 +680,7 @@ class UDFEngine:
         P, L, dev = st["P"], self.L, x.device
         X = st["X"]
         net = self.net
-        DA = [_buf(P, self.layers[l].out, dev, zero=False) for l in range(L)]
+        DA = [_buf(P, self.layers[l].out, dev, zero=False, dtype=X[L].dtype) for l in range(L)]
         plL = self.layers[L]
         Epad = pad32(self.E)
         cb = ChainBuilder(P, "SEED", k8(self.layers[L - 1].out))
@@ -684,8 +715,9 @@ class UDFEngine:
         second = d_g is not None and DA is not None
         R = EX = None
         if second:
-            R = [_buf(P, pl.inp, dev, zero=False) for pl in layers]
-            EX = [_buf(P, layers[l].out, dev, zero=False) for l in range(L)]
+            sd = X[L].dtype
+            R = [_buf(P, layers[0].inp, dev, zero=False)] + [_buf(P, pl.inp, dev, zero=False, dtype=sd) for pl in layers[1:]]
+            EX = [_buf(P, layers[l].out, dev, zero=False, dtype=sd) for l in range(L)]
             cb = ChainBuilder(P, "POSENC", k8(self.E))
             cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
             cb.init_store(R[0])
@@ -719,7 +751,7 @@ class UDFEngine:
                  ABAR[L].shape[1])
             r1, ldr1 = ABAR[L], ABAR[L].shape[1]
         for l in range(L):
-            ABAR[l] = _buf(P, layers[l].out, dev, zero=False)
+            ABAR[l] = _buf(P, layers[l].out, dev, zero=False, dtype=X[L].dtype)
         # adjoint sweep: the tile starts as d feat (ABAR[L] columns 1..F); column 0 enters as a rank-1 term
         cb = ChainBuilder(P, "LOAD", k8(F))
         if d_feat is None:

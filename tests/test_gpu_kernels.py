@@ -130,6 +130,31 @@ def test_gemm_tn_grouped_ragged_layouts(dev, M):
         mlp.TN_DETERMINISTIC = True
 
 
+@pytest.mark.parametrize("M", [77, 5000])
+def test_gemm_tn_grouped_bf16_operands(dev, M):
+    """operands stored as bf16 (the 16-bit mode's saved state) in every combination with fp32 ones: the kernel widens
+    them on the way into LDS, so with fp32 MFMAs the result equals the contraction of the ROUNDED operands to fp32
+    rounding -- including the bias sums taken from a bf16 A operand and the ragged last k-step."""
+    from neuraludf_amd import mlp
+    g = torch.Generator().manual_seed(12)
+    shapes = [(256, 256, True, True), (217, 256, True, False), (256, 40, False, True), (3, 128, True, True), (129, 72, True, True)]
+    jobs, refs = [], []
+    for NA, NB, a16, b16 in shapes:
+        lda, ldb = (NA + 7) // 8 * 8, (NB + 7) // 8 * 8
+        A = torch.randn(M, lda, generator=g)
+        B = torch.randn(M, ldb, generator=g)
+        Ad = A.to(dev).to(torch.bfloat16) if a16 else A.to(dev)
+        Bd = B.to(dev).to(torch.bfloat16) if b16 else B.to(dev)
+        Ar, Br = Ad.float().cpu().double(), Bd.float().cpu().double()
+        refs.append((Ar[:, :NA].t() @ Br[:, :NB], Ar[:, :NA].sum(0)))
+        jobs.append((Ad, NA, Bd, NB, torch.zeros(mlp.pad32(NA), ldb, device=dev), torch.zeros(mlp.pad32(NA), device=dev)))
+    assert mlp.PRECISION == "fp32"
+    mlp.gemm_tn_grouped(jobs, M)
+    for (NA, NB, a16, b16), j, (rC, rb) in zip(shapes, jobs, refs):
+        assert rel(j[4][:NA, :NB], rC.float()) < 2e-5, (NA, NB, a16, b16)
+        assert rel(j[5][:NA], rb.float()) < 2e-5, (NA, NB, a16, b16)
+
+
 def test_posenc_and_vjp(dev):
     from neuraludf_amd._lib import call, ptr
     g = torch.Generator().manual_seed(2)
