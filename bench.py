@@ -244,7 +244,7 @@ def main():
         "metric": "ray-samples/sec (train step)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f16/bf16 MFMA operands, f32 accumulate+state (config 5 mode)",
+        "dtype": "f32" if args.precision == "fp32" else "f16/bf16 MFMA operands, f32 accumulate, bf16 saved state (config 5 mode)",
         "data": "synthetic",
         "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
@@ -299,8 +299,13 @@ def main():
                               "algorithmic_gflop_per_step": fl / 1e9}
         result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
                                  "tflops": v[1] / v[2] / 1e12} for k, v in agg.items()}
-        result["roofline"]["traffic"] = pmc_traffic(dom, args.workload) if args.precision == "fp32" else None
+        result["roofline"]["traffic"] = pmc_traffic(dom, args.workload, args.precision)
         result["roofline"]["traffic_source"] = getattr(pmc_traffic, "source", None) if result["roofline"]["traffic"] else None
+        if args.precision != "fp32" and result["roofline"]["traffic"]:
+            # the 16-bit mode is priced against BOTH roofs: the sweeps are nowhere near the 2.5 PFLOP/s matrix peak, so the
+            # HBM side (measured bytes per launch / average launch time) is the one to watch
+            gbs = result["roofline"]["traffic"] / (sec / n) / 1e9
+            result["roofline"]["vs_hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         # ---- fused composite kernel alone (HBM roof) ----
         try:
             result["roofline_composite"] = composite_roofline(dev, rays_per_gpu, s_core)
@@ -323,15 +328,18 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, workload):
+def pmc_traffic(kernel, workload, precision="fp32"):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes over this same command (FETCH_SIZE and
     WRITE_SIZE, separate passes, scripts/pmc_traffic.sh; committed under profiles/).  rocprofv3 cannot wrap the
     timed process from inside, so the counters are collected beforehand; corrected as MI355X_MICROARCH.md
     prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
-    if workload != "dtu_scan24_512x128":
+    if (workload, precision) == ("dtu_scan24_512x128", "fp32"):
+        names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (2, 1)]
+    elif (workload, precision) == ("dtu_scan24_1024x256", "mixed16"):
+        names = ["r02_traffic_%s_cfg5_mixed16.json" % kernel]
+    else:
         return None
-    path = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic_%s.json" % (r, kernel)) for r in (2, 1))
-                 if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", nm) for nm in names) if os.path.exists(q)), None)
     if path is None:
         return None
     pmc_traffic.source = os.path.relpath(path, ROOT) + " (rocprofv3 PMC passes recorded beforehand, scripts/pmc_traffic.sh)"
