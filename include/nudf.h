@@ -91,6 +91,8 @@ typedef struct NudfGemmTNProblem {
 } NudfGemmTNProblem;
 #define NUDF_TN_A16 1
 #define NUDF_TN_B16 2
+#define NUDF_TN_A_BLK 4                         /* fp32 operand in the BLOCKED layout of NudfChainStep (rows padded to 32) */
+#define NUDF_TN_B_BLK 8
 typedef struct NudfGemmTNGroup {
   int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
   int32_t prec;                                 /* as NudfGemmTN.prec                     */
@@ -412,7 +414,8 @@ typedef struct NudfChain {
                                       and fall back to 64 otherwise */
   int32_t lda0, ldg0;
   int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */
-  int32_t init_state16;            /* INIT_SEED: bit 0 = A0 holds bf16, bit 1 = G0 receives bf16                 */
+  int32_t init_state16;            /* INIT_SEED: bit 0 = A0 holds bf16, bit 1 = G0 receives bf16, bit 2 = A0 is in the
+                                      BLOCKED layout, bit 3 = G0 is (fp32, transposed-product kernel only)          */
   float pe_in_scale;
   float seed_scale, seed_xscale;
   const float* A0;                 /* INIT_LOAD source / INIT_SEED stored activation                 */

@@ -91,17 +91,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   // k-step (all 32 rows exist -- every step but the last of the last row chunk) is plain loads off per-thread base
   // pointers and plain LDS stores; only the ragged step clamps rows and zeroes rows >= mend with selects.
   const bool a16 = (q.flags & NUDF_TN_A16) != 0, b16 = (q.flags & NUDF_TN_B16) != 0;
-  struct Op { const char* p; size_t rowb; int tk, tc; };      // base pointer (bytes), row stride (bytes), thread row / column
-  auto mk = [&](const float* base, int ld, int c0, bool h) {
+  // base pointer (bytes), row stride (bytes), byte offset of each of this thread's passes, bytes per k-step, thread row /
+  // first column, LDS offset (floats) between passes
+  struct Op { const char* p; size_t rowb, stepb; unsigned poff[4]; int tk, tc, lds_pass; bool blk; };
+  auto mk = [&](const float* base, int ld, int c0, bool h, bool blk) {
     Op o;
-    o.tk = h ? tid >> 4 : tid >> 5;
-    o.tc = h ? (tid & 15) * 8 : (tid & 31) * 4;
     const int esz = h ? 2 : 4;
     o.rowb = (size_t)ld * esz;
-    o.p = reinterpret_cast<const char*>(base) + (size_t)(mbeg + o.tk) * o.rowb + (size_t)min(c0 + o.tc, ld - (h ? 8 : 4)) * esz;
+    o.stepb = (size_t)BK * o.rowb;
+    o.blk = blk;
+    if (blk) {
+      // fp32, blocked: [32-row block][quad of columns][row in block][4]; row chunks start on block boundaries.  Lane ->
+      // row of the block, so that a wave instruction reads two whole quads = 1 KB of contiguous memory; the passes walk
+      // the quads (8 per pass), i.e. 32 tile columns
+      o.tk = tid & 31;
+      o.tc = (tid >> 5) * 4;
+      o.lds_pass = 32;
+      o.p = reinterpret_cast<const char*>(base) + (size_t)mbeg * o.rowb + (size_t)o.tk * 16;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) o.poff[ps] = (unsigned)(min(c0 + o.tc + 32 * ps, ld - 4) >> 2) * 512u;
+    } else {
+      o.tk = h ? tid >> 4 : tid >> 5;
+      o.tc = h ? (tid & 15) * 8 : (tid & 31) * 4;
+      o.lds_pass = (h ? 16 : 8) * LDT;
+      const int col = min(c0 + o.tc, ld - (h ? 8 : 4));
+      o.p = reinterpret_cast<const char*>(base) + (size_t)(mbeg + o.tk) * o.rowb + (size_t)col * esz;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) o.poff[ps] = (unsigned)((size_t)ps * (h ? 16 : 8) * o.rowb);
+    }
     return o;
   };
-  const Op oa = mk(q.A1, lda, i0, a16), ob = mk(q.B1, ldb, j0, b16);
+  const Op oa = mk(q.A1, lda, i0, a16, (q.flags & NUDF_TN_A_BLK) != 0), ob = mk(q.B1, ldb, j0, b16, (q.flags & NUDF_TN_B_BLK) != 0);
   f32x4 ra[4], rb[4];
   int ld_rows = 0;
   // the operand kind is a COMPILE-TIME parameter of these (dispatched once per workgroup below): with run-time kinds the
@@ -109,10 +129,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   auto load_op = [&](const Op& o, auto H, f32x4 (&r)[4], int kt, bool full) {
     constexpr bool h = decltype(H)::value;
     constexpr int np = h ? 2 : 4, rs = h ? 16 : 8;
-    if (full) {
-      const char* b = o.p + (size_t)kt * BK * o.rowb;
+    if (full || o.blk) {   // blocked buffers are padded to whole 32-row blocks: the ragged step needs no row clamp
+      const char* b = o.p + (size_t)kt * o.stepb;
 #pragma unroll
-      for (int ps = 0; ps < np; ++ps) r[ps] = *reinterpret_cast<const f32x4*>(b + (size_t)(ps * rs) * o.rowb);
+      for (int ps = 0; ps < np; ++ps) r[ps] = *reinterpret_cast<const f32x4*>(b + o.poff[ps]);
     } else {
 #pragma unroll
       for (int ps = 0; ps < np; ++ps) {
@@ -124,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   // bias gradient = column sums of A, taken from the registers on their way to LDS (tiles of the first tile column)
   const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
   f32x4 bacc = {0.f, 0.f, 0.f, 0.f}, bacc2 = {0.f, 0.f, 0.f, 0.f};   // bacc2: columns 4..7 of a bf16 operand's 8
+  f32x4 bacc3 = {0.f, 0.f, 0.f, 0.f}, bacc4 = {0.f, 0.f, 0.f, 0.f};   // blocked fp32 operand: one accumulator per pass
   auto widen = [](const f32x4& raw, f32x4& lo, f32x4& hi) {   // 8 bf16 -> 8 fp32 (memory order)
     const uint4 u = __builtin_bit_cast(uint4, raw);
     lo = f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
@@ -138,15 +159,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
     if constexpr (!h) {
       if (ld_rows >= BK) {   // the common case: no selects
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(dst + ps * 8 * LDT) = r[ps];
-        if (bias) bacc += (r[0] + r[1]) + (r[2] + r[3]);
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(dst + ps * o.lds_pass) = r[ps];
+        if (bias) {
+          if (o.blk) { bacc += r[0]; bacc2 += r[1]; bacc3 += r[2]; bacc4 += r[3]; }   // a pass = other columns
+          else bacc += (r[0] + r[1]) + (r[2] + r[3]);                               // a pass = other rows
+        }
         return;
       }
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
-        const f32x4 v = ((ps * 8 + o.tk) < ld_rows) ? r[ps] : z;
-        *reinterpret_cast<f32x4*>(dst + ps * 8 * LDT) = v;
-        if (bias) bacc += v;
+        const f32x4 v = ((o.blk ? o.tk : ps * 8 + o.tk) < ld_rows) ? r[ps] : z;
+        *reinterpret_cast<f32x4*>(dst + ps * o.lds_pass) = v;
+        if (bias) {
+          if (!o.blk || ps == 0) bacc += v;
+          else if (ps == 1) bacc2 += v;
+          else if (ps == 2) bacc3 += v;
+          else bacc4 += v;
+        }
       }
     } else {
 #pragma unroll
@@ -352,12 +381,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   if (g.flags & TNF_NO_EPILOGUE) return;
   float* slot = g.ws ? g.ws + (size_t)blockIdx.x * TN_WS_TILE : nullptr;
   if (do_bias) {   // the loop's last barrier has passed: the operand tiles are free
-    *reinterpret_cast<f32x4*>(smem + oa.tk * BM + oa.tc) = bacc;
-    if (a16) *reinterpret_cast<f32x4*>(smem + oa.tk * BM + oa.tc + 4) = bacc2;
+    int ngroups;
+    if (oa.blk) {   // thread = (row of the block, quad): 32 partial rows x 128 columns
+      ngroups = 32;
+      float* d = smem + oa.tk * BM + oa.tc;
+      *reinterpret_cast<f32x4*>(d) = bacc;
+      *reinterpret_cast<f32x4*>(d + 32) = bacc2;
+      *reinterpret_cast<f32x4*>(d + 64) = bacc3;
+      *reinterpret_cast<f32x4*>(d + 96) = bacc4;
+    } else {
+      ngroups = a16 ? 16 : 8;
+      *reinterpret_cast<f32x4*>(smem + oa.tk * BM + oa.tc) = bacc;
+      if (a16) *reinterpret_cast<f32x4*>(smem + oa.tk * BM + oa.tc + 4) = bacc2;
+    }
     __syncthreads();
     if (tid < BM) {
       float s = 0.0f;
-      const int ngroups = a16 ? 16 : 8;
       for (int k = 0; k < ngroups; ++k) s += smem[k * BM + tid];
       if (slot) slot[BM * BN + tid] = s;
       else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, s);
@@ -469,6 +508,10 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   for (int i = 0; i < g.n_problems; ++i) {
     const NudfGemmTNProblem& q = g.prob[i];
     const int ma = (q.flags & NUDF_TN_A16) ? 8 : 4, mb = (q.flags & NUDF_TN_B16) ? 8 : 4;
+    if (((q.flags & NUDF_TN_A_BLK) && (q.flags & NUDF_TN_A16)) || ((q.flags & NUDF_TN_B_BLK) && (q.flags & NUDF_TN_B16))) {
+      nudf_set_error("nudf_gemm_tn_grouped: the blocked layout is defined for fp32 operands", hipErrorInvalidValue);
+      return -1;
+    }
     if ((q.lda1 % ma) || (q.ldb1 % mb) || q.NA <= 0 || q.NB <= 0 || q.lda1 < ma || q.ldb1 < mb ||
         (((uintptr_t)q.A1) & 15) || (((uintptr_t)q.B1) & 15)) {
       nudf_set_error("nudf_gemm_tn_grouped: leading dimensions must be multiples of 4, operands 16-byte aligned",

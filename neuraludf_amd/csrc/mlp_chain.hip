@@ -624,7 +624,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
   if (dbg && lane == 0) dbg[63] = wall_clock64();
 }
 
-int nudf_chain_rows_class(const NudfChain& p);                              // mlp_chain_rows.hip
+int nudf_chain_rows_class(const NudfChain& p, bool allow_blocked = false);  // mlp_chain_rows.hip
 int nudf_mlp_chain_rows_launch(const NudfChain& p, int cls, hipStream_t st);
 int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st);
 
@@ -684,6 +684,17 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0) return nudf_mlp_chain_rows_launch(p, cls, st);
     // contract of the wave-private kernel not met (16-bit operands, unaligned row buffers): workgroup-shared tiles
+  }
+  bool blocked = (p.init_state16 & 12) != 0;
+  for (int i = 0; i < p.n_steps; ++i) blocked = blocked || (p.step[i].layout & 31) != 0;
+  if (blocked) {   // only the transposed-product shared tile addresses the blocked layout
+    const int cls = nudf_chain_rows_class(p, true);
+    if (cls < 0 || (p.tile_rows != 66 && p.tile_rows != 0)) {
+      nudf_set_error("nudf_mlp_chain: blocked-layout buffers need the transposed-product kernel (tile_rows 0 / 66, fp32 "
+                     "steps, 16-byte aligned rows)", hipErrorInvalidValue);
+      return (int)hipErrorInvalidValue;
+    }
+    return nudf_mlp_chain_tq_launch(p, cls, st);
   }
   if (p.tile_rows == 66 || (p.tile_rows == 0 && p.P > 256 * 64 && nudf_chain_quad_mode() > 0)) {
     const int cls = nudf_chain_rows_class(p);

@@ -116,7 +116,8 @@ __device__ __forceinline__ void chr_store_range(chr_gp C, unsigned base, int f0,
 // reads (operand loads clamp their columns into [0, N)).
 template <int EPI>
 __device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act, const ChrStep& cs, int t, int h, int ln,
-                                             const f32x16& a, float (&w1)[16], float (&w2)[16], bool reload, int t_next) {
+                                             const f32x16& a, float (&w1)[16], float (&w2)[16], bool reload, int t_next,
+                                             const float* bias_lds = nullptr) {
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
   const int fb = 32 * t + 4 * h;
   const int N = cs.N;
@@ -128,10 +129,12 @@ __device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act
   for (int q = 0; q < 4; ++q) {
     const int f0 = fb + 8 * q;
     f32x4 o, o2;
+    f32x4 bq = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias_lds) bq = *reinterpret_cast<const f32x4*>(bias_lds + f0);   // bias added AFTER the products (shared-tile form)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * q + i;
-      float v = a[r];
+      float v = a[r] + bq[i];
       if (has_r1) v += r1 * st.r1_col[min(f0 + i, N - 1)];
       const float x1 = U1 ? w1[r] : 0.0f, x2 = U2 ? w2[r] : 0.0f;
       if (EPI == NUDF_CH_SOFTPLUS) {
@@ -484,7 +487,8 @@ __global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfC
 // can have 64 VMEM operations in flight (6-bit vmcnt); mlp_chain_kernel issues ~256 b32 loads / stores per layer
 // and wave, i.e. at least four HBM round trips per layer spent purely on that limit (scripts/chain_timeline.py:
 // the epilogues' memory operations are 4 / 11 / 28 / 18 % of the four UDF sweeps).  Same contract as the wave-private
-// kernel above (nudf_chain_rows_class), same step tables, bias-first summation.
+// kernel above (nudf_chain_rows_class), same step tables; the bias is added after the products, as in
+// mlp_chain_kernel, so the two shared-tile kernels agree to the bit wherever the compiler contracts the same way.
 // =====================================================================================================
 struct ChainTqSmem {
   float act[64 * CH_LD];   // 74 752 B
@@ -495,18 +499,14 @@ struct ChainTqSmem {
 
 template <int NRT, int NCT, class Tail>
 __device__ __forceinline__ void tq_mma(const float* __restrict__ arow, const f32x4* __restrict__ bptr, size_t bstride,
-                                       int G, const float* bb, f32x16 (&acc)[2][2], Tail&& tail) {
+                                       int G, f32x16 (&acc)[2][2], Tail&& tail) {
   f32x4 a0[NRT], a1[NRT], b0[NCT], b1[NCT];
 #pragma unroll
-  for (int j = 0; j < NCT; ++j)
+  for (int i = 0; i < NRT; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bb + 32 * j + 8 * q);
+    for (int j = 0; j < NCT; ++j)
 #pragma unroll
-      for (int i = 0; i < NRT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b[e];
-    }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
   for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD);
 #pragma unroll
@@ -573,7 +573,7 @@ __device__ __forceinline__ void tq_mma(const float* __restrict__ arow, const f32
 // the wave's tiles as straight-line code; X2 of tile t + 1 is requested before tile t is computed and stored
 template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
-                                            int h, int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16]) {
+                                            int h, int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16], const float* bias_lds) {
   constexpr bool U2 = CH_USES_X2(EPI);
   constexpr int NTL = NRT * NCT;
   float xb[2][16];
@@ -591,7 +591,8 @@ __device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act,
   for (int t = 0; t < NTL; ++t) {
     if (U2 && t + 1 < NTL) issue(xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
     const int i = t / NCT, j = t % NCT;
-    chr_epi_tile<EPI>(st, act + (rt0 + i) * 32 * CH_LD, cs[i], ct0 + j, h, ln, acc[i][j], px1[i][j], xb[t & 1], false, 0);
+    chr_epi_tile<EPI>(st, act + (rt0 + i) * 32 * CH_LD, cs[i], ct0 + j, h, ln, acc[i][j], px1[i][j], xb[t & 1], false, 0,
+                      bias_lds);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -599,11 +600,11 @@ __device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act,
 template <int EPI>
 __device__ __forceinline__ void tq_epilogue_any(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
                                                 int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
-                                                float (&px1)[2][2][16]) {
-  if (nrt == 2 && nct == 2) tq_epilogue<EPI, 2, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1);
-  else if (nrt == 2) tq_epilogue<EPI, 2, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1);
-  else if (nct == 2) tq_epilogue<EPI, 1, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1);
-  else tq_epilogue<EPI, 1, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1);
+                                                float (&px1)[2][2][16], const float* bias_lds) {
+  if (nrt == 2 && nct == 2) tq_epilogue<EPI, 2, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
+  else if (nrt == 2) tq_epilogue<EPI, 2, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
+  else if (nct == 2) tq_epilogue<EPI, 1, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
+  else tq_epilogue<EPI, 1, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
 }
 
 template <int XCLS>
@@ -648,10 +649,14 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
       const bool live = gr < p.P;
       if (!live) gr = p.P - 1;
       float s, om;
-      ch_sp_derivs(p.A0[(size_t)gr * p.lda0 + c], p.seed_xscale, s, om);
+      const float hst = (p.init_state16 & 4) ? p.A0[ch_blk_off(gr, c, p.lda0)] : p.A0[(size_t)gr * p.lda0 + c];
+      ch_sp_derivs(hst, p.seed_xscale, s, om);
       const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
       sm.act[r * CH_LD + c] = val;
-      if (p.G0 && live) p.G0[(size_t)gr * p.ldg0 + c] = val;
+      if (p.G0 && live) {
+        if (p.init_state16 & 8) p.G0[ch_blk_off(gr, c, p.ldg0)] = val;
+        else p.G0[(size_t)gr * p.ldg0 + c] = val;
+      }
     }
   }
   __syncthreads();
@@ -718,7 +723,6 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
       const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
       const f32x4* bptr = reinterpret_cast<const f32x4*>(st.Bp) + (size_t)ct0 * 64 + lane;
       const size_t bstride = (size_t)NT * 64;
-      const float* bb = sm.bias[si & 1] + 32 * ct0 + 4 * h;
       const bool u1 = XCLS >= 1 && CH_USES_X1(st.epi);
       auto tail = [&]() {
         if (XCLS == 0) return;
@@ -734,10 +738,10 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
               for (int e = 0; e < 4; ++e) px1[i][j][4 * q + e] = v[e];
             }
       };
-      if (nrt == 2 && nct == 2) tq_mma<2, 2>(arow, bptr, bstride, G, bb, acc, tail);
-      else if (nrt == 2) tq_mma<2, 1>(arow, bptr, bstride, G, bb, acc, tail);
-      else if (nct == 2) tq_mma<1, 2>(arow, bptr, bstride, G, bb, acc, tail);
-      else tq_mma<1, 1>(arow, bptr, bstride, G, bb, acc, tail);
+      if (nrt == 2 && nct == 2) tq_mma<2, 2>(arow, bptr, bstride, G, acc, tail);
+      else if (nrt == 2) tq_mma<2, 1>(arow, bptr, bstride, G, acc, tail);
+      else if (nct == 2) tq_mma<1, 2>(arow, bptr, bstride, G, acc, tail);
+      else tq_mma<1, 1>(arow, bptr, bstride, G, acc, tail);
     }
     sm.bias[(si + 1) & 1][tid] = nbias;
     if (dbg && lane == 0) dbg[2 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -746,17 +750,17 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: tq_epilogue_any<NUDF_CH_SOFTPLUS>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_NONE: tq_epilogue_any<NUDF_CH_NONE>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELU: tq_epilogue_any<NUDF_CH_RELU>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_SIGMOIDN: tq_epilogue_any<NUDF_CH_SIGMOIDN>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_UDFHEAD: tq_epilogue_any<NUDF_CH_UDFHEAD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULSP: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULSP>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULMASK: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_TANGENT: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_TANGENT>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_BWD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_BWD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_ADDMASK: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_ADDMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELUADD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_RELUADD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SOFTPLUS: tq_epilogue_any<NUDF_CH_SOFTPLUS>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_NONE: tq_epilogue_any<NUDF_CH_NONE>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_RELU: tq_epilogue_any<NUDF_CH_RELU>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_SIGMOIDN: tq_epilogue_any<NUDF_CH_SIGMOIDN>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_UDFHEAD: tq_epilogue_any<NUDF_CH_UDFHEAD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_MULSP: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULSP>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_MULMASK: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_TANGENT: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_TANGENT>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_BWD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_BWD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_ADDMASK: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_ADDMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_RELUADD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_RELUADD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
         default: break;
       }
     }
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
       __syncthreads();
       const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
       ch_write_pe_rows<256>(sm.act, sm.xs, sm.vs, 64, tid, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe,
-                            st.pe_tail_col, min((pe_end + 15) & ~15, 288));
+                            st.pe_tail_col, min((pe_end + 15) & ~15, 288), false, (st.layout & NUDF_CH_BLK_PE) != 0);
     }
     __syncthreads();
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -797,12 +801,14 @@ int nudf_mlp_chain_tq_launch(const NudfChain& p0, int cls, hipStream_t st) {
 }
 
 // The launch-time contract above; also picks the operand class.  Returns -1 when the workgroup-shared kernel must run.
-int nudf_chain_rows_class(const NudfChain& p) {
+int nudf_chain_rows_class(const NudfChain& p, bool allow_blocked) {
   int cls = 0;
+  if ((p.init_state16 & 12) && !allow_blocked) return -1;
   auto vec_ok = [](const void* q, int ld) { return ((((uintptr_t)q) | ((unsigned)ld << 2)) & 15) == 0; };
   for (int i = 0; i < p.n_steps; ++i) {
     const NudfChainStep& s = p.step[i];
     if (s.prec != 0 || (s.layout & NUDF_CH_STATE16)) return -1;
+    if ((s.layout & 31) && !allow_blocked) return -1;
     const int e = s.epi;
     if (CH_USES_X1(e)) {
       if (!s.X1 || !vec_ok(s.X1, s.ldx1)) return -1;

@@ -12,6 +12,11 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// element (r, c) of a [P, ld] buffer in the BLOCKED layout of nudf.h
+__device__ __forceinline__ size_t ch_blk_off(int r, int c, int ld) {
+  return (size_t)(r >> 5) * 32 * ld + (size_t)(c >> 2) * 128 + (size_t)(r & 31) * 4 + (c & 3);
+}
+
 // bf16 <-> fp32 of the 16-bit stored state (round to nearest even on the way out)
 __device__ __forceinline__ float ch_bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ unsigned short ch_f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -53,7 +58,8 @@ __device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, 
 template <int NTHR>
 __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, const float* vs, int rows, int tid,
                                                  const NudfChain& p, int m0, int col0, float scale, float* gdst,
-                                                 int ldg, int gcol0, int zero_to, bool dst16 = false) {
+                                                 int ldg, int gcol0, int zero_to, bool dst16 = false,
+                                                 bool dstblk = false) {
   const int L = p.pe_L;
   const int E = 3 * (2 * L + 1);
   for (int it = tid; it < rows * 3 * (L + 1); it += NTHR) {
@@ -69,6 +75,7 @@ __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, co
       arow[c] = val;
       if (mirror) {
         if (dst16) reinterpret_cast<unsigned short*>(gdst)[goff + c] = ch_f2bf(val);
+        else if (dstblk) gdst[ch_blk_off(m0 + r, gcol0 + c, ldg)] = val;
         else gdst[goff + c] = val;
       }
     };

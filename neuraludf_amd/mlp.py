@@ -36,9 +36,16 @@ def pad_rows(P: int) -> int:
     return (P + 63) // 64 * 64
 
 
-def _buf(P, width, dev, zero=None, dtype=torch.float32):
+def _buf(P, width, dev, zero=None, dtype=torch.float32, blocked=False):
     """[pad_rows(P), pad32(width)] fp32 (rows >= P are scratch for the tile kernels); pad columns zeroed (default),
-    everything zeroed (zero=True) or nothing (zero=False).  dtype = bfloat16: stored state of the 16-bit mode."""
+    everything zeroed (zero=True) or nothing (zero=False).  dtype = bfloat16: stored state of the 16-bit mode.
+    blocked = True marks the buffer as holding the BLOCKED layout of include/nudf.h (same size; only the
+    transposed-product chain kernel and the grouped weight-gradient GEMM address it; `unblock` gives the plain view)."""
+    if blocked:
+        assert zero is False and dtype == torch.float32
+        t = torch.empty((pad_rows(P), pad32(width)), device=dev, dtype=dtype)
+        t._nudf_blk = True
+        return t
     ld = pad32(width)
     if zero is None:          # only the pad COLUMNS must be finite zeros (they meet zero weight rows / unread dW columns);
         t = torch.empty((pad_rows(P), ld), device=dev, dtype=dtype)            # a full fill of a [65536, 224] buffer
@@ -50,6 +57,28 @@ def _buf(P, width, dev, zero=None, dtype=torch.float32):
 
 def _is16(t):
     return t is not None and t.dtype == torch.bfloat16
+
+
+def _isblk(t):
+    return t is not None and getattr(t, "_nudf_blk", False)
+
+
+def block(t):
+    """blocked-layout copy of a row-major [R, ld] fp32 buffer (R % 32 == 0, ld % 4 == 0); inverse of `unblock`."""
+    R, ld = t.shape
+    assert R % 32 == 0 and ld % 4 == 0 and t.dtype == torch.float32
+    b = t.reshape(R // 32, 32, ld // 4, 4).permute(0, 2, 1, 3).reshape(R, ld).contiguous()
+    b._nudf_blk = True
+    return b
+
+
+def unblock(t):
+    """row-major copy of a buffer in the blocked layout (tests / debugging): element (r, c) sits at
+    (r // 32) * 32 * ld + (c // 4) * 128 + (r % 32) * 4 + c % 4."""
+    if not _isblk(t):
+        return t
+    R, ld = t.shape
+    return t.reshape(R // 32, ld // 4, 32, 4).permute(0, 2, 1, 3).reshape(R, ld).contiguous()
 
 
 def _zero_cols(t, c0):
@@ -174,10 +203,10 @@ class ChainBuilder:
     def init_store(self, G0):
         if G0 is not None:
             self.c.G0, self.c.ldg0 = self._p(G0), G0.shape[1]
-            if _is16(G0):
+            if _is16(G0) or _isblk(G0):
                 if self.c.init != CH_INIT["SEED"]:
-                    raise _lib.NudfError("a bf16 copy of the initial tile exists for the SEED initialisation only")
-                self.c.init_state16 |= 2
+                    raise _lib.NudfError("a bf16 / blocked copy of the initial tile exists for the SEED initialisation only")
+                self.c.init_state16 |= 2 if _is16(G0) else 8
 
     def init_load(self, A0, lda0):
         self.c.A0, self.c.lda0 = self._p(A0), lda0
@@ -186,6 +215,8 @@ class ChainBuilder:
         self.c.A0, self.c.lda0 = self._p(A0), lda0
         if _is16(A0):
             self.c.init_state16 |= 1
+        if _isblk(A0):
+            self.c.init_state16 |= 4
         self.c.seed_sign, self.c.seed_wrow = self._p(sign), self._p(wrow)
         self.c.seed_scale, self.c.seed_xscale = scale, xscale
 
@@ -213,7 +244,10 @@ class ChainBuilder:
                                      "the 16-bit mode, or none")
             s.layout = _lib.CH_STATE16
         else:
-            s.layout = 0
+            s.layout = ((1 if _isblk(X1) else 0) | (2 if _isblk(X2) else 0) | (4 if _isblk(C1) else 0) |
+                        (8 if (_isblk(C2) and epi == "TANGENT") else 0) | (16 if _isblk(pe_dst) else 0))
+            if _isblk(C2) and epi != "TANGENT":
+                raise _lib.NudfError("blocked layout: C2 of a TANGENT step only")
         s.act_write, s.act_col0, s.pe_tail_col, s.pe_tail_scale = act_write, act_col0, pe_tail_col, pe_tail_scale
         s.scale, s.xscale = scale, xscale
         self.n += 1
@@ -258,7 +292,7 @@ def gemm_tn_grouped(jobs, M):
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
             q.A1, q.B1, q.C, q.dbias = ptr(A1), ptr(B1), ptr(Cm), ptr(db)
-            q.flags = (1 if _is16(A1) else 0) | (2 if _is16(B1) else 0)
+            q.flags = (1 if _is16(A1) else 0) | (2 if _is16(B1) else 0) | (4 if _isblk(A1) else 0) | (8 if _isblk(B1) else 0)
             q.lda1, q.ldb1, q.ldc, q.NA, q.NB = A1.shape[1], B1.shape[1], Cm.shape[1], NA, NB
             flops += 2.0 * M * NA * NB
         if TN_DETERMINISTIC:
@@ -395,6 +429,16 @@ _PREC = {"f32": 0, "f16": 1, "bf16": 2}
 # 16-bit mode: the UDF engine's saved-for-backward arrays (X, DA, R, EX, ABAR) are stored as bf16 -- half the HBM
 # traffic of the sweeps and of the weight-gradient GEMMs that read them.  STATE16 = False keeps them fp32 (A-B).
 STATE16 = os.environ.get("NUDF_STATE16", "1") != "0"
+
+
+# fp32 mode, large launches: the UDF engine's saved state in the BLOCKED layout + the transposed-product chain kernel
+# (1 KB of contiguous memory per wave instruction in the epilogues, 16 KB contiguous operand tiles in the weight-gradient
+# GEMM).  NUDF_BLOCKED_STATE=0 keeps row-major buffers and the default kernel (A-B).
+BLOCKED_STATE = os.environ.get("NUDF_BLOCKED_STATE", "1") != "0"
+
+
+def _state_blocked(P):
+    return BLOCKED_STATE and PRECISION == "fp32" and USE_CHAIN and CHAIN_TILE in (0, 66) and P > 256 * 64
 
 
 def _state_dtype():
@@ -638,9 +682,10 @@ class UDFEngine:
         P, dev, L = x.shape[0], x.device, self.L
         net = self.net
         pack_group(self.layers, self._frag_kinds())
-        sd = _state_dtype()     # X[0] (the encoding, written by the tile initialisation) stays fp32
+        sd = _state_dtype()     # X[0] (the encoding, written by the tile initialisation) stays fp32, row-major
+        blk = _state_blocked(P)
         X = ([_buf(P, self.layers[0].inp, dev, zero=False)] +
-             [_buf(P, pl.inp, dev, zero=False, dtype=sd) for pl in self.layers[1:]]) if need_grad_state else None
+             [_buf(P, pl.inp, dev, zero=False, dtype=sd, blocked=blk) for pl in self.layers[1:]]) if need_grad_state else None
         cb = ChainBuilder(P, "POSENC", k8(self.E))
         cb.posenc(x, net.multires, float(net.scale))
         if need_grad_state:
@@ -680,7 +725,7 @@ class UDFEngine:
         P, L, dev = st["P"], self.L, x.device
         X = st["X"]
         net = self.net
-        DA = [_buf(P, self.layers[l].out, dev, zero=False, dtype=X[L].dtype) for l in range(L)]
+        DA = [_buf(P, self.layers[l].out, dev, zero=False, dtype=X[L].dtype, blocked=_isblk(X[L])) for l in range(L)]
         plL = self.layers[L]
         Epad = pad32(self.E)
         cb = ChainBuilder(P, "SEED", k8(self.layers[L - 1].out))
@@ -715,9 +760,10 @@ class UDFEngine:
         second = d_g is not None and DA is not None
         R = EX = None
         if second:
-            sd = X[L].dtype
-            R = [_buf(P, layers[0].inp, dev, zero=False)] + [_buf(P, pl.inp, dev, zero=False, dtype=sd) for pl in layers[1:]]
-            EX = [_buf(P, layers[l].out, dev, zero=False, dtype=sd) for l in range(L)]
+            sd, blk = X[L].dtype, _isblk(X[L])
+            R = ([_buf(P, layers[0].inp, dev, zero=False)] +
+                 [_buf(P, pl.inp, dev, zero=False, dtype=sd, blocked=blk) for pl in layers[1:]])
+            EX = [_buf(P, layers[l].out, dev, zero=False, dtype=sd, blocked=blk) for l in range(L)]
             cb = ChainBuilder(P, "POSENC", k8(self.E))
             cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
             cb.init_store(R[0])
@@ -751,7 +797,7 @@ class UDFEngine:
                  ABAR[L].shape[1])
             r1, ldr1 = ABAR[L], ABAR[L].shape[1]
         for l in range(L):
-            ABAR[l] = _buf(P, layers[l].out, dev, zero=False, dtype=X[L].dtype)
+            ABAR[l] = _buf(P, layers[l].out, dev, zero=False, dtype=X[L].dtype, blocked=_isblk(X[L]))
         # adjoint sweep: the tile starts as d feat (ABAR[L] columns 1..F); column 0 enters as a rank-1 term
         cb = ChainBuilder(P, "LOAD", k8(F))
         if d_feat is None:

@@ -32,9 +32,10 @@ def sweeps(dev, P, tile, seed=0, S=64):
         rays_d = torch.nn.functional.normalize(torch.randn((P + S - 1) // S, 3, generator=g), dim=-1).to(dev)
         out = {}
         st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
-        out.update(udf=st["udf"], sign=st["sign"], feat=st["feat"][:, :256], X4=st["X"][4][:P, :256], X8=st["X"][8][:P])
+        ub = mlp.unblock
+        out.update(udf=st["udf"], sign=st["sign"], feat=st["feat"][:, :256], X4=ub(st["X"][4])[:P, :256], X8=ub(st["X"][8])[:P])
         gr, DA = eng.gradient(x, st)
-        out.update(g=gr, DA0=DA[0][:P], DA3=DA[3][:P, :217], DA7=DA[7][:P])
+        out.update(g=gr, DA0=ub(DA[0])[:P], DA3=ub(DA[3])[:P, :217], DA7=ub(DA[7])[:P])
         out["uo"] = eng.forward(x, need_grad_state=False, udf_only=True)["udf"]
         # colour net on the UDF features
         Pc = (P // S) * S

@@ -72,6 +72,32 @@ def test_tq_kernel_full_size_is_the_one_that_ran_and_deterministic(dev):
     c = sweeps(dev, P, 66, seed=5)
     bad, _, worst, worst_l2 = compare(a, b, f"P={P} shared vs tq", verbose=True)
     assert not bad, bad
-    assert not torch.equal(a["feat"], b["feat"])          # bias-first summation: a silent fall-back would be bit-equal
+    # same products in the same order, bias added after them in both kernels: the UDF sweeps agree to the BIT (what makes
+    # chunked and unchunked renders identical although their launches pick different kernels)
+    for k in ("udf", "sign", "feat", "X4", "X8", "g", "DA0", "DA3", "DA7", "uo"):
+        assert torch.equal(a[k], b[k]), k
     for k in ("udf", "feat", "X8", "g", "DA0", "uo", "cb", "cc", "dCIN", "nsig", "nrgb"):
         assert torch.equal(b[k], c[k]), k
+
+
+def mlp_state_probe(dev, P):
+    from chain_sweeps import engines
+    x = (torch.rand(P, 3) * 2 - 1).to(dev)
+    return engines(dev)["eng"].forward(x, need_grad_state=True)
+
+
+def test_blocked_state_layout_matches_row_major_path(dev):
+    """large fp32 launches keep the UDF engine's saved state in the BLOCKED layout (transposed-product kernel + grouped
+    weight-gradient GEMM address it): every value, stored array (un-blocked for the comparison) and parameter gradient
+    against the row-major path on the default kernel, at a size with a ragged last tile."""
+    from neuraludf_amd import mlp
+    P = 64 * 300 + 21
+    assert mlp.BLOCKED_STATE and mlp._state_blocked(P)
+    a = sweeps(dev, P, 64, seed=8)          # tile 64: row-major state, mlp_chain_kernel
+    b = sweeps(dev, P, 0, seed=8)           # auto: blocked state
+    bad, _, worst, worst_l2 = compare(a, b, f"P={P} row-major vs blocked", verbose=True)
+    assert not bad, bad
+    for k in ("udf", "sign", "feat", "X4", "X8", "g", "DA0", "DA3", "DA7", "uo"):     # bit-identical sweeps
+        assert torch.equal(a[k], b[k]), k
+    st = mlp_state_probe(dev, P)
+    assert mlp._isblk(st["X"][4]) and not mlp._isblk(st["X"][0])      # the blocked path really ran

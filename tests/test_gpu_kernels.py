@@ -155,6 +155,31 @@ def test_gemm_tn_grouped_bf16_operands(dev, M):
         assert rel(j[5][:NA], rb.float()) < 2e-5, (NA, NB, a16, b16)
 
 
+@pytest.mark.parametrize("M", [77, 5000])
+def test_gemm_tn_grouped_blocked_operands(dev, M):
+    """fp32 operands in the BLOCKED layout of nudf.h (what the transposed-product chain kernel stores), alone and mixed
+    with row-major ones, ragged widths and a ragged last k-step: same contraction and bias sums as the row-major call."""
+    from neuraludf_amd import mlp
+    g = torch.Generator().manual_seed(13)
+    shapes = [(256, 256, True, True), (217, 256, True, True), (256, 40, True, False), (3, 128, False, True), (129, 72, True, True)]
+    Mp = (M + 63) // 64 * 64
+    jobs, refs = [], []
+    for NA, NB, ablk, bblk in shapes:
+        lda, ldb = (NA + 3) // 4 * 4, (NB + 3) // 4 * 4
+        A = torch.zeros(Mp, lda); A[:M] = torch.randn(M, lda, generator=g)
+        B = torch.zeros(Mp, ldb); B[:M] = torch.randn(M, ldb, generator=g)
+        A[M:] = float("nan"); B[M:] = float("nan")          # rows past M must never reach a result
+        refs.append((A[:M, :NA].double().t() @ B[:M, :NB].double(), A[:M, :NA].double().sum(0)))
+        Ad, Bd = A.to(dev), B.to(dev)
+        jobs.append((mlp.block(Ad) if ablk else Ad, NA, mlp.block(Bd) if bblk else Bd, NB,
+                     torch.zeros(mlp.pad32(NA), ldb, device=dev), torch.zeros(mlp.pad32(NA), device=dev)))
+        assert torch.equal(mlp.unblock(mlp.block(Ad)).nan_to_num(7.0), Ad.nan_to_num(7.0))
+    mlp.gemm_tn_grouped(jobs, M)
+    for (NA, NB, ablk, bblk), j, (rC, rb) in zip(shapes, jobs, refs):
+        assert rel(j[4][:NA, :NB], rC.float()) < 2e-5, (NA, NB, ablk, bblk)
+        assert rel(j[5][:NA], rb.float()) < 2e-5, (NA, NB, ablk, bblk)
+
+
 def test_posenc_and_vjp(dev):
     from neuraludf_amd._lib import call, ptr
     g = torch.Generator().manual_seed(2)
