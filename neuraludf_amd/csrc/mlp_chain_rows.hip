@@ -776,22 +776,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
   }
 }
 
-int nudf_mlp_chain_tq_launch(const NudfChain& p0, int cls, hipStream_t st) {
-  NudfChain p = p0;
-  {
-    // TIMING EXPERIMENT ONLY (NUDF_TQ_FAKE_BLOCKED=1): address every quad-accessed buffer as if it were blocked
-    // (same footprint, wrong elements -> wrong results)
-    static const int fake = [] {
-      const char* e = getenv("NUDF_TQ_FAKE_BLOCKED");
-      const int on = (e && e[0] == '1') ? 1 : 0;
-      if (on) fprintf(stderr, "nudf: NUDF_TQ_FAKE_BLOCKED=1 -- chain results are WRONG on purpose (timing experiment)\n");
-      return on;
-    }();
-    if (fake)
-      for (int i = 0; i < p.n_steps; ++i)
-        if (p.step[i].epi != NUDF_CH_UDFHEAD && p.step[i].epi != NUDF_CH_SIGMOIDN)
-          p.step[i].layout = NUDF_CH_BLK_X1 | NUDF_CH_BLK_X2 | NUDF_CH_BLK_C1 | (p.step[i].epi == NUDF_CH_TANGENT ? NUDF_CH_BLK_C2 : 0);
-  }
+int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st) {
   const dim3 grid((p.P + 63) / 64), block(256);
   if (cls == 0) hipLaunchKernelGGL((mlp_chain_tq_kernel<0>), grid, block, 0, st, p);
   else if (cls == 1) hipLaunchKernelGGL((mlp_chain_tq_kernel<1>), grid, block, 0, st, p);
