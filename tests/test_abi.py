@@ -30,7 +30,8 @@ def test_ctypes_structs_match_header_field_counts():
                       ("NudfCompositeGrad", _lib.CompositeGrad), ("NudfUpsample", _lib.Upsample),
                       ("NudfPixelBlend", _lib.PixelBlend), ("NudfPixelComposite", _lib.PixelComposite),
                       ("NudfPatchBlend", _lib.PatchBlend), ("NudfPatchWarp", _lib.PatchWarp), ("NudfAdamTensor", _lib.AdamTensor),
-                      ("NudfAdamGroup", _lib.AdamGroup), ("NudfChainStep", _lib.ChainStep), ("NudfRayBatch", _lib.RayBatch)]:
+                      ("NudfAdamGroup", _lib.AdamGroup), ("NudfChainStep", _lib.ChainStep), ("NudfRayBatch", _lib.RayBatch),
+                      ("NudfGemmTNProblem", _lib.GemmTNProblem)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -41,6 +42,51 @@ def test_ctypes_structs_match_header_field_counts():
             for part in decl.split(","):
                 names.append(re.findall(r"[A-Za-z_0-9]+", part)[-1])
         assert names == [f[0] for f in st._fields_], cname
+
+
+def test_weight_gradient_gemm_plan_host_logic():
+    """the planner of nudf_gemm_tn_grouped is host code: workspace sizes (= workgroups x slot) of known groups, one
+    resident wave of <= 512 workgroups, argument errors -- no GPU involved."""
+    import ctypes as C
+    from neuraludf_amd import _lib
+    lib = _lib.lib()
+    SLOT = 128 * 128 + 128
+
+    def group(shapes, M, flags=0, ld=None):
+        g = _lib.GemmTNGroup()
+        g.n_problems, g.M, g.rows_per_block, g.prec = len(shapes), M, 0, 0
+        for i, (NA, NB) in enumerate(shapes):
+            q = g.prob[i]
+            q.A1, q.B1, q.C = 4096, 8192, 16384          # fake 16-byte aligned addresses: never dereferenced here
+            q.lda1, q.ldb1, q.ldc = ld or (NA + 3) // 4 * 4, ld or (NB + 3) // 4 * 4, NB
+            q.NA, q.NB, q.flags = NA, NB, flags
+        return g
+
+    udf = [(256, 40)] + [(256, 256)] * 3 + [(217, 256)] + [(256, 256)] * 3 + [(256, 256), (1, 256)]
+    n = lib.nudf_gemm_tn_grouped_workspace(C.byref(group(udf, 65536)))
+    assert n % SLOT == 0 and 36 * 8 <= n // SLOT <= 512          # 36 tiles, several row chunks each, one resident wave
+    small = lib.nudf_gemm_tn_grouped_workspace(C.byref(group([(3, 5)], 17)))
+    assert small == SLOT                                         # one tile, one chunk (at least 8 k-steps per workgroup)
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(group([], 100))) == 0
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(group([(1024, 1024)] * 2, 100))) < 0     # 128 tiles > 64
+    assert b"64 output tiles" in lib.nudf_last_error()
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(group([(64, 64)], 100, ld=66))) < 0       # ld % 4
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(group([(64, 64)], 100, flags=1 | 4))) < 0  # blocked is fp32-only
+    # 16-bit launches and bf16 operands use whole quadrants and equal costs: still one resident wave
+    g16 = group(udf, 262144, flags=3, ld=256)
+    g16.prec = 2
+    assert 0 < lib.nudf_gemm_tn_grouped_workspace(C.byref(g16)) // SLOT <= 512
+
+
+def test_blocked_layout_helpers_are_inverse():
+    from neuraludf_amd import mlp
+    t = torch.arange(128 * 24, dtype=torch.float32).reshape(128, 24)
+    b = mlp.block(t)
+    assert mlp._isblk(b) and not mlp._isblk(t) and b.shape == t.shape
+    r, c = 77, 13                                                   # the formula of include/nudf.h
+    assert float(b.reshape(-1)[(r // 32) * 32 * 24 + (c // 4) * 128 + (r % 32) * 4 + c % 4]) == float(t[r, c])
+    assert torch.equal(mlp.unblock(b), t)
+    assert mlp.unblock(t) is t
 
 
 def test_no_cpu_fallback():
