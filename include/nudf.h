@@ -272,6 +272,10 @@ int nudf_patch_warp(const NudfPatchWarp* a, void* stream);
 /* loss/patch_metric.py:21-41, 76-84; d_out/d_pred NULL = forward only */
 int nudf_ssim_patch(const float* pred, const float* gt, const float* window, int N, int Npx, float* out,
                     const float* d_out, float* d_pred, void* stream);
+/* every patch error of ColorPatchLoss (loss/loss.py:66-73, loss/patch_metric.py:44-67): type 0 'ssim', 1 'l1', 2 'ssd',
+ * 3 'ncc' (returned as 1 - ncc); pred / gt [N, Npx, 3], window [Npx] (Gaussian, used by ssim / ncc), out [N] */
+int nudf_patch_metric(int type, const float* pred, const float* gt, const float* window, int N, int Npx, float* out,
+                      const float* d_out, float* d_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * ray sampling helpers (models/udf_renderer_blending.py:605-630, 352-357, 164-173, 205)

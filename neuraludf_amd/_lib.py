@@ -178,7 +178,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_set_tn_flags", "nudf_set_tn_debug", "nudf_composite_fwd",
+    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
     "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
@@ -226,6 +226,7 @@ _ARGTYPES = {
     "nudf_pixel_warp": [C.POINTER(PixelBlend), _P, _P, _P],
     "nudf_patch_warp": [C.POINTER(PatchWarp), _P],
     "nudf_ssim_patch": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "nudf_patch_metric": [_I] + [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "nudf_adam_step": [C.POINTER(Adam), _P],
     "nudf_mlp_chain": [C.POINTER(Chain), _P],
     "nudf_pack_frag": [_P, _I, _I, _I, _P, _P],

@@ -612,6 +612,80 @@ __global__ __launch_bounds__(256) void ssim_patch_kernel(const float* __restrict
   if (l == 0) out[ray] = total * 0.5f;
 }
 extern "C" int nudf_ssim_patch(const float* pred, const float* gt, const float* window, int N, int Npx, float* out,
+                               const float* d_out, float* d_pred, void* stream);
+
+// The other patch errors of ColorPatchLoss (loss/loss.py:66-73): TYPE 1 'l1' = sum_px mean_c |pred - gt|, 2 'ssd' =
+// sum_px mean_c (pred - gt)^2, 3 'ncc' = 1 - mean_c NCC_c with the full-patch Gaussian window (loss/patch_metric.py:44-67:
+// NCC_c = sum_px w (a - mu1)(b - mu2) / ((sqrt(var1 + 1e-4) + 1e-8)(sqrt(var2 + 1e-4) + 1e-8)), sum w = 1).
+// One wave per ray, lanes over patch pixels; with d_out / d_pred non-NULL also d out / d pred * d_out.
+template <int TYPE>
+__global__ __launch_bounds__(256) void patch_metric_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                           const float* __restrict__ win, int N, int Npx,
+                                                           float* __restrict__ out, const float* __restrict__ d_out,
+                                                           float* __restrict__ d_pred) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + wave;
+  if (ray >= N) return;
+  const float dout = d_out ? d_out[ray] : 0.f;
+  const size_t base = (size_t)ray * Npx;
+  if (TYPE == 1 || TYPE == 2) {
+    float acc = 0.f;
+    for (int i = l; i < Npx; i += 64)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = pred[(base + i) * 3 + c] - gt[(base + i) * 3 + c];
+        acc += (TYPE == 1) ? fabsf(d) : d * d;
+        if (d_pred)
+          d_pred[(base + i) * 3 + c] = ((TYPE == 1) ? ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) : 2.f * d) * (dout * (1.0f / 3.0f));
+      }
+    acc = wave_sum(acc);
+    if (l == 0) out[ray] = acc * (1.0f / 3.0f);
+    return;
+  }
+  float total = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    float m1 = 0, m2 = 0, e11 = 0, e22 = 0, e12 = 0;
+    for (int i = l; i < Npx; i += 64) {
+      const float w = win[i];
+      const float a = pred[(base + i) * 3 + c], b = gt[(base + i) * 3 + c];
+      m1 += w * a; m2 += w * b; e11 += w * a * a; e22 += w * b * b; e12 += w * a * b;
+    }
+    m1 = wave_sum(m1); m2 = wave_sum(m2); e11 = wave_sum(e11); e22 = wave_sum(e22); e12 = wave_sum(e12);
+    const float s1 = sqrtf(e11 - m1 * m1 + 1e-4f), s2 = sqrtf(e22 - m2 * m2 + 1e-4f);
+    const float d1 = s1 + 1e-8f, d2 = s2 + 1e-8f;
+    const float cov = e12 - m1 * m2;
+    total += cov / (d1 * d2);
+    if (d_pred) {
+      // d cov / d a_i = w_i (b_i - mu2); d s1 / d a_i = w_i (a_i - mu1) / s1
+      const float k1 = 1.0f / (d1 * d2), k2 = cov / (d1 * d1 * d2 * s1);
+      for (int i = l; i < Npx; i += 64) {
+        const float w = win[i];
+        const float a = pred[(base + i) * 3 + c], b = gt[(base + i) * 3 + c];
+        d_pred[(base + i) * 3 + c] = -(w * (b - m2) * k1 - w * (a - m1) * k2) * (dout * (1.0f / 3.0f));
+      }
+    }
+  }
+  if (l == 0) out[ray] = 1.0f - total * (1.0f / 3.0f);
+}
+
+extern "C" int nudf_patch_metric(int type, const float* pred, const float* gt, const float* window, int N, int Npx,
+                                 float* out, const float* d_out, float* d_pred, void* stream) {
+  if (N <= 0) return 0;
+  if (type == 0) return nudf_ssim_patch(pred, gt, window, N, Npx, out, d_out, d_pred, stream);
+  const dim3 grid((N + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (type == 1) hipLaunchKernelGGL(patch_metric_kernel<1>, grid, block, 0, st, pred, gt, window, N, Npx, out, d_out, d_pred);
+  else if (type == 2) hipLaunchKernelGGL(patch_metric_kernel<2>, grid, block, 0, st, pred, gt, window, N, Npx, out, d_out, d_pred);
+  else if (type == 3) hipLaunchKernelGGL(patch_metric_kernel<3>, grid, block, 0, st, pred, gt, window, N, Npx, out, d_out, d_pred);
+  else {
+    nudf_set_error("nudf_patch_metric: type must be 0 (ssim), 1 (l1), 2 (ssd) or 3 (ncc)", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  NUDF_CHECK_LAUNCH("nudf_patch_metric");
+  return 0;
+}
+
+extern "C" int nudf_ssim_patch(const float* pred, const float* gt, const float* window, int N, int Npx, float* out,
                                const float* d_out, float* d_pred, void* stream) {
   if (N <= 0) return 0;
   hipLaunchKernelGGL(ssim_patch_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, gt, window, N, Npx, out,

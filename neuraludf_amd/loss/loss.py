@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import dist as nudf_dist
-from .patch_metric import ssim_patch_error
+from .patch_metric import PATCH_TYPES, patch_error
 
 
 class _L1SumFn(torch.autograd.Function):
@@ -137,18 +137,19 @@ class ColorPixelLoss(nn.Module):
 
 
 class ColorPatchLoss(nn.Module):
-    """loss/loss.py:47-84 ('ssim'): per-ray SSIM error, masked, top-30 % errors trimmed."""
+    """loss/loss.py:47-84: per-ray patch error ('ssim' in every shipped conf; 'l1', 'ncc', 'ssd' as in the reference),
+    masked, top-30 % errors trimmed."""
 
     def __init__(self, type='ssim', h_patch_size=3):
         super().__init__()
-        if type != 'ssim':
-            raise NotImplementedError("patch_loss_type %r: the shipped confs use 'ssim'" % type)
+        if type not in PATCH_TYPES:
+            raise ValueError("patch_loss_type %r: one of %s" % (type, sorted(PATCH_TYPES)))
         self.type = type
         self.h_patch_size = h_patch_size
         self.data_parallel = False
 
     def forward(self, pred, gt, mask, penalize_ratio=0.3):
-        error = ssim_patch_error(pred, gt, self.h_patch_size)            # [N]
+        error = patch_error(pred, gt, self.h_patch_size, self.type)      # [N]
         m = mask.reshape(-1).bool()
         error = error * m.float()
         if self.data_parallel and nudf_dist.world_size() > 1:

@@ -1,6 +1,6 @@
-"""SSIM patch error with a full-patch Gaussian window (reference loss/patch_metric.py:9-41, 69-84):
-one value per ray = sum over the 3 channels of (1 - ssim) / 2.  Runs in the `nudf_ssim_patch` HIP
-kernel (forward + backward w.r.t. the predicted patch)."""
+"""Per-ray patch errors of ColorPatchLoss (reference loss/loss.py:66-73, loss/patch_metric.py:9-67): 'ssim' (sum over
+the 3 channels of (1 - ssim) / 2, full-patch Gaussian window), 'l1', 'ssd' and 'ncc' (1 - mean-channel NCC).  All run
+in the `nudf_patch_metric` HIP kernels (forward + backward w.r.t. the predicted patch)."""
 import math
 
 import torch
@@ -15,15 +15,19 @@ def gaussian_window(h_patch_size, std=1.5):
     return (g[:, None] @ g[None, :]).reshape(-1).contiguous()
 
 
-class _SSIMFn(torch.autograd.Function):
+PATCH_TYPES = {"ssim": 0, "l1": 1, "ssd": 2, "ncc": 3}
+
+
+class _PatchMetricFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, gt, window):
+    def forward(ctx, pred, gt, window, kind):
         pred = pred.detach().contiguous()
         gt = gt.detach().contiguous()
         n, npx, _ = pred.shape
         out = torch.empty(n, device=pred.device)
-        call("nudf_ssim_patch", ptr(pred), ptr(gt), ptr(window), n, npx, ptr(out), None, None)
+        call("nudf_patch_metric", kind, ptr(pred), ptr(gt), ptr(window), n, npx, ptr(out), None, None)
         ctx.save_for_backward(pred, gt, window)
+        ctx.kind = kind
         return out
 
     @staticmethod
@@ -32,16 +36,21 @@ class _SSIMFn(torch.autograd.Function):
         n, npx, _ = pred.shape
         d_pred = torch.empty_like(pred)
         out = torch.empty(n, device=pred.device)
-        call("nudf_ssim_patch", ptr(pred), ptr(gt), ptr(window), n, npx, ptr(out), ptr(d_out.contiguous()), ptr(d_pred))
-        return d_pred, None, None
+        call("nudf_patch_metric", ctx.kind, ptr(pred), ptr(gt), ptr(window), n, npx, ptr(out), ptr(d_out.contiguous()),
+             ptr(d_pred))
+        return d_pred, None, None, None
 
 
 _win_cache = {}
 
 
-def ssim_patch_error(pred, gt, h_patch_size):
-    """pred, gt: [N, Npx, 3] -> [N]."""
+def patch_error(pred, gt, h_patch_size, kind="ssim"):
+    """pred, gt: [N, Npx, 3] -> [N]; kind in PATCH_TYPES."""
     key = (h_patch_size, str(pred.device))
     if key not in _win_cache:
         _win_cache[key] = gaussian_window(h_patch_size).to(pred.device)
-    return _SSIMFn.apply(pred, gt, _win_cache[key])
+    return _PatchMetricFn.apply(pred, gt, _win_cache[key], PATCH_TYPES[kind])
+
+
+def ssim_patch_error(pred, gt, h_patch_size):
+    return patch_error(pred, gt, h_patch_size, "ssim")

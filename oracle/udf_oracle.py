@@ -767,9 +767,32 @@ def ssim_patch_error(pred, gt, hps: int) -> Tensor:
     return val.sum(-1) / 2
 
 
-def patch_loss(pred, gt, mask, hps: int, penalize_ratio: float = 0.3):
-    """ColorPatchLoss 'ssim' (loss/loss.py:56-84)."""
-    err = ssim_patch_error(pred, gt, hps) * mask[:, 0].float()
+def ncc_patch(pred, gt, hps: int) -> Tensor:
+    """NCC.forward/_ncc with a full-patch window (loss/patch_metric.py:44-67, 86-107).  pred, gt [N,Npx,3] -> [N]."""
+    w = ssim_window(hps)[None, :, None]
+    mu1 = (pred * w).sum(1)
+    mu2 = (gt * w).sum(1)
+    sigma1 = torch.sqrt((pred * pred * w).sum(1) - mu1 ** 2 + 1e-4)
+    sigma2 = torch.sqrt((gt * gt * w).sum(1) - mu2 ** 2 + 1e-4)
+    pn = (pred - mu1[:, None]) / (sigma1[:, None] + 1e-8)
+    gn = (gt - mu2[:, None]) / (sigma2[:, None] + 1e-8)
+    return (pn * gn * w).sum(1).mean(-1)
+
+
+def patch_error(pred, gt, hps: int, kind: str = "ssim") -> Tensor:
+    """the four per-ray errors of ColorPatchLoss.forward (loss/loss.py:66-73)."""
+    if kind == "l1":
+        return (pred - gt).abs().mean(-1).sum(-1)
+    if kind == "ssd":
+        return ((pred - gt) ** 2).mean(-1).sum(-1)
+    if kind == "ncc":
+        return 1 - ncc_patch(pred, gt, hps)
+    return ssim_patch_error(pred, gt, hps)
+
+
+def patch_loss(pred, gt, mask, hps: int, penalize_ratio: float = 0.3, kind: str = "ssim"):
+    """ColorPatchLoss (loss/loss.py:56-84)."""
+    err = patch_error(pred, gt, hps, kind) * mask[:, 0].float()
     err, idx = torch.sort(err, descending=True)
     m = mask[idx].clone()
     m[:int(penalize_ratio * m.sum())] = False

@@ -151,6 +151,32 @@ def test_ssim_patch_loss(dev):
         assert rel(pd.grad, pr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("kind", ["l1", "ssd", "ncc"])
+def test_patch_loss_types_l1_ssd_ncc(dev, kind):
+    """the patch-error types no shipped conf uses (loss/loss.py:66-73): nudf_patch_metric against the oracle, values
+    of the trimmed loss and gradients w.r.t. the predicted patches; patch sizes below and above one wave of pixels."""
+    from neuraludf_amd.loss.loss import ColorPatchLoss
+    from neuraludf_amd.loss.patch_metric import patch_error
+    g = torch.Generator().manual_seed(16)
+    for hps in (1, 3, 5):
+        npx = (2 * hps + 1) ** 2
+        N = 53
+        pred = torch.rand(N, npx, 3, generator=g)
+        gt = (pred + 0.1 * torch.randn(N, npx, 3, generator=g)).clamp(0, 1)
+        mask = torch.rand(N, 1, generator=g) > 0.2
+        e_ref = O.patch_error(pred, gt, hps, kind)
+        e = patch_error(pred.to(dev), gt.to(dev), hps, kind)
+        assert rel(e, e_ref) < 1e-5, (kind, hps)
+        pr = pred.clone().requires_grad_(True)
+        O.patch_loss(pr, gt, mask.clone(), hps, kind=kind).backward()
+        pd = pred.to(dev).requires_grad_(True)
+        out = ColorPatchLoss(kind, hps)(pd, gt.to(dev), mask.clone().to(dev))
+        out.backward()
+        assert rel(pd.grad, pr.grad) < 1e-4, (kind, hps)
+    with pytest.raises(ValueError):
+        ColorPatchLoss("huber", 3)
+
+
 def test_render_with_blending_matches_reference_fixture(dev):
     """full render (mix sampling + pixel + patch blending) on the committed reference fixture's inputs;
     compared on the rays whose samples did not take a different quantile bin."""

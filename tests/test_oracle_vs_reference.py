@@ -117,6 +117,31 @@ def test_blending_and_loss_match_reference(ref):
         assert abs(float(l[k]) - float(l_ref[k])) < 1e-5 * max(1.0, abs(float(l_ref[k]))), k
 
 
+@pytest.mark.parametrize("kind", ["l1", "ssd", "ncc", "ssim"])
+def test_patch_loss_types_match_reference(ref, kind):
+    """the oracle's restatement of every ColorPatchLoss error type (loss/loss.py:56-84, loss/patch_metric.py:44-67)
+    against the reference class, values and gradients w.r.t. the predicted patches."""
+    rl = ref[2] if len(ref) > 2 else None
+    import importlib
+    rl = rl or importlib.import_module("loss.loss")
+    g = torch.Generator().manual_seed(17)
+    for hps in (3, 5):
+        npx = (2 * hps + 1) ** 2
+        N = 41
+        pred = torch.rand(N, npx, 3, generator=g)
+        gt = (pred + 0.1 * torch.randn(N, npx, 3, generator=g)).clamp(0, 1)
+        mask = torch.rand(N, 1, generator=g) > 0.2
+        crit = rl.ColorPatchLoss(kind, hps)
+        p1 = pred.clone().requires_grad_(True)
+        l_ref = crit(p1, gt, mask.clone())
+        l_ref.backward()
+        p2 = pred.clone().requires_grad_(True)
+        l = O.patch_loss(p2, gt, mask.clone(), hps, kind=kind)
+        l.backward()
+        assert abs(float(l) - float(l_ref)) < 1e-5 * max(1.0, abs(float(l_ref))), (kind, hps)
+        assert _maxrel(p2.grad, p1.grad) < 1e-4, (kind, hps)
+
+
 RN_CASES = [dict(mode="idr", d_in=12, multires_view=4, squeeze_out=True, blending_cand_views=0),
             dict(mode="no_normal", d_in=6, multires_view=4, squeeze_out=True, blending_cand_views=10),
             dict(mode="no_view_dir", d_in=9, multires_view=0, squeeze_out=False, blending_cand_views=0)]
