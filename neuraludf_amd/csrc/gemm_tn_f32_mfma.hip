@@ -549,6 +549,13 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   const int nkt = (g.M + BK - 1) / BK;                 // k-steps over all points
   int chunks_of[TN_MAX_TILES];
   if (g.rows_per_block > 0) {
+    bool any_blk = false;
+    for (int i = 0; i < g.n_problems; ++i) any_blk = any_blk || (g.prob[i].flags & (NUDF_TN_A_BLK | NUDF_TN_B_BLK));
+    if (any_blk && (g.rows_per_block % 32)) {
+      nudf_set_error("nudf_gemm_tn_grouped: rows_per_block must be a multiple of 32 with blocked operands",
+                     hipErrorInvalidValue);
+      return -1;
+    }
     for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = g.rows_per_block;
   } else {
     // exactly one resident wave of workgroups (2 per CU x 256 CUs; NUDF_TNG_BLOCKS: tuning hook), at least 8 k-steps
