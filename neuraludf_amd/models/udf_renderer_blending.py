@@ -429,7 +429,7 @@ class UDFRendererBlending:
     # ------------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, near, far, cos_anneal_ratio=None, perturb_overwrite=-1, background_rgb=None,
                flip_saturation=0, color_maps=None, w2cs=None, intrinsics=None, query_c2w=None, img_index=None,
-               rays_uv=None):
+               rays_uv=None, z_vals_override=None):
         dev = rays_o.device
         N = len(rays_o)
         if N == 0:
@@ -468,7 +468,13 @@ class UDFRendererBlending:
                  self.n_samples, ptr(z_out))
 
         n_samples = self.n_samples
-        if self.n_importance > 0:
+        if z_vals_override is not None:
+            # not part of the reference signature: evaluate GIVEN inside-sphere sample positions [N, S] (sorted) instead
+            # of running the hierarchical sampling -- what lets a test hold everything downstream of the (discontinuous)
+            # up-sampling against the reference's outputs on the reference's own samples
+            z_vals = z_vals_override.detach().float().contiguous()
+            n_samples = z_vals.shape[1]
+        elif self.n_importance > 0:
             if self.upsampling_type == 'classical':
                 z_vals = self.importance_sample(rays_o, rays_d, z_vals, sample_dist)
             elif self.upsampling_type == 'mix':

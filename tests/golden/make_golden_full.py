@@ -22,7 +22,14 @@ from common import build_modules, perturb_, state_dicts, checksum  # noqa: E402
 from refload import load_reference  # noqa: E402
 from neuraludf_amd import synth  # noqa: E402
 
-KW = dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)
+CASES = {
+    # BASELINE config 2 (the headline): file ref_cfg2_full.npz
+    "cfg2": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0),
+    # the shipped DTU conf's sampling (confs/udf_dtu_blending.conf): 64 + 50 in 5 rounds inside the sphere (114 samples:
+    # ragged 64-sample chunks) + 32 outside samples through the background NeRF: file ref_dtu_shipped_full.npz
+    "dtu_shipped": dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, perturb=1.0),
+}
+KW = CASES["cfg2"]
 N_RAYS = 512
 KEYS = ["z_vals", "color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum",
         "gradient_error", "gradient_error_near_surface", "sparse_error"]
@@ -37,13 +44,15 @@ def loss_of(out, rays):
 
 
 def main():
+    case = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    kw = CASES[case]
     rf, rr, rl = load_reference()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     mods = perturb_(build_modules(rf, seed=0))
     sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
     scene = synth.make_scene("tiny")
     rays = synth.make_rays(scene, 0, N_RAYS, seed=11, margin=6)
-    r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **KW)
+    r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
     t0 = time.time()
     out = r.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7, perturb_overwrite=0,
                    flip_saturation=0.9)
@@ -54,14 +63,14 @@ def main():
     data.update({"out_" + k: out[k].detach().numpy().astype(np.float32) for k in KEYS})
     data["loss"] = np.float64(loss.item())
     n = 0
-    for net in ("udf", "color", "var", "beta"):
+    for net in ("udf", "color", "var", "beta") + (("nerf",) if kw["n_outside"] > 0 else ()):
         for pn, p in mods[net].named_parameters():
             if p.grad is not None:
                 data[f"grad_{net}_{pn}"] = p.grad.numpy()
                 n += p.grad.numel()
     for k, v in sums.items():
         data["wsum_" + k] = np.float64(v)
-    path = os.path.join(HERE, "ref_cfg2_full.npz")
+    path = os.path.join(HERE, "ref_%s_full.npz" % case)
     np.savez_compressed(path, **data)
     print("wrote", path, "%.1f MB" % (os.path.getsize(path) / 1e6), "param-grad floats", n)
 

@@ -104,6 +104,52 @@ def test_cfg2_render_core_and_all_parameter_gradients_vs_reference(dev, setup, t
     print(f"cfg2 full size (tile {tile}): {n} parameter gradients vs the reference, worst {worst[0]} {worst[1]:.2e}")
 
 
+def test_shipped_dtu_sampling_with_background_nerf_vs_reference(dev):
+    """the shipped DTU conf's sampling at full size -- 512 rays x (64 + 50 in 5 rounds) inside the sphere (114 samples:
+    ragged 64-sample chunks in the composite) + 32 outside samples through the background NeRF -- on the reference's own
+    inside sample positions (fixture tests/golden/ref_dtu_shipped_full.npz, written by make_golden_full.py dtu_shipped
+    from the reference code): every output <= 1e-4, every one of the 1 291 482 parameter-gradient floats (UDF, colour,
+    variance, beta AND NeRF) <= 1e-3."""
+    from neuraludf_amd.models import fields
+    from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
+    fx = dict(np.load(os.path.join(HERE, "golden", "ref_dtu_shipped_full.npz")))
+    kw = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, perturb=1.0)
+    mods = perturb_(build_modules(fields, seed=0))
+    for k, v in state_dicts(mods).items():
+        assert abs(checksum(v) - float(fx["wsum_" + k])) < 1e-6 * max(1.0, abs(float(fx["wsum_" + k]))), k
+    for m in mods.values():
+        m.to(dev)
+    rend = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
+    rays = {k[4:]: torch.from_numpy(v).to(dev) for k, v in fx.items() if k.startswith("ray_")}
+    z_ref = torch.from_numpy(fx["out_z_vals"]).to(dev)
+    assert z_ref.shape == (512, 114)
+    out = rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7, perturb_overwrite=0,
+                      flip_saturation=0.9, z_vals_override=z_ref)
+    loss = _loss(out, rays["true_rgb"])
+    loss.backward()
+    torch.cuda.synchronize()
+    for k in ["color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum", "gradient_error",
+              "gradient_error_near_surface", "sparse_error"]:
+        assert rel(out[k], fx["out_" + k]) < (2e-3 if k == "sparse_error" else VTOL), k
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
+    worst, n, floats = ("", 0.0), 0, 0
+    for net in ("udf", "color", "var", "beta", "nerf"):
+        for pn, p in mods[net].named_parameters():
+            key = f"grad_{net}_{pn}"
+            if key not in fx:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, key
+                continue
+            assert p.grad is not None, key
+            r = rel(p.grad, fx[key])
+            n += 1
+            floats += p.grad.numel()
+            if r > worst[1]:
+                worst = (key, r)
+            assert r < GTOL, (key, r)
+    assert n >= 80 and floats == 1291482
+    print(f"shipped DTU sampling, full size: {n} parameter gradients ({floats} floats) vs the reference, worst {worst[0]} {worst[1]:.2e}")
+
+
 def test_cfg2_end_to_end_matching_rays_and_first_divergence(dev, setup):
     fx, mods, sds, rend, rays = setup
     N = 512
