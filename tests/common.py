@@ -72,3 +72,16 @@ def checksum(sd):
     for i, (k, v) in enumerate(sorted(sd.items())):
         s += float((v.double() * ((i % 7) + 1)).sum())
     return s
+
+
+def smooth_images(v, h, w, seed=0):
+    """band-limited images: bilinear taps then differ by O(1e-6) for sub-1e-4-pixel coordinate differences
+    (i.i.d. noise images would turn fp32 coordinate rounding into 1e-4 colour noise in BOTH implementations)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+    imgs = torch.zeros(v, 3, h, w)
+    for i in range(v):
+        for c in range(3):
+            f = torch.rand(4, generator=g) * 6 + 1
+            imgs[i, c] = 0.5 + 0.25 * torch.sin(f[0] * xx + f[1] * yy + i) + 0.2 * torch.cos(f[2] * xx - f[3] * yy + c)
+    return imgs

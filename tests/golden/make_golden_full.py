@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from common import build_modules, perturb_, state_dicts, checksum  # noqa: E402
+from common import build_modules, perturb_, state_dicts, checksum, smooth_images  # noqa: E402
 from refload import load_reference  # noqa: E402
 from neuraludf_amd import synth  # noqa: E402
 
@@ -28,6 +28,10 @@ CASES = {
     # the shipped DTU conf's sampling (confs/udf_dtu_blending.conf): 64 + 50 in 5 rounds inside the sphere (114 samples:
     # ragged 64-sample chunks) + 32 outside samples through the background NeRF: file ref_dtu_shipped_full.npz
     "dtu_shipped": dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, perturb=1.0),
+    # BASELINE config 3's sampling and blending at 512 rays: mix up-sampling (64 + 64 in 3 rounds), normalised-gradient
+    # cosines, pixel + patch blending over 8 source views with 7 x 7 patches, full ColorLoss: file ref_cfg3_blend_full.npz
+    "cfg3_blend": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
+                       use_norm_grad_for_cosine=True, h_patch_size=3),
 }
 KW = CASES["cfg2"]
 N_RAYS = 512
@@ -54,13 +58,34 @@ def main():
     rays = synth.make_rays(scene, 0, N_RAYS, seed=11, margin=6)
     r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
     t0 = time.time()
+    bkw, keys = {}, list(KEYS)
+    blend = "h_patch_size" in kw
+    if blend:
+        src = synth.make_source_views(scene, 0, 8)
+        src["color_maps"] = smooth_images(8, scene.H, scene.W)       # band-limited: taps insensitive to 1e-4-pixel noise
+        bkw = dict(color_maps=src["color_maps"], w2cs=src["w2cs"], intrinsics=src["intrinsics"],
+                   query_c2w=src["query_c2w"], rays_uv=rays["rays_uv"].clone())
+        keys += ["color_pixel", "patch_colors", "patch_mask"]
     out = r.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7, perturb_overwrite=0,
-                   flip_saturation=0.9)
+                   flip_saturation=0.9, **bkw)
     loss = loss_of(out, rays)
+    extra = {}
+    if blend:
+        g = torch.Generator().manual_seed(3)
+        gt_patch = torch.rand(N_RAYS, 49, 3, generator=g)
+        pmask = (out["patch_mask"].detach() > 0.3).reshape(-1, 1)
+        crit = rl.ColorLoss(color_base_weight=1.0, color_weight=1.0, color_pixel_weight=0.5, color_patch_weight=0.2,
+                            pixel_loss_type="l1", patch_loss_type="ssim", h_patch_size=3)
+        cl = crit(out["color_base"], out["color"], rays["true_rgb"], out["color_pixel"], rays["mask"],
+                  out["patch_colors"], gt_patch, pmask.clone())
+        loss = loss + cl["loss"]
+        extra = {"gt_patch": gt_patch.numpy(), "pmask": pmask.numpy()}
+        extra.update({"closs_" + k: np.float64(float(v)) for k, v in cl.items()})
     loss.backward()
     print("reference fwd+bwd %.1f s, loss %.6f" % (time.time() - t0, loss.item()))
     data = {"ray_" + k: v.numpy() for k, v in rays.items()}
-    data.update({"out_" + k: out[k].detach().numpy().astype(np.float32) for k in KEYS})
+    data.update({"out_" + k: out[k].detach().numpy().astype(np.float32) for k in keys})
+    data.update(extra)
     data["loss"] = np.float64(loss.item())
     n = 0
     for net in ("udf", "color", "var", "beta") + (("nerf",) if kw["n_outside"] > 0 else ()):
