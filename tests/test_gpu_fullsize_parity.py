@@ -219,7 +219,7 @@ def test_cfg2_end_to_end_matching_rays_and_first_divergence(dev, setup):
     good = zerr < 1e-4
     frac = float(good.float().mean())
     for k in ["color", "color_base", "depth", "weight_sum"]:
-        assert rel(out[k][good.to(dev)], torch.from_numpy(fx["out_" + k])[good]) < 5e-4, k
+        assert rel(out[k][good.to(dev)], torch.from_numpy(fx["out_" + k])[good]) < 1e-4, k
     mse = float(((out["color"].cpu() - torch.from_numpy(fx["out_color"])) ** 2).mean())
     psnr = 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-20))
 

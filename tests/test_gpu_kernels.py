@@ -516,7 +516,7 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
     # under 1e-6 relative noise); those rays are compared statistically (PSNR)
     assert good.float().mean() > 0.7
     for k in ["color", "color_base", "depth", "weight_sum"]:
-        assert rel(out[k][good.to(dev)], ref[k][good]) < 5e-4, k
+        assert rel(out[k][good.to(dev)], ref[k][good]) < 1e-4, k
     mse = ((out["color"].cpu() - ref["color"]) ** 2).mean()
     psnr = 20.0 * math.log10(1.0 / math.sqrt(float(mse) + 1e-20))
     assert psnr > 70.0, psnr
