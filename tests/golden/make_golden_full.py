@@ -30,6 +30,9 @@ CASES = {
     "dtu_shipped": dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, perturb=1.0),
     # BASELINE config 3's sampling and blending at 512 rays: mix up-sampling (64 + 64 in 3 rounds), normalised-gradient
     # cosines, pixel + patch blending over 8 source views with 7 x 7 patches, full ColorLoss: file ref_cfg3_blend_full.npz
+    # BASELINE config 5's per-GPU shape in fp32: 1024 rays x (128 + 128 in 4 rounds) = 262 144 points per render_core (four
+    # rounds of workgroups per chain launch, M = 262 144 in the weight-gradient GEMMs): file ref_cfg5_shape_full.npz
+    "cfg5_shape": dict(n_samples=128, n_importance=128, n_outside=0, up_sample_steps=4, perturb=1.0),
     "cfg3_blend": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
                        use_norm_grad_for_cosine=True, h_patch_size=3),
 }
@@ -55,7 +58,8 @@ def main():
     mods = perturb_(build_modules(rf, seed=0))
     sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
     scene = synth.make_scene("tiny")
-    rays = synth.make_rays(scene, 0, N_RAYS, seed=11, margin=6)
+    n_rays = 1024 if case == "cfg5_shape" else N_RAYS
+    rays = synth.make_rays(scene, 0, n_rays, seed=11, margin=6)
     r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
     t0 = time.time()
     bkw, keys = {}, list(KEYS)
@@ -72,7 +76,7 @@ def main():
     extra = {}
     if blend:
         g = torch.Generator().manual_seed(3)
-        gt_patch = torch.rand(N_RAYS, 49, 3, generator=g)
+        gt_patch = torch.rand(n_rays, 49, 3, generator=g)
         pmask = (out["patch_mask"].detach() > 0.3).reshape(-1, 1)
         crit = rl.ColorLoss(color_base_weight=1.0, color_weight=1.0, color_pixel_weight=0.5, color_patch_weight=0.2,
                             pixel_loss_type="l1", patch_loss_type="ssim", h_patch_size=3)
@@ -84,6 +88,9 @@ def main():
     loss.backward()
     print("reference fwd+bwd %.1f s, loss %.6f" % (time.time() - t0, loss.item()))
     data = {"ray_" + k: v.numpy() for k, v in rays.items()}
+    if case == "cfg5_shape":      # keep the file small: per-ray outputs, sample positions and weights only
+        keys = ["z_vals", "color", "color_base", "weights", "depth", "weight_sum", "gradient_error",
+                "gradient_error_near_surface", "sparse_error"]
     data.update({"out_" + k: out[k].detach().numpy().astype(np.float32) for k in keys})
     data.update(extra)
     data["loss"] = np.float64(loss.item())
