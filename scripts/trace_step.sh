@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof6 -o b -- python $GRAFT_REPO_ROOT/bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 2 --warmup 1 --no-cpu-baseline --no-forward-only --no-roofline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof6 -o b -- python $GRAFT_REPO_ROOT/bench.py ${TRACE_ARGS:---workload dtu_scan24_1024x256 --precision mixed16} --steps 2 --warmup 1 --no-cpu-baseline --no-forward-only --no-roofline > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/prof6/**/*kernel_trace.csv", recursive=True)[0]
