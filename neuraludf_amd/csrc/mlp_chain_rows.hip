@@ -670,6 +670,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
   if (dbg && lane == 0) {
     dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     dbg[1] = __builtin_amdgcn_s_memtime();
+    dbg[62] = wall_clock64();      // 100 MHz reference: the shader clock the sweep ran at
   }
 
   for (int si = 0; si < p.n_steps; ++si) {
@@ -774,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
     __syncthreads();
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
   }
+  if (dbg && lane == 0) dbg[63] = wall_clock64();
 }
 
 int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st) {

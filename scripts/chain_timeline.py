@@ -48,10 +48,11 @@ def run():
     eng.backward(x, st, DA, d_udf, d_feat, ceng.cin_ld, d_g)
 
 
-run()
-torch.cuda.synchronize()
+WARM = int(os.environ.get("TIMELINE_WARM", "12"))     # back-to-back sweeps before the stamped one: steady-state clocks
+for _ in range(WARM):
+    run()
 mlp.CHAIN_DEBUG = torch.zeros(1, dtype=torch.int64, device=dev)
-run()
+run()                                                   # enqueued behind the warm-up without a host sync in between
 torch.cuda.synchronize()
 mlp.CHAIN_DEBUG = None
 from neuraludf_amd._lib import CH as _CH

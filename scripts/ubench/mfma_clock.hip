@@ -1,6 +1,7 @@
 // Which companion work lowers the shader clock under an fp32 MFMA stream (gfx950)?  512-thread workgroups, one per CU:
 // waves 0-3 run v_mfma_f32_32x32x2_f32 back to back, waves 4-7 (same SIMDs) run a companion stream:
-//   0 nothing, 1 plain fma, 2 exp2, 3 LDS reads (ds_read_b128), 4 HBM streaming loads (global_load_dwordx4 over 1 GB)
+//   0 nothing, 1 plain fma, 2 exp2, 3 LDS reads (ds_read_b128), 4 HBM streaming loads (global_load_dwordx4 over 1 GB),
+//   5 L2-resident streaming loads (a 256 KB buffer re-read by every CU, like the chains' weight fragments), 6 = 3 + 5 + 1
 // The clock is (s_memtime ticks) / (wall_clock64 ticks at 100 MHz) of the MFMA waves.
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_clock mfma_clock.hip
 #include <hip/hip_runtime.h>
@@ -54,11 +55,20 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* stam
       } else if (KIND == 3) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) accv += lds[(l + 37 * r + i) % (150 * 64)];
-      } else {
+      } else if (KIND == 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           accv += big[gi % big_n];
           gi += (size_t)256 * 256;
+        }
+      } else {   // 5, 6: 256 KB = 16384 float4, every CU reads the same buffer
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accv += big[(size_t)((l + 256 * (4 * i + r)) & 16383)];
+        if (KIND == 6) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accv += lds[(l + 37 * r + i) % (150 * 64)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(v[r], 1.0001f, 0.5f);
         }
       }
     }
@@ -98,5 +108,7 @@ int main() {
   run<2>("MFMA + exp2 wave", out, stamps, big, big_n, 60000);
   run<3>("MFMA + LDS read wave", out, stamps, big, big_n, 100000);
   run<4>("MFMA + HBM streaming wave", out, stamps, big, big_n, 40000);
+  run<5>("MFMA + L2 streaming wave", out, stamps, big, big_n, 120000);
+  run<6>("MFMA + L2 + LDS + fma wave", out, stamps, big, big_n, 80000);
   return 0;
 }
