@@ -42,8 +42,20 @@ def launch(self):
 mlp.ChainBuilder.launch = launch
 
 
+S = 128
+rays_d = torch.nn.functional.normalize(torch.randn(P // S, 3, generator=g), dim=-1).to(dev)
+d_cb = torch.randn(P, 3, generator=g).to(dev)
+d_cc = torch.randn(P, 3, generator=g).to(dev)
+COLOUR = os.environ.get("TIMELINE_COLOUR", "0") == "1"
+
+
 def run():
     st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
+    if COLOUR:      # the colour net's forward (both branches) and its two reverse sweeps instead of the UDF backward
+        cb, cc, logits, cst = ceng.forward(st["feat"], rays_d, S, P)
+        d_lg = torch.zeros_like(logits) if logits is not None else None
+        ceng.backward(cst, cb, cc, d_cb, d_cc, d_lg)
+        return
     gr, DA = eng.gradient(x, st)
     eng.backward(x, st, DA, d_udf, d_feat, ceng.cin_ld, d_g)
 
