@@ -33,6 +33,8 @@
 #define TNF_ATOMICS 8
 #define TNF_UNIFORM_CHUNKS 16
 #define TNF_NO_QUADRANTS 32
+#define TNF_NO_XCD_MAP 64           // plain tile-major blockIdx (A/B of the XCD-aware order)
+#define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -44,6 +46,8 @@ struct TnTile {
   short layout;         // 0: wave w <-> column sub-tile w, n live row sub-tiles; 1: wave w <-> row sub-tile w, n column
                         // ones; 2 (full tiles): waves 2 x 2, each a 64 x 64 quadrant = 2 x 2 sub-tiles (n = 4)
   short n;
+  short gfirst;         // tile group = consecutive tiles of one problem with the same row chunks: its first tile ...
+  short gn;             // ... and its size (the group's workgroups are one contiguous range of blockIdx)
   short pad;
 };
 struct TnPlan {
@@ -68,11 +72,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   float* Bs = smem + 2 * T_TILE;
 
   const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
+  const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  // blockIdx -> (tile, row chunk).  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2:
+  // the tiles of one problem that read the same rows (same chunk; tiles of a tile row share the A panel, of a tile column
+  // the B panel) are put on the SAME XCD -- within a tile group, blockIdx = first + (chunk / 8) * 8 T + tile * 8 + chunk % 8
+  // (T tiles; the last chunk % 8 columns are narrower).  Workspace slots stay tile-major (tile.blk_start + chunk).
   int t = 0;
   while (t + 1 < g.n_tiles && g.tile[t + 1].blk_start <= (int)blockIdx.x) ++t;
+  int chunk = blockIdx.x - g.tile[t].blk_start;
+  if (!(g.flags & TNF_NO_XCD_MAP) && g.tile[t].gn > 1) {
+    const int gf = g.tile[t].gfirst, T = g.tile[gf].gn;
+    const int C = g.tile[gf + 1].blk_start - g.tile[gf].blk_start;
+    const int o = blockIdx.x - g.tile[gf].blk_start;
+    const int c_hi = o / (8 * T), rem = o - c_hi * 8 * T;
+    const int w = (c_hi < (C >> 3)) ? 8 : (C & 7);
+    const int k = rem / w;
+    t = gf + k;
+    chunk = c_hi * 8 + (rem - k * w);
+  }
   const TnTile tl = g.tile[t];
   const NudfGemmTNProblem& q = g.prob[tl.prob];
-  const int chunk = blockIdx.x - tl.blk_start;
+  const int slot_id = tl.blk_start + chunk;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -315,6 +335,121 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
   using I4 = std::integral_constant<int, 4>;
+  // The loop of a FULL tile with fp32 operands and fp32 MFMAs -- 85 % of the step's weight-gradient work -- with every
+  // wave's instruction stream arranged so that it never issues a long run of non-MFMA instructions
+  // (scripts/ubench/mfma_pair.hip: the 64 operand reads in blocks of 16, the 8 LDS writes + wait in front of the barrier
+  // and the 8 global loads at the top cost a wave pair 22 % of the matrix pipe; interleaved, 12 %):
+  //   groups 0 .. 2 of 16 MFMAs, one LDS operand read (of the next group) behind every MFMA; the LDS writes of the NEXT
+  //   k-step's operands spread over group 2; the barrier; group 3 -- its operands are in registers -- with the next
+  //   k-step's first reads and the global loads of the k-step AFTER the next spread over it.
+  // The steady-state body is branch-free (full k-steps only; the bias sums are always accumulated, one accumulator per
+  // pass); the last iterations run the same pipeline through the generic load / store helpers.
+  auto kloop_full = [&]() {
+    const float* as0 = As + (lane >> 5) * LDT + (wave >> 1) * 64 + (lane & 31);
+    const float* bs0 = Bs + (lane >> 5) * LDT + (wave & 1) * 64 + (lane & 31);
+    float av[2][4][2], bv[2][4][2];
+    const char* pa = oa.p;                       // this thread's operand rows of the k-step to LOAD next
+    const char* pb = ob.p;
+    float* const da0 = As + oa.tk * LDT + oa.tc;
+    float* const db0 = Bs + ob.tk * LDT + ob.tc;
+    auto gload = [&](int kt) {
+      const bool full = kt < nfull;
+      load_op(oa, std::false_type{}, ra, kt, full);
+      load_op(ob, std::false_type{}, rb, kt, full);
+      ld_rows = full ? BK : mend - (mbeg + kt * BK);
+    };
+    auto sstore = [&](int buf) {
+      store_op(oa, std::false_type{}, ra, As + buf * T_TILE, do_bias);
+      store_op(ob, std::false_type{}, rb, Bs + buf * T_TILE, false);
+    };
+    auto group = [&](auto C, auto FAST, int cur) {
+      constexpr int c = decltype(C)::value;
+      constexpr bool fast = decltype(FAST)::value;
+      constexpr int ns = (c + 1) & 1, nc = (c + 1) & 3;
+      const float* as = as0 + (c == 3 ? cur ^ 1 : cur) * T_TILE;
+      const float* bs = bs0 + (c == 3 ? cur ^ 1 : cur) * T_TILE;
+      float* da = da0 + (cur ^ 1) * T_TILE;
+      float* db = db0 + (cur ^ 1) * T_TILE;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c & 1][qd][i], bv[c & 1][qd][j], acc[i * 2 + j], 0, 0, 0);
+            const int r = j * 2 + i, kk = nc * 4 + qd;
+            if (r < 2) av[ns][qd][r] = as[(2 * kk) * LDT + 32 * r];
+            else bv[ns][qd][r - 2] = bs[(2 * kk) * LDT + 32 * (r - 2)];
+            const int m = qd * 4 + r;
+            if (fast && c == 2 && (m & 1)) {
+              const int ps = (m >> 1) & 3;
+              if (m < 8) {
+                *reinterpret_cast<f32x4*>(da + ps * oa.lds_pass) = ra[ps];
+                if (ps == 0) bacc += ra[0]; else if (ps == 1) bacc2 += ra[1]; else if (ps == 2) bacc3 += ra[2]; else bacc4 += ra[3];
+              } else {
+                *reinterpret_cast<f32x4*>(db + ps * ob.lds_pass) = rb[ps];
+              }
+            }
+            if (fast && c == 3 && (m & 1)) {
+              const int ps = (m >> 1) & 3;
+              if (m < 8) ra[ps] = *reinterpret_cast<const f32x4*>(pa + oa.poff[ps]);
+              else rb[ps] = *reinterpret_cast<const f32x4*>(pb + ob.poff[ps]);
+            }
+          }
+      if constexpr (fast) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (c == 2 && (m & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (c == 3 && (m & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using F = std::true_type;
+    using S = std::false_type;
+    if (nk > 1) gload(1);   // run_kind has put k-step 0 into LDS buffer 0 (and passed the barrier behind it)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[0][qd][i] = as0[(2 * qd) * LDT + 32 * i];
+        bv[0][qd][i] = bs0[(2 * qd) * LDT + 32 * i];
+      }
+    int kt = 0;
+    if (2 < nfull) {
+      pa += 2 * oa.stepb;
+      pb += 2 * ob.stepb;
+      for (; kt + 2 < nfull; ++kt) {   // k-steps kt + 1 (stored) and kt + 2 (loaded) are full
+        const int cur = kt & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        group(I0{}, F{}, cur);
+        group(I1{}, F{}, cur);
+        group(I2{}, F{}, cur);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        group(I3{}, F{}, cur);
+        pa += oa.stepb;
+        pb += ob.stepb;
+      }
+      ld_rows = BK;
+    }
+    for (; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      group(I0{}, S{}, cur);
+      group(I1{}, S{}, cur);
+      group(I2{}, S{}, cur);
+      if (kt + 1 < nk) sstore(cur ^ 1);
+      __syncthreads();
+      if (kt + 2 < nk) gload(kt + 2);
+      group(I3{}, S{}, cur);
+    }
+    if (!oa.blk) {   // row-major A: the four passes are rows of the same columns
+      bacc = (bacc + bacc2) + (bacc3 + bacc4);
+      bacc2 = bacc3 = bacc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
   // Everything from the first operand load to the last k-step, for one (A kind, B kind).  The k-loop inside is
   // instantiated ONCE PER (sub-tile count, layout, precision), chosen outside the loop: a shape switch inside it made
   // the compiler copy all 64 accumulator registers (behind an MFMA drain) on every k-step.  bf16 operands and the 16-bit
@@ -355,6 +490,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
       else kloop(N, LAY, I0{});
     };
     if (n_w == 0) { by_prec(I0{}, I0{}); return; }
+    if constexpr (!kA && !kB) {
+      if (tl.layout == 2 && g.prec == 0 && !(g.flags & TNF_NO_INTERLEAVE)) { kloop_full(); return; }
+    }
     if (tl.layout == 2) { by_prec(I4{}, I2{}); return; }
     if constexpr (!kA && !kB) {
       if (tl.layout == 0) {
@@ -376,10 +514,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
 
   if (g.dbg && tid == 0) {
     long long* d = g.dbg + 4 * (size_t)blockIdx.x;
-    d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = tl.layout * 16 + tl.n; d[3] = nk;
+    d[0] = t_begin; d[1] = (long long)wall_clock64();
+    // tile kind | CU identity (HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]) -> which workgroups shared a CU
+    d[2] = (tl.layout * 16 + tl.n) | ((long long)(__builtin_amdgcn_s_getreg(63492) & 0xff00) << 8) |
+           ((long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 32);
+    d[3] = nk | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 16);   // shader-clock ticks of the same span
   }
   if (g.flags & TNF_NO_EPILOGUE) return;
-  float* slot = g.ws ? g.ws + (size_t)blockIdx.x * TN_WS_TILE : nullptr;
+  float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
   if (do_bias) {   // the loop's last barrier has passed: the operand tiles are free
     int ngroups;
     if (oa.blk) {   // thread = (row of the block, quad): 32 partial rows x 128 columns
@@ -594,6 +736,13 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
     blocks += (g.M + pl.tile[t].rows_per_block - 1) / pl.tile[t].rows_per_block;
   }
   pl.tile[nt].blk_start = blocks;
+  pl.tile[nt].gfirst = (short)nt; pl.tile[nt].gn = 1;
+  for (int t = 0; t < nt;) {   // tile groups: same problem, same chunking
+    int e = t + 1;
+    while (e < nt && pl.tile[e].prob == pl.tile[t].prob && pl.tile[e].rows_per_block == pl.tile[t].rows_per_block) ++e;
+    for (int k = t; k < e; ++k) { pl.tile[k].gfirst = (short)t; pl.tile[k].gn = (short)(e - t); }
+    t = e;
+  }
   return blocks;
 }
 
