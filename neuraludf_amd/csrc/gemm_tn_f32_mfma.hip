@@ -35,6 +35,7 @@
 #define TNF_NO_QUADRANTS 32
 #define TNF_NO_XCD_MAP 64           // plain tile-major blockIdx (A/B of the XCD-aware order)
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
+#define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -66,20 +67,14 @@ __device__ __forceinline__ int tn_jsub(int layout, int wave, int s) {
   return layout == 0 ? wave : layout == 1 ? s : (wave & 1) * 2 + (s & 1);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
-  float* As = smem;
-  float* Bs = smem + 2 * T_TILE;
-
-  const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
-  const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  // blockIdx -> (tile, row chunk).  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2:
-  // the tiles of one problem that read the same rows (same chunk; tiles of a tile row share the A panel, of a tile column
-  // the B panel) are put on the SAME XCD -- within a tile group, blockIdx = first + (chunk / 8) * 8 T + tile * 8 + chunk % 8
-  // (T tiles; the last chunk % 8 columns are narrower).  Workspace slots stay tile-major (tile.blk_start + chunk).
-  int t = 0;
+// blockIdx -> (tile, row chunk).  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2:
+// the tiles of one problem that read the same rows (same chunk; tiles of a tile row share the A panel, of a tile column
+// the B panel) are put on the SAME XCD -- within a tile group, blockIdx = first + (chunk / 8) * 8 T + tile * 8 + chunk % 8
+// (T tiles; the last chunk % 8 columns are narrower).  Workspace slots stay tile-major (tile.blk_start + chunk).
+__device__ __forceinline__ void tn_decode(const TnPlan& g, int& t, int& chunk) {
+  t = 0;
   while (t + 1 < g.n_tiles && g.tile[t + 1].blk_start <= (int)blockIdx.x) ++t;
-  int chunk = blockIdx.x - g.tile[t].blk_start;
+  chunk = blockIdx.x - g.tile[t].blk_start;
   if (!(g.flags & TNF_NO_XCD_MAP) && g.tile[t].gn > 1) {
     const int gf = g.tile[t].gfirst, T = g.tile[gf].gn;
     const int C = g.tile[gf + 1].blk_start - g.tile[gf].blk_start;
@@ -90,6 +85,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
     t = gf + k;
     chunk = c_hi * 8 + (rem - k * w);
   }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
+  float* As = smem;
+  float* Bs = smem + 2 * T_TILE;
+
+  const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
+  const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  int t, chunk;
+  tn_decode(g, t, chunk);
   const TnTile tl = g.tile[t];
   const NudfGemmTNProblem& q = g.prob[tl.prob];
   const int slot_id = tl.blk_start + chunk;
@@ -605,6 +611,226 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnPlan g) {
     if (row + k < q.NA) q.C[(size_t)(row + k) * q.ldc + col] += sum[k];
 }
 
+
+// =======================================================================================================
+// 16-bit MFMA mode (NudfGemmTNGroup.prec != 0, config 5): the same 128 x 128 tiles, quadrant layout, workspace slots
+// and reduce, but k-steps of 64 rows and an LDS image that is ALREADY the MFMA operand: one dword = the bf16 values of
+// rows (2 p, 2 p + 1) of one column, 32 such k-pair rows of LD16 dwords per operand and buffer.  Lane (i, h) of
+// v_mfma_f32_32x32x16_bf16 needs rows 16 kk + 8 h .. + 7 of column i = 4 dwords a k-pair row apart: 4 ds_read_b32 (two
+// ds_read2_b32) per sub-tile and MFMA, no conversion in the loop.  The generic kernel's 16-bit loop read the fp32 image
+// instead: 8 ds_read_b32 + 4 v_cvt_pk per sub-tile and MFMA, and that -- not HBM -- bound it (2.07 ms at 1024 x 256).
+// Rounding is unchanged: fp32 operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on the way INTO the image instead of
+// out of it, bf16 operands are copied bit for bit, the MFMAs run over the same rows in the same order: bit-identical C.
+// Thread (r = tid / 16, c = 8 (tid % 16)) stages k-pairs r and r + 16, 8 columns each: 2 x 2 rows of 16 B (bf16 operand)
+// or 32 B (fp32 operand).
+// =======================================================================================================
+#define BK16 64
+#define LD16 132
+#define T16 (32 * LD16)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <bool H> struct Tn16Stage { f32x4 v[2][2][H ? 1 : 2]; };   // [pass][row of the pair][16-byte piece]
+
+__global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
+  __shared__ __attribute__((aligned(16))) unsigned smem[4 * T16];
+  unsigned* As = smem;
+  unsigned* Bs = smem + 2 * T16;
+
+  const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
+  const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  int t, chunk;
+  tn_decode(g, t, chunk);
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const int slot_id = tl.blk_start + chunk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const int mbeg = chunk * tl.rows_per_block;
+  const int mend = min(mbeg + tl.rows_per_block, g.M);
+  const int nk = (mend - mbeg + BK16 - 1) / BK16;
+  const int pr = tid >> 4, pc = (tid & 15) * 8;
+  const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
+  f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+
+  auto run_kind = [&](auto KA, auto KB) {
+    constexpr bool kA = decltype(KA)::value, kB = decltype(KB)::value;
+    // this thread's 8 columns of an operand, clamped into the buffer (columns past NA / NB only feed outputs that are
+    // never stored); rows are clamped per load
+    // (a bf16 operand's leading dimension is a multiple of 8, an fp32 one's of 4: the two 4-column pieces of an fp32
+    // row are clamped separately)
+    const int ca = i0 + pc, cb = j0 + pc;
+    const char* pa = reinterpret_cast<const char*>(q.A1) + (size_t)min(ca, q.lda1 - (kA ? 8 : 4)) * (kA ? 2 : 4);
+    const char* pb = reinterpret_cast<const char*>(q.B1) + (size_t)min(cb, q.ldb1 - (kB ? 8 : 4)) * (kB ? 2 : 4);
+    const int pa2 = (min(ca + 4, q.lda1 - 4) - min(ca, q.lda1 - 4)) * 4;   // byte offset of an fp32 row's second piece
+    const int pb2 = (min(cb + 4, q.ldb1 - 4) - min(cb, q.ldb1 - 4)) * 4;
+    const size_t rowa = (size_t)q.lda1 * (kA ? 2 : 4), rowb = (size_t)q.ldb1 * (kB ? 2 : 4);
+    Tn16Stage<kA> sa;
+    Tn16Stage<kB> sb;
+    auto load = [&](auto Hc, const char* p, int p2, size_t rowbytes, auto& st, int kt) {
+      constexpr bool h = decltype(Hc)::value;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int row = min(mbeg + kt * BK16 + 2 * (pr + 16 * ps) + rr, g.M - 1);
+          const char* src = p + (size_t)row * rowbytes;
+          st.v[ps][rr][0] = *reinterpret_cast<const f32x4*>(src);
+          if constexpr (!h) st.v[ps][rr][1] = *reinterpret_cast<const f32x4*>(src + p2);
+        }
+    };
+    auto widen = [](const f32x4& raw, f32x4& lo, f32x4& hi) {
+      const uint4 u = __builtin_bit_cast(uint4, raw);
+      lo = f32x4{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+      hi = f32x4{__builtin_bit_cast(float, u.z << 16), __builtin_bit_cast(float, u.z & 0xffff0000u),
+                 __builtin_bit_cast(float, u.w << 16), __builtin_bit_cast(float, u.w & 0xffff0000u)};
+    };
+    auto pack2 = [](float a, float b) {
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    };
+    auto store = [&](auto Hc, const auto& st, int kt, unsigned* tile, bool bias) {
+      constexpr bool h = decltype(Hc)::value;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int k0 = mbeg + kt * BK16 + 2 * (pr + 16 * ps);
+        const bool v0 = k0 < mend, v1 = k0 + 1 < mend;
+        u32x4 olo, ohi;
+        if constexpr (h) {
+          const f32x4 r0 = v0 ? st.v[ps][0][0] : z, r1 = v1 ? st.v[ps][1][0] : z;
+          const uint4 a = __builtin_bit_cast(uint4, r0), b = __builtin_bit_cast(uint4, r1);
+          olo = u32x4{(a.x & 0xffffu) | (b.x << 16), (a.x >> 16) | (b.x & 0xffff0000u),
+                      (a.y & 0xffffu) | (b.y << 16), (a.y >> 16) | (b.y & 0xffff0000u)};
+          ohi = u32x4{(a.z & 0xffffu) | (b.z << 16), (a.z >> 16) | (b.z & 0xffff0000u),
+                      (a.w & 0xffffu) | (b.w << 16), (a.w >> 16) | (b.w & 0xffff0000u)};
+          if (bias) {
+            f32x4 l0, h0, l1, h1;
+            widen(r0, l0, h0);
+            widen(r1, l1, h1);
+            bias_lo += l0 + l1;
+            bias_hi += h0 + h1;
+          }
+        } else {
+          const f32x4 r0l = v0 ? st.v[ps][0][0] : z, r0h = v0 ? st.v[ps][0][1] : z;
+          const f32x4 r1l = v1 ? st.v[ps][1][0] : z, r1h = v1 ? st.v[ps][1][1] : z;
+          olo = u32x4{pack2(r0l[0], r1l[0]), pack2(r0l[1], r1l[1]), pack2(r0l[2], r1l[2]), pack2(r0l[3], r1l[3])};
+          ohi = u32x4{pack2(r0h[0], r1h[0]), pack2(r0h[1], r1h[1]), pack2(r0h[2], r1h[2]), pack2(r0h[3], r1h[3])};
+          if (bias) {
+            bias_lo += r0l + r1l;
+            bias_hi += r0h + r1h;
+          }
+        }
+        unsigned* dst = tile + (pr + 16 * ps) * LD16 + pc;
+        *reinterpret_cast<u32x4*>(dst) = olo;
+        *reinterpret_cast<u32x4*>(dst + 4) = ohi;
+      }
+    };
+    // one k-step: 4 groups of 16 rows, per group 2 + 2 operand sub-tiles and 4 MFMAs; operand reads one group ahead
+    auto mma = [&](int cur) {
+      const unsigned* as = As + cur * T16 + (4 * (lane >> 5)) * LD16 + (wave >> 1) * 64 + (lane & 31);
+      const unsigned* bs = Bs + cur * T16 + (4 * (lane >> 5)) * LD16 + (wave & 1) * 64 + (lane & 31);
+      u32x4 a[2][2], b[2][2];
+      auto rd = [&](int set, int kk) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[set][s2][e] = as[(8 * kk + e) * LD16 + 32 * s2];
+            b[set][s2][e] = bs[(8 * kk + e) * LD16 + 32 * s2];
+          }
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < BK16 / 16; ++kk) {
+        if (kk + 1 < BK16 / 16) rd((kk + 1) & 1, kk + 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk & 1][i]),
+                                                                     __builtin_bit_cast(bf16x8, b[kk & 1][j]), acc[i * 2 + j], 0, 0, 0);
+      }
+    };
+    if (nk > 0) {
+      load(KA, pa, pa2, rowa, sa, 0);
+      load(KB, pb, pb2, rowb, sb, 0);
+      store(KA, sa, 0, As, do_bias);
+      store(KB, sb, 0, Bs, false);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        load(KA, pa, pa2, rowa, sa, kt + 1);
+        load(KB, pb, pb2, rowb, sb, kt + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+      mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        store(KA, sa, kt + 1, As + (cur ^ 1) * T16, do_bias);
+        store(KB, sb, kt + 1, Bs + (cur ^ 1) * T16, false);
+      }
+      __syncthreads();
+    }
+  };
+  const bool a16 = (q.flags & NUDF_TN_A16) != 0, b16 = (q.flags & NUDF_TN_B16) != 0;
+  if (a16 && b16) run_kind(std::true_type{}, std::true_type{});
+  else if (!a16 && !b16) run_kind(std::false_type{}, std::false_type{});
+  else if (a16) run_kind(std::true_type{}, std::false_type{});
+  else run_kind(std::false_type{}, std::true_type{});
+
+  if (g.dbg && tid == 0) {
+    long long* d = g.dbg + 4 * (size_t)blockIdx.x;
+    d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = 2 * 16 + 4;
+    d[3] = nk | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 16);
+  }
+  if (g.flags & TNF_NO_EPILOGUE) return;
+  float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
+  if (do_bias) {   // the loop's last barrier has passed: the operand image is free
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
+    *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
+    __syncthreads();
+    if (tid < BM) {
+      float sum = 0.0f;
+      for (int k = 0; k < 16; ++k) sum += red[k * BM + tid];
+      if (slot) slot[BM * BN + tid] = sum;
+      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (slot) {   // accumulator register order, 64 contiguous bytes per lane (tn_reduce_kernel decodes it)
+      float* w = slot + ((wave * 4 + s) * 64 + lane) * 16;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {acc[s][4 * qd], acc[s][4 * qd + 1], acc[s][4 * qd + 2], acc[s][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
+      }
+    } else {
+      const int col = j0 + 32 * tn_jsub(2, wave, s) + (lane & 31);
+      if (col >= q.NB) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 32 * tn_isub(2, wave, s) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s][r]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side: the plan (tiles, layouts, cost-weighted row chunks) and the C ABI
 // ---------------------------------------------------------------------------------------
@@ -765,7 +991,19 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
                    "(nudf_gemm_tn_grouped_workspace gives the size)", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  // 16-bit MFMA mode: the packed-image kernel, unless an operand is in the blocked fp32 layout (generic kernel only) or
+  // most operands are stored as fp32 (its staging of an fp32 operand is heavier: 262 -> 278 us with all-fp32 operands,
+  // 228 -> 183 us with all-bf16 ones at 65 536 points)
+  bool packed16 = pl.prec != 0 && !(pl.flags & TNF_NO_PACK16);
+  int n16 = 0;
+  for (int i = 0; i < args->n_problems && packed16; ++i) {
+    const int f = args->prob[i].flags;
+    if (f & (NUDF_TN_A_BLK | NUDF_TN_B_BLK)) packed16 = false;
+    n16 += ((f & NUDF_TN_A16) ? 1 : 0) + ((f & NUDF_TN_B16) ? 1 : 0);
+  }
+  if (n16 < args->n_problems) packed16 = false;
+  if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
   if (pl.ws && !(pl.flags & TNF_NO_EPILOGUE)) {
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(pl.n_tiles * 17), dim3(256), 0, (hipStream_t)stream, pl);

@@ -137,6 +137,38 @@ def check(flags):
     print(f"flags {flags}: identical run to run {same}, worst relative error vs float64 {worst:.2e}", flush=True)
 
 
+if os.environ.get("TN_BENCH_16"):       # 16-bit MFMA mode: packed k-pair image (default) against the generic kernel (flag 256)
+    mlp.PRECISION = "mixed16"
+    kinds = os.environ["TN_BENCH_16"]          # "bb": bf16 x bf16, "fb": fp32 A x bf16 B, ...
+    jobs16 = []
+    for (A, NA, B, NB, Cm, db), ka, kb in zip(jobs, (kinds * len(jobs))[0::2], (kinds * len(jobs))[1::2]):
+        A16 = A.to(torch.bfloat16) if ka == "b" and A.shape[1] % 8 == 0 else A
+        B16 = B.to(torch.bfloat16) if kb == "b" and B.shape[1] % 8 == 0 else B
+        jobs16.append((A16, NA, B16, NB, Cm, db))
+    jobs[:] = jobs16
+    a, b = results(), results()
+    _lib.lib().nudf_set_tn_flags(256)
+    c = results()
+    _lib.lib().nudf_set_tn_flags(0)
+    print("packed image run-to-run identical:", all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(a, b)))
+    print("C bit-identical to the generic kernel's 16-bit loop:", all(torch.equal(x[0], y[0]) for x, y in zip(a, c)))
+    worst = 0.0
+    for (A, NA, B, NB, _, _), (Cw, dbw), (Co, dbo) in zip(jobs, a, c):
+        ref = A[:, :NA].to(torch.bfloat16).double().t() @ B.to(torch.bfloat16).double()   # the MFMAs see bf16-rounded operands
+        refb = A[:, :NA].double().sum(0)
+        if os.environ.get("TN_BENCH_VERBOSE"):
+            print(f"   {NA} x {NB} ({A.dtype}, {B.dtype}): C err {((Cw[:NA].double() - ref).abs().max() / ref.abs().max()).item():.2e}"
+                  f" generic {((Co[:NA].double() - ref).abs().max() / ref.abs().max()).item():.2e} identical {torch.equal(Cw, Co)}"
+                  f" bias err {((dbw[:NA].double() - refb).abs().max() / refb.abs().max()).item():.2e}")
+        worst = max(worst, ((Cw[:NA].double() - ref).abs().max() / ref.abs().max()).item(),
+                    ((dbw[:NA].double() - refb).abs().max() / refb.abs().max()).item(),
+                    ((dbw[:NA].double() - dbo[:NA].double()).abs().max() / refb.abs().max()).item())
+    print(f"worst relative error vs float64 of the bf16-rounded operands (C, bias, bias vs generic kernel): {worst:.2e}")
+    for rnd in range(2):
+        timed("packed k-pair image (default)", 0)
+        timed("generic kernel, fp32 image (256)", 256)
+        timed("no epilogue: packed", 2)
+    sys.exit(0)
 if os.environ.get("TN_BENCH_CHECK"):
     check(int(os.environ["TN_BENCH_CHECK"]))
     sys.exit(0)

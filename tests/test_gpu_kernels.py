@@ -155,6 +155,47 @@ def test_gemm_tn_grouped_bf16_operands(dev, M):
         assert rel(j[5][:NA], rb.float()) < 2e-5, (NA, NB, a16, b16)
 
 
+@pytest.mark.parametrize("M", [77, 1000, 5000])
+def test_gemm_tn_grouped_16bit_mfma_mode(dev, M):
+    """config-5 mode (NudfGemmTNGroup.prec != 0): 16-bit MFMAs over bf16-ROUNDED operands with fp32 accumulation, from
+    bf16- and fp32-stored operands in every combination, ragged widths, a ragged last k-step.  The packed k-pair LDS
+    image (gemm_tn16_group_kernel) must give the contraction of the rounded operands to fp32 rounding, bit-identical C
+    to the generic kernel's 16-bit loop (NUDF_TN_FLAGS bit 256), and the bias sums of the operands AS STORED."""
+    from neuraludf_amd import mlp, _lib
+    g = torch.Generator().manual_seed(14)
+    shapes = [(256, 256, True, True), (217, 256, False, True), (256, 40, True, True), (3, 128, True, False), (129, 72, True, True),
+              (1, 256, False, True)]
+    jobs, refs = [], []
+    for NA, NB, a16, b16 in shapes:
+        lda, ldb = ((NA + 7) // 8 * 8, (NB + 7) // 8 * 8) if True else (NA, NB)
+        if not a16:
+            lda = (NA + 3) // 4 * 4          # an fp32 operand only needs a multiple of 4 (the two pieces clamp separately)
+        A = torch.randn(M, lda, generator=g)
+        B = torch.randn(M, ldb, generator=g)
+        Ad = A.to(dev).to(torch.bfloat16) if a16 else A.to(dev)
+        Bd = B.to(dev).to(torch.bfloat16) if b16 else B.to(dev)
+        Ar, Br = Ad.to(torch.bfloat16).float().cpu().double(), Bd.to(torch.bfloat16).float().cpu().double()
+        refs.append((Ar[:, :NA].t() @ Br[:, :NB], Ad.float().cpu().double()[:, :NA].sum(0)))
+        jobs.append((Ad, NA, Bd, NB, torch.zeros(mlp.pad32(NA), ldb, device=dev), torch.zeros(mlp.pad32(NA), device=dev)))
+    old = mlp.PRECISION
+    mlp.PRECISION = "mixed16"
+    try:
+        mlp.gemm_tn_grouped(jobs, M)
+        packed = [(j[4].clone(), j[5].clone()) for j in jobs]
+        for j in jobs:
+            j[4].zero_(); j[5].zero_()
+        _lib.lib().nudf_set_tn_flags(256)
+        mlp.gemm_tn_grouped(jobs, M)
+    finally:
+        _lib.lib().nudf_set_tn_flags(0)
+        mlp.PRECISION = old
+    for (NA, NB, a16, b16), j, (pC, pb), (rC, rb) in zip(shapes, jobs, packed, refs):
+        assert rel(pC[:NA, :NB], rC.float()) < 2e-5, (NA, NB, a16, b16)
+        assert rel(pb[:NA], rb.float()) < 2e-5, (NA, NB, a16, b16)
+        assert torch.equal(pC, j[4]), (NA, NB, a16, b16)
+        assert rel(pb[:NA], j[5][:NA]) < 2e-5
+
+
 @pytest.mark.parametrize("M", [77, 5000])
 def test_gemm_tn_grouped_blocked_operands(dev, M):
     """fp32 operands in the BLOCKED layout of nudf.h (what the transposed-product chain kernel stores), alone and mixed
