@@ -142,6 +142,8 @@ typedef struct NudfComposite {
   float flip_saturation;
   int32_t use_norm_grad;
   float sparse_scale;
+  int32_t alpha_type;                          /* sdf2alpha_type: 0 'numerical' (every shipped conf), 1 'theorical'
+                                                  (udf_renderer_blending.py:321-323); occupies what was padding   */
   /* outputs */
   float* weights;                              /* [N,S+n_out]                               */
   float* out_color; float* out_color_base;     /* [N,3]                                     */
@@ -196,11 +198,13 @@ typedef struct NudfUpsample {
   const float* u;                              /* [K] quantiles linspace(.5/K, 1-.5/K, K)   */
   const float* sample_dist;                    /* [1] device                                */
   const float* gamma_dev;                      /* [1] device gamma (mix schedule) or NULL   */
-  int32_t N, M, K, mode;
+  int32_t N, M, K, mode;                       /* mode & 0xff: 0 up_sample_unbias, 1 up_sample_no_occ_aware;
+                                                  | NUDF_UP_THEORICAL: sdf2alpha_type 'theorical' in up_sample_unbias */
   float inv_s, beta, gamma;
   float* z_new;                                /* [N,K] ascending                           */
   float* pts_new;                              /* [N*K,3] o + d*z_new, or NULL              */
 } NudfUpsample;
+#define NUDF_UP_THEORICAL 256
 int nudf_upsample(const NudfUpsample* args, void* stream);
 int nudf_merge(const float* z, const float* udf, const float* z_new, const float* udf_new, int N, int M,
                int K, float* z_out, float* udf_out, void* stream);

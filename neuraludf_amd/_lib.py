@@ -62,7 +62,7 @@ class Composite(C.Structure):
                 ("scal", c_fp), ("sample_dist", c_fp), ("background_rgb", c_fp),
                 ("N", i32), ("S", i32), ("n_out", i32), ("s_nominal", i32),
                 ("has_anneal", i32), ("cos_anneal", f32), ("flip_saturation", f32),
-                ("use_norm_grad", i32), ("sparse_scale", f32),
+                ("use_norm_grad", i32), ("sparse_scale", f32), ("alpha_type", i32),
                 ("weights", c_fp), ("out_color", c_fp), ("out_color_base", c_fp), ("out_depth", c_fp),
                 ("out_normals", c_fp), ("out_wsum", c_fp), ("out_wsum_all", c_fp), ("sums", c_fp), ("ws", c_fp),
                 ("o_alpha", c_fp), ("o_alpha_plus", c_fp), ("o_alpha_minus", c_fp), ("o_vis_prob", c_fp),

@@ -53,6 +53,39 @@ __device__ __forceinline__ AlphaOut sdf2alpha_f(float sdf, float ic, float dist,
 }
 __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
+// sdf2alpha before the clip, both variants (udf_renderer_blending.py:308-323): type 0 'numerical' (the shipped setting),
+// type 1 'theorical' = 1 - exp(-relu(|iter_cos| inv_s (1 - sigmoid(sdf inv_s))) dist), which is in [0, 1) by itself
+__device__ __forceinline__ float alpha_raw_f(int type, float sdf, float ic, float dist, float inv_s) {
+  if (type == 0) return sdf2alpha_f(sdf, ic, dist, inv_s).a;
+  const float raw = fabsf(ic) * inv_s * (1.0f - csigmoid(sdf * inv_s));
+  return 1.0f - CEXP(-fmaxf(raw, 0.0f) * dist);
+}
+// adjoint of one side (sdf = sign * u) of the two-sided alpha: da -> d inv_s, d u, d iter_cos.  The caller has applied the
+// clip's mask (0 <= alpha_raw <= 1).
+__device__ __forceinline__ void alpha_bwd_f(int type, float sign, float u, float ic, float dist, float inv_s, float da,
+                                            float& d_invs, float& du, float& dic) {
+  if (type == 0) {
+    AlphaOut o = sdf2alpha_f(sign * u, ic, dist, inv_s);
+    const float rden = CRCP(o.den);
+    const float dnum = da * rden;
+    const float dden = -da * o.num * rden * rden;
+    const float tP = (dnum + dden) * o.P * (1.0f - o.P);
+    const float tN = (-dnum) * o.Nx * (1.0f - o.Nx);
+    d_invs += tP * o.ep + tN * o.en;
+    const float dep = tP * inv_s, den_ = tN * inv_s;
+    du += sign * (dep + den_);
+    dic += (den_ - dep) * dist * 0.5f;
+    return;
+  }
+  const float sdf = sign * u;
+  const float sg = csigmoid(sdf * inv_s), om = 1.0f - sg, aic = fabsf(ic);
+  const float raw = aic * inv_s * om;
+  const float draw = (raw > 0.0f) ? da * dist * CEXP(-raw * dist) : 0.0f;       // relu'(0) = 0 as in torch
+  d_invs += draw * aic * om * (1.0f - inv_s * sg * sdf);
+  du += sign * (-draw * aic * inv_s * inv_s * sg * om);
+  dic += draw * inv_s * om * ((ic > 0.0f) ? 1.0f : ((ic < 0.0f) ? -1.0f : 0.0f));
+}
+
 // raw per-sample inputs.  ALL chunks of a ray are loaded before any arithmetic or store, so the HBM latency
 // is paid once per ray instead of once per 64-sample chunk (stores to the diagnostic outputs would otherwise
 // fence the next chunk's loads).
@@ -181,8 +214,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
         const size_t b = (size_t)ray * S + i;
         // sdf2alpha(+-udf, -|true_cos|, dist, inv_s, cos_anneal_ratio)  (:414-417)
         const float ic = iter_cos_of(-fabsf(s.tc), p.has_anneal, p.cos_anneal);
-        apv[c] = clip01(sdf2alpha_f(s.u, ic, s.dist, rc.inv_s).a);
-        amv[c] = clip01(sdf2alpha_f(-s.u, ic, s.dist, rc.inv_s).a);
+        apv[c] = clip01(alpha_raw_f(p.alpha_type, s.u, ic, s.dist, rc.inv_s));
+        amv[c] = clip01(alpha_raw_f(p.alpha_type, -s.u, ic, s.dist, rc.inv_s));
         // eikonal / sparsity partial sums (:484-487, 531-536, 553)
         const float pn = CSQRT(s.px * s.px + s.py * s.py + s.pz * s.pz);
         const float ge = (s.gm - 1.0f) * (s.gm - 1.0f);
@@ -446,8 +479,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
       Vraw[c] = exc;
       vis[c] = clip01(exc);
       if (FULL || i < S) {
-        ap_raw[c] = sdf2alpha_f(ps[c].u, icv[c], ps[c].dist, rc.inv_s).a;
-        am_raw[c] = sdf2alpha_f(-ps[c].u, icv[c], ps[c].dist, rc.inv_s).a;
+        ap_raw[c] = alpha_raw_f(p.alpha_type, ps[c].u, icv[c], ps[c].dist, rc.inv_s);
+        am_raw[c] = alpha_raw_f(p.alpha_type, -ps[c].u, icv[c], ps[c].dist, rc.inv_s);
         alpha[c] = clip01(ap_raw[c]) * vis[c] + clip01(am_raw[c]) * (1.0f - vis[c]);
       }
     }
@@ -562,18 +595,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
           const float sign = sgn ? -1.0f : 1.0f;
           const float a_raw = sgn ? am_raw[c] : ap_raw[c];
           const float da = sgn ? dam : dap;
-          if (a_raw >= 0.0f && a_raw <= 1.0f) {
-            AlphaOut o = sdf2alpha_f(sign * s.u, icv[c], s.dist, rc.inv_s);
-            const float rden = CRCP(o.den);
-            const float dnum = da * rden;
-            const float dden = -da * o.num * rden * rden;
-            const float tP = (dnum + dden) * o.P * (1.0f - o.P);
-            const float tN = (-dnum) * o.Nx * (1.0f - o.Nx);
-            d_invs += tP * o.ep + tN * o.en;
-            const float dep = tP * rc.inv_s, den_ = tN * rc.inv_s;
-            du += sign * (dep + den_);
-            dic += (den_ - dep) * s.dist * 0.5f;
-          }
+          if (a_raw >= 0.0f && a_raw <= 1.0f) alpha_bwd_f(p.alpha_type, sign, s.u, icv[c], s.dist, rc.inv_s, da, d_invs, du, dic);
         }
         // iter_cos -> c = -|tc| -> tc
         const float cc = -fabsf(s.tc);
@@ -734,8 +756,8 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p)
       eval_sample(p, rc, i, r, s);
       tcv[c] = s.tc; aocc[c] = s.aocc; flipv[c] = s.flip; midv[c] = s.mid;
       const float ic = iter_cos_of(-fabsf(s.tc), p.has_anneal, p.cos_anneal);
-      apv[c] = clip01(sdf2alpha_f(s.u, ic, s.dist, rc.inv_s).a);
-      amv[c] = clip01(sdf2alpha_f(-s.u, ic, s.dist, rc.inv_s).a);
+      apv[c] = clip01(alpha_raw_f(p.alpha_type, s.u, ic, s.dist, rc.inv_s));
+      amv[c] = clip01(alpha_raw_f(p.alpha_type, -s.u, ic, s.dist, rc.inv_s));
       const float pn = CSQRT(s.px * s.px + s.py * s.py + s.pz * s.pz);
       const float ge = (s.gm - 1.0f) * (s.gm - 1.0f);
       if (pn < 1.2f) { s_relax_n += ge; s_relax_d += 1.0f; }
@@ -880,8 +902,8 @@ __global__ __launch_bounds__(256) void composite_bwd_blk_kernel(NudfComposite p,
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
       vis[c] = clip01(Vraw[c]);
-      ap_raw[c] = sdf2alpha_f(ps[c].u, icv[c], ps[c].dist, rc.inv_s).a;
-      am_raw[c] = sdf2alpha_f(-ps[c].u, icv[c], ps[c].dist, rc.inv_s).a;
+      ap_raw[c] = alpha_raw_f(p.alpha_type, ps[c].u, icv[c], ps[c].dist, rc.inv_s);
+      am_raw[c] = alpha_raw_f(p.alpha_type, -ps[c].u, icv[c], ps[c].dist, rc.inv_s);
       alpha[c] = clip01(ap_raw[c]) * vis[c] + clip01(am_raw[c]) * (1.0f - vis[c]);
       f[c] = 1.0f - alpha[c] + 1e-7f;
     }
@@ -934,18 +956,7 @@ __global__ __launch_bounds__(256) void composite_bwd_blk_kernel(NudfComposite p,
         const float sign = sgn ? -1.0f : 1.0f;
         const float a_raw = sgn ? am_raw[c] : ap_raw[c];
         const float da = sgn ? dam : dap;
-        if (a_raw >= 0.0f && a_raw <= 1.0f) {
-          AlphaOut o = sdf2alpha_f(sign * s.u, icv[c], s.dist, rc.inv_s);
-          const float rden = CRCP(o.den);
-          const float dnum = da * rden;
-          const float dden = -da * o.num * rden * rden;
-          const float tP = (dnum + dden) * o.P * (1.0f - o.P);
-          const float tN = (-dnum) * o.Nx * (1.0f - o.Nx);
-          d_invs += tP * o.ep + tN * o.en;
-          const float dep = tP * rc.inv_s, den_ = tN * rc.inv_s;
-          du += sign * (dep + den_);
-          dic += (den_ - dep) * s.dist * 0.5f;
-        }
+        if (a_raw >= 0.0f && a_raw <= 1.0f) alpha_bwd_f(p.alpha_type, sign, s.u, icv[c], s.dist, rc.inv_s, da, d_invs, du, dic);
       }
       const float cc = -fabsf(s.tc);
       float dic_dc = 1.0f;

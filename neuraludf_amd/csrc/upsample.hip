@@ -16,8 +16,12 @@
 
 __device__ __forceinline__ float clip01u(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
-__device__ __forceinline__ float sdf2alpha_plain(float sdf, float cosv, float dist, float inv_s) {
+__device__ __forceinline__ float sdf2alpha_plain(float sdf, float cosv, float dist, float inv_s, int theorical) {
   // sdf2alpha with cos_anneal_ratio=None: iter_cos = true_cos (:298-320)
+  if (theorical) {   // sdf2alpha_type == 'theorical' (:321-323): 1 - exp(-relu(|cos| inv_s (1 - sigmoid(sdf inv_s))) dist)
+    const float raw = fabsf(cosv) * inv_s * (1.0f - sigmoidf_(sdf * inv_s));
+    return 1.0f - expf(-fmaxf(raw, 0.0f) * dist);
+  }
   const float en = sdf + cosv * dist * 0.5f;
   const float ep = sdf - cosv * dist * 0.5f;
   const float P = sigmoidf_(ep * inv_s);
@@ -57,7 +61,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
 
   // weights w_i for the M-1 sections
   float w[NC];
-  if (p.mode == 1) {
+  const int theorical = (p.mode >> 8) & 1;   // NUDF_UP_THEORICAL
+  if ((p.mode & 0xff) == 1) {
     // up_sample_no_occ_aware (:846-858): w = alpha_occ[:, :-1]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(NudfUpsample p) {
       const int i = c * 64 + l;
       float alpha = 0.f;
       if (i < M - 1) {
-        const float ap = sdf2alpha_plain(midu[c], cosv[c], dists[c], p.inv_s);
-        const float am = sdf2alpha_plain(-midu[c], cosv[c], dists[c], p.inv_s);
+        const float ap = sdf2alpha_plain(midu[c], cosv[c], dists[c], p.inv_s, theorical);
+        const float am = sdf2alpha_plain(-midu[c], cosv[c], dists[c], p.inv_s, theorical);
         alpha = ap * vis[c] + am * (1.0f - vis[c]);
       }
       const float f = (i < M - 1) ? (1.0f - alpha + 1e-7f) : 1.0f;

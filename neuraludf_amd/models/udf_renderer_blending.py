@@ -37,6 +37,7 @@ def _fill_composite(a, c, N, S, n_out):
     a.flip_saturation = float(c["flip_saturation"])
     a.use_norm_grad = 1 if c["use_norm_grad"] else 0
     a.sparse_scale = float(c["sparse_scale"])
+    a.alpha_type = int(c.get("alpha_type", 0))
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -236,8 +237,8 @@ class UDFRendererBlending:
         self.n_outside = n_outside
         self.perturb = perturb
         self.up_sample_steps = up_sample_steps
-        if sdf2alpha_type != 'numerical':
-            raise NotImplementedError("sdf2alpha_type %r: every shipped conf uses 'numerical'" % sdf2alpha_type)
+        if sdf2alpha_type not in ('numerical', 'theorical'):     # the reference's two branches (:308, :321)
+            raise ValueError("sdf2alpha_type %r (the reference knows 'numerical' and 'theorical')" % sdf2alpha_type)
         self.sdf2alpha_type = sdf2alpha_type
         self.upsampling_type = upsampling_type
         self.sparse_scale_factor = sparse_scale_factor
@@ -292,7 +293,7 @@ class UDFRendererBlending:
         a = Upsample()
         a.rays_o, a.rays_d, a.z, a.udf = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf)
         a.u, a.sample_dist, a.gamma_dev = ptr(self._quantiles(k, dev)), ptr(sample_dist), ptr(gamma_dev)
-        a.N, a.M, a.K, a.mode = N, M, k, mode
+        a.N, a.M, a.K, a.mode = N, M, k, mode | (256 if self.sdf2alpha_type == 'theorical' else 0)   # NUDF_UP_THEORICAL
         a.inv_s, a.beta, a.gamma = float(inv_s), float(beta), float(gamma)
         z_new = torch.empty(N, k, device=dev)
         pts_new = torch.empty(N * k, 3, device=dev)
@@ -377,7 +378,8 @@ class UDFRendererBlending:
         scal, recip = self._scalars(dev)
         c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,
                  flip_saturation=flip_saturation, use_norm_grad=self.use_norm_grad_for_cosine,
-                 sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics)
+                 sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics,
+                 alpha_type=1 if self.sdf2alpha_type == 'theorical' else 0)
         outs = _CompositeFn.apply(c, rays_o, rays_d, z_vals, sample_dist, background_rgb, udf.reshape(N, S),
                                   grad.reshape(N, S, 3), col.reshape(N, S, 3), cb.reshape(N, S, 3), bg_z, bg_sigma,
                                   bg_color, scal)

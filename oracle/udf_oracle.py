@@ -277,13 +277,17 @@ def udf2logistic(udf, inv_s, gamma=20.0, abs_cos=1.0):
     return abs_cos * inv_s * e / (1 + e) ** 2 * gamma
 
 
-def sdf2alpha(sdf, true_cos, dists, inv_s, cos_anneal_ratio=None):
-    """'numerical' variant, udf_renderer_blending.py:292-320."""
+def sdf2alpha(sdf, true_cos, dists, inv_s, cos_anneal_ratio=None, kind="numerical"):
+    """udf_renderer_blending.py:292-325: 'numerical' (:308-320, the shipped setting) or 'theorical' (:321-323)."""
     if cos_anneal_ratio is not None:
         it = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio)
                + F.relu(-true_cos) * cos_anneal_ratio)
     else:
         it = true_cos
+    if kind == "theorical":
+        raw = it.abs() * inv_s * (1 - torch.sigmoid(sdf * inv_s))
+        return 1.0 - torch.exp(-F.relu(raw) * dists)
+    assert kind == "numerical", kind
     nxt = sdf + it * dists * 0.5
     prv = sdf - it * dists * 0.5
     pc = torch.sigmoid(prv * inv_s)
@@ -317,7 +321,7 @@ def sample_pdf_det(bins: Tensor, weights: Tensor, k: int) -> Tensor:
     return b0 + t * (b1 - b0)
 
 
-def up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k, inv_s, beta, gamma) -> Tensor:
+def up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k, inv_s, beta, gamma, kind="numerical") -> Tensor:
     """udf_renderer_blending.py:197-272 -> new z [N,k]."""
     n, m = z.shape
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z[..., :, None]
@@ -339,8 +343,8 @@ def up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k, inv_s, beta, gamma)
     alpha_occ = 1.0 - torch.exp(-F.relu(raw_occ) * gamma * d_raw)
     vis = excl_cumprod((1.0 - alpha_occ + vis_mask).clip(0, 1) + 1e-7)
     sp = vis[:, :-1]
-    a_p = sdf2alpha(mid_udf, cos_val, dists, inv_s)
-    a_m = sdf2alpha(-mid_udf, cos_val, dists, inv_s)
+    a_p = sdf2alpha(mid_udf, cos_val, dists, inv_s, kind=kind)
+    a_m = sdf2alpha(-mid_udf, cos_val, dists, inv_s, kind=kind)
     alpha = a_p * sp + a_m * (1 - sp)
     w = alpha * excl_cumprod(1.0 - alpha + 1e-7)
     return sample_pdf_det(z, w, k)
@@ -373,6 +377,7 @@ class RenderCfg:
     up_sample_steps: int = 4
     perturb: float = 1.0
     upsampling_type: str = "classical"
+    sdf2alpha_type: str = "numerical"
     sparse_scale_factor: float = 25000.0
     h_patch_size: int = 3
     use_norm_grad_for_cosine: bool = False
@@ -406,7 +411,7 @@ def importance_sample(nets: Nets, cfg: RenderCfg, rays_o, rays_d, z, sample_dist
             for i in range(steps):
                 g = float(np.clip(20 * 2 ** (steps - i), 20, 320))
                 z_new = up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k,
-                                         64 * 2 ** i, 64 * 2 ** (i + 1), g)
+                                         64 * 2 ** i, 64 * 2 ** (i + 1), g, kind=cfg.sdf2alpha_type)
                 last = (i + 1 == steps)
                 if trace is not None:
                     trace.append(dict(z=z.clone(), udf=udf.clone(), z_new=z_new.clone(),
@@ -423,7 +428,7 @@ def importance_sample(nets: Nets, cfg: RenderCfg, rays_o, rays_d, z, sample_dist
                 z, udf = merge_sorted(z, z_new, udf, udf_at(z_new))
             i = steps - 1
             z_new = up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k,
-                                     64 * 2 ** i, 64 * 2 ** (i + 1), 20 if i < 4 else 10)
+                                     64 * 2 ** i, 64 * 2 ** (i + 1), 20 if i < 4 else 10, kind=cfg.sdf2alpha_type)
             if trace is not None:
                 trace.append(dict(z=z.clone(), udf=udf.clone(), z_new=z_new.clone(),
                                   inv_s=64 * 2 ** i, beta=64 * 2 ** (i + 1), gamma=20 if i < 4 else 10,
@@ -480,8 +485,10 @@ def render_core(nets: Nets, cfg: RenderCfg, rays_o, rays_d, z, sample_dist,
     vis_mask = torch.cat([vis_mask[:, 1:], torch.ones(n, 1)], -1)
     vis = excl_cumprod((1.0 - alpha_occ + flip_saturation * vis_mask).clip(0, 1) + 1e-7).clip(0, 1)
 
-    a_p = sdf2alpha(udf, -1 * torch.abs(true_cos), dists.reshape(-1, 1), inv_s, cos_anneal_ratio).reshape(n, s)
-    a_m = sdf2alpha(-udf, -1 * torch.abs(true_cos), dists.reshape(-1, 1), inv_s, cos_anneal_ratio).reshape(n, s)
+    a_p = sdf2alpha(udf, -1 * torch.abs(true_cos), dists.reshape(-1, 1), inv_s, cos_anneal_ratio,
+                    kind=cfg.sdf2alpha_type).reshape(n, s)
+    a_m = sdf2alpha(-udf, -1 * torch.abs(true_cos), dists.reshape(-1, 1), inv_s, cos_anneal_ratio,
+                    kind=cfg.sdf2alpha_type).reshape(n, s)
     alpha = a_p * vis + a_m * (1 - vis)
     udf = udf.reshape(n, s)
 

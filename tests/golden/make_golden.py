@@ -26,6 +26,9 @@ CASES = {
     "cfg1_flat": dict(n_rays=64, kw=dict(n_samples=32, n_importance=0, n_outside=0, up_sample_steps=1, perturb=1.0)),
     "classical_bg": dict(n_rays=32, kw=dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5,
                                             perturb=1.0)),
+    # the reference's other sdf2alpha branch ('theorical', udf_renderer_blending.py:321-323): core + up-sampling
+    "theorical_bg": dict(n_rays=32, kw=dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, perturb=1.0,
+                                            sdf2alpha_type="theorical")),
     "mix_blend": dict(n_rays=24, kw=dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, perturb=1.0,
                                          upsampling_type="mix", use_norm_grad_for_cosine=True, h_patch_size=3),
                       blend=True),
@@ -41,7 +44,10 @@ def main():
     mods = perturb_(build_modules(rf, seed=0))
     sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
     scene = synth.make_scene("tiny")
+    only = sys.argv[1:]
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         for m in mods.values():
             m.zero_grad()
         n = case["n_rays"]

@@ -386,11 +386,13 @@ def _rays(n, seed=7):
     return synth.make_rays(scene, 0, n, seed=seed)
 
 
-@pytest.mark.parametrize("case", ["plain", "bg_anneal", "normgrad"])
+@pytest.mark.parametrize("case", ["plain", "bg_anneal", "normgrad", "theorical", "theorical_bg_anneal"])
 def test_composite_stagewise(dev, case):
     """identical (z, udf, grad, colours) into the oracle's composite math and into the kernel."""
     from neuraludf_amd.models.udf_renderer_blending import _CompositeFn
     g = torch.Generator().manual_seed(11)
+    kind = "theorical" if case.startswith("theorical") else "numerical"      # sdf2alpha_type (:308 / :321)
+    case = {"theorical": "plain", "theorical_bg_anneal": "bg_anneal"}.get(case, case)
     N, S = 37, (70 if case != "bg_anneal" else 130)
     n_out = 9 if case == "bg_anneal" else 0
     r = _rays(N)
@@ -429,8 +431,8 @@ def test_composite_stagewise(dev, case):
         aocc = 1.0 - torch.exp(-torch.relu(raw) * ga * dists)
         vm = torch.cat([(tc < 0.01).float()[:, 1:], torch.ones(N, 1)], -1)
         vis = O.excl_cumprod((1.0 - aocc + fs * vm).clip(0, 1) + 1e-7).clip(0, 1)
-        ap = O.sdf2alpha(u, -tc.abs(), dists, s_, anneal)
-        am = O.sdf2alpha(-u, -tc.abs(), dists, s_, anneal)
+        ap = O.sdf2alpha(u, -tc.abs(), dists, s_, anneal, kind=kind)
+        am = O.sdf2alpha(-u, -tc.abs(), dists, s_, anneal, kind=kind)
         alpha = ap * vis + am * (1 - vis)
         cc, bb = c, b
         if bs is not None:
@@ -463,7 +465,7 @@ def test_composite_stagewise(dev, case):
     dl = [t.detach().clone().to(dev).requires_grad_(True) for t in leaves]
     scal = torch.cat([dl[4], dl[5], dl[6]])
     c = dict(s_nominal=S, cos_anneal=anneal, flip_saturation=fs, use_norm_grad=use_norm, sparse_scale=25000.0,
-             diagnostics=True)
+             diagnostics=True, alpha_type=1 if kind == "theorical" else 0)
     outs = _CompositeFn.apply(c, D(r["rays_o"]), D(r["rays_d"]), D(z), torch.tensor([sdist], device=dev), None,
                               dl[0], dl[1], dl[2], dl[3], D(bg_z), dl[7] if n_out else None, dl[8] if n_out else None,
                               scal)
@@ -480,21 +482,23 @@ def test_composite_stagewise(dev, case):
         assert rel(dl[i].grad, leaves[i].grad) < GTOL, nm
 
 
-@pytest.mark.parametrize("kind", ["unbias", "noocc"])
+@pytest.mark.parametrize("kind", ["unbias", "noocc", "unbias_theorical"])
 def test_upsample_and_merge_stagewise(dev, nets, kind):
     """each up-sampling round of the oracle (given its z, udf) against nudf_upsample / nudf_merge."""
     mods, sds = nets
     from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
     r = _rays(53, seed=21)
+    a_kind = "theorical" if kind.endswith("theorical") else "numerical"
+    kind = kind.split("_")[0]
     cfg = O.RenderCfg(n_samples=64, n_importance=60 if kind == "unbias" else 66, n_outside=0, up_sample_steps=5,
-                      upsampling_type="classical" if kind == "unbias" else "mix")
+                      upsampling_type="classical" if kind == "unbias" else "mix", sdf2alpha_type=a_kind)
     trace = []
     on = oracle_nets(sds)
     z0, _, sd = O.coarse_z(cfg, r["near"], r["far"], 53)
     O.importance_sample(on, cfg, r["rays_o"], r["rays_d"], z0, sd, trace)
     rend = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], n_samples=64,
                                n_importance=cfg.n_importance, n_outside=0, up_sample_steps=5, perturb=0.0,
-                               upsampling_type=cfg.upsampling_type)
+                               upsampling_type=cfg.upsampling_type, sdf2alpha_type=a_kind)
     ro, rd = r["rays_o"].to(dev), r["rays_d"].to(dev)
     sdd = torch.tensor([sd], device=dev)
     n_bad = 0
@@ -519,10 +523,13 @@ def test_upsample_and_merge_stagewise(dev, nets, kind):
             return torch.gather(u1, 1, torch.argsort(z1, dim=1, stable=True))
         assert rel(canon(zo.cpu(), uo.cpu()), canon(zs, us)) < 1e-6
     # quantile bins may flip on ~ulp-level CDF differences (hard part 2)
-    assert n_bad <= max(2, len(trace) * 53 // 20), n_bad
+    # ('theorical' takes 1 - sigmoid(sdf inv_s) with inv_s up to 1024: where the sigmoid is within a few ulp of 1 the
+    # difference is an ulp-quantised 1e-7-ish number, so one ulp of the sigmoid moves those small weights by tens of
+    # percent -- in the fp32 reference just the same -- and a few more bins flip)
+    assert n_bad <= max(2, len(trace) * 53 // (12 if a_kind == "theorical" else 20)), n_bad
 
 
-@pytest.mark.parametrize("case", ["cfg1_flat", "classical_bg", "mix"])
+@pytest.mark.parametrize("case", ["cfg1_flat", "classical_bg", "mix", "theorical_bg"])
 def test_render_end_to_end_and_param_grads(dev, nets, case):
     mods, sds = nets
     from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
@@ -532,6 +539,8 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
         kw = dict(n_samples=32, n_importance=0, n_outside=0, up_sample_steps=1)
     elif case == "classical_bg":
         kw = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5)
+    elif case == "theorical_bg":     # the reference's other sdf2alpha branch, core and up-sampling
+        kw = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, sdf2alpha_type="theorical")
     else:
         kw = dict(n_samples=64, n_importance=78, n_outside=0, up_sample_steps=5, upsampling_type="mix",
                   use_norm_grad_for_cosine=True)
@@ -555,7 +564,9 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
     # up-sampling is discontinuous (searchsorted bins, thresholds): ulp-level differences in the MLP
     # output move the new samples of some rays by a bin (the reference itself moves ~9 % of the rays
     # under 1e-6 relative noise); those rays are compared statistically (PSNR)
-    assert good.float().mean() > 0.7
+    # ('theorical' weights come from 1 - sigmoid(x) near sigmoid = 1, see test_upsample_and_merge_stagewise: more rays
+    # change a bin in one of the five rounds; everything downstream is still checked exactly on the oracle's own samples)
+    assert good.float().mean() > (0.3 if case == "theorical_bg" else 0.7)
     for k in ["color", "color_base", "depth", "weight_sum"]:
         assert rel(out[k][good.to(dev)], ref[k][good]) < 1e-4, k
     mse = ((out["color"].cpu() - ref["color"]) ** 2).mean()
