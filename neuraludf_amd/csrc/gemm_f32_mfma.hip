@@ -105,8 +105,11 @@ __device__ __forceinline__ void epilogue_store(const NudfGemmNN& p, int row, int
     // channel 0 = |x| * scale (the 'abs' UDF head, fields.py:184-190, 210) -> C2[row], its sign ->
     // C3[row] (kept for the backward); channels 1.. (the appearance feature) -> C1[row, col-1]
     if (col == 0) {
-      if (p.C2) p.C2[r] = fabsf(v) * p.scale;
-      if (p.C3) p.C3[r] = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);
+      // udf_out and its derivative by p.iparam: 0 'abs', 1 'square', 2 'sdf' (fields.py:184-190)
+      const float hv = (p.iparam == 1) ? v * v : ((p.iparam == 2) ? v : fabsf(v));
+      const float hm = (p.iparam == 1) ? 2.0f * v : ((p.iparam == 2) ? 1.0f : ((v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f)));
+      if (p.C2) p.C2[r] = hv * p.scale;
+      if (p.C3) p.C3[r] = hm;
     } else if (p.C1) {
       p.C1[r * p.ldc1 + (col - 1)] = v;
     }

@@ -255,8 +255,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     } else if (EPI == NUDF_CH_NONE) {
       out[r] = v[r] * st.scale;
     } else if (EPI == NUDF_CH_UDFHEAD) {
-      out[r] = fabsf(v[r]) * st.scale;
-      out2[r] = (v[r] > 0.0f) ? 1.0f : ((v[r] < 0.0f) ? -1.0f : 0.0f);
+      ch_udf_head(st.iparam, v[r], st.scale, out[r], out2[r]);
     } else if (EPI == NUDF_CH_RELU) {
       out[r] = fmaxf(v[r], 0.0f);
       out2[r] = out[r];                                       // optional mirror (hidden tap of the colour net)

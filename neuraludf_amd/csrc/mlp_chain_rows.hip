@@ -145,8 +145,10 @@ __device__ __forceinline__ void chr_epi_tile(const NudfChainStep& st, float* act
       } else if (EPI == NUDF_CH_NONE) {
         o[i] = v * cs.scale;
       } else if (EPI == NUDF_CH_UDFHEAD) {
-        o[i] = fabsf(v) * cs.scale;
-        o2[i] = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);
+        float hv, hm;
+        ch_udf_head(cs.iparam, v, cs.scale, hv, hm);
+        o[i] = hv;
+        o2[i] = hm;
       } else if (EPI == NUDF_CH_RELU) {
         o[i] = fmaxf(v, 0.0f);
         o2[i] = o[i];

@@ -105,3 +105,12 @@ __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, co
   ((e) == NUDF_CH_MULSP || (e) == NUDF_CH_TANGENT || (e) == NUDF_CH_BWD || (e) == NUDF_CH_MULMASK || (e) == NUDF_CH_ADDMASK)
 
 #define CH_USES_X2(e) ((e) == NUDF_CH_TANGENT || (e) == NUDF_CH_BWD || (e) == NUDF_CH_ADDMASK || (e) == NUDF_CH_RELUADD)
+
+// UDFNetwork.udf_out (fields.py:184-190) and its derivative, the per-point multiplier every sweep behind the head uses:
+// type 0 'abs' (|v|, sign v: every shipped conf), 1 'square' (v^2, 2 v), 2 'sdf' (v, 1).  The type travels in the head
+// step's iparam (unused by this epilogue otherwise).
+__device__ __forceinline__ void ch_udf_head(int type, float v, float scale, float& out, float& mult) {
+  if (type == 1) { out = v * v * scale; mult = 2.0f * v; }
+  else if (type == 2) { out = v * scale; mult = 1.0f; }
+  else { out = fabsf(v) * scale; mult = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+}

@@ -607,6 +607,9 @@ class UDFEngine:
         self.layers = [PackedLinear(getattr(net, f"lin{l}")) for l in range(self.L + 1)]
         self.skip = set(net.skip_in)
         self.inv_sqrt2 = 1.0 / math.sqrt(2.0)
+        # udf_out (fields.py:184-190): the head kernels store f(h0) / scale and the multiplier f'(h0) ("sign" below: sign h0,
+        # 2 h0 or 1) that every sweep behind the head uses
+        self.head_type = {"abs": 0, "square": 1, "sdf": 2}[getattr(net, "udf_type", "abs")]
 
     def params(self):
         out = []
@@ -715,7 +718,7 @@ class UDFEngine:
             cb.step("NONE", pl.frag(_kind("fwd_feat", "fwd")), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat,
                     act_write=0)
         cb.step("UDFHEAD", pl.frag("fwd_head0"), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,
-                act_write=0, scale=1.0 / float(net.scale))
+                act_write=0, scale=1.0 / float(net.scale), iparam=self.head_type)
         cb.launch()
         return dict(udf=udf[:P], sign=(sign[:P] if sign is not None else None),
                     feat=(feat[:P] if feat is not None else None), X=X, P=P)
@@ -872,7 +875,7 @@ class UDFEngine:
             if ld >= F + 3:
                 call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
         gemm_nn(X[L], pl.Wt, P, 1 if udf_only else pl.out, pl.in_pad, "UDFHEAD", C1=feat, C2=udf, ldc2=1, C3=sign,
-                ldc3=1, bias=pl.bias, scale=1.0 / float(self.net.scale))
+                ldc3=1, bias=pl.bias, scale=1.0 / float(self.net.scale), iparam=self.head_type)
         return dict(udf=udf, sign=sign, feat=feat, X=X, P=P)
 
     def _xs(self, j):

@@ -46,6 +46,9 @@ class _UDFEvalFn(torch.autograd.Function):
             g, DA = engine.gradient(x, st)
         ctx.engine, ctx.x = engine, x
         ctx.st, ctx.DA = (st if need_state else None), (DA if need_state else None)
+        # udf_type 'square': d udf / dx = 2 h0 grad h0 depends on h0 a second time (f'' = 2); the backward needs the
+        # forward gradient for that term
+        ctx.g = g if (need_state and engine.head_type == 1) else None
         return st["udf"], st["feat"], (g if g is not None else x.new_zeros(0))
 
     @staticmethod
@@ -61,6 +64,14 @@ class _UDFEvalFn(torch.autograd.Function):
         if d_feat is not None:
             d_feat = d_feat.contiguous()
             ldf = d_feat.shape[1]
+        if ctx.g is not None and d_g is not None:
+            # g = f'(h0) grad_u h0 with f' = 2 h0 (the stored multiplier): h0_bar += f''(h0) (g_bar . grad_u h0)
+            # = 2 (g_bar . g) / f'.  The head's adjoint is f' * d_udf / scale, so the term rides in d_udf.
+            mult = st["sign"]
+            dot = (d_g * ctx.g).sum(-1)
+            extra = torch.where(mult != 0, 2.0 * dot / (mult * mult), torch.zeros_like(dot)) * float(engine.net.scale)
+            d_udf = extra if d_udf is None else d_udf.reshape(-1) + extra
+        ctx.g = None
         grads = engine.backward(ctx.x, st, ctx.DA, d_udf.contiguous() if d_udf is not None else None,
                                 d_feat, ldf, d_g.contiguous() if d_g is not None else None)
         ctx.st = ctx.DA = None
@@ -72,8 +83,8 @@ class UDFNetwork(nn.Module):
                  geometric_init=True, weight_norm=True, udf_type='abs',
                  udf_shift=None, predict_grad=None):   # the garment confs pass these two; the reference ignores/chokes
         super().__init__()
-        if udf_type != 'abs':
-            raise NotImplementedError("udf_type %r: the shipped confs (and the HIP head) use 'abs'" % udf_type)
+        if udf_type not in ('abs', 'square', 'sdf'):       # the reference's three udf_out branches (fields.py:184-190)
+            raise ValueError("udf_type %r (the reference knows 'abs', 'square' and 'sdf')" % udf_type)
         dims = [d_in] + [d_hidden for _ in range(n_layers)] + [d_out]
         self.embed_fn_fine = None
         self.multires = multires

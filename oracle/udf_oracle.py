@@ -130,7 +130,8 @@ def udf_gradient_analytic(sd: SD, x: Tensor, cfg: UDFCfg = UDFCfg()) -> Tensor:
             h = softplus100(a)
         else:
             h = a
-    s = torch.sign(h[:, :1]) if cfg.udf_type == "abs" else torch.ones_like(h[:, :1])
+    s = (torch.sign(h[:, :1]) if cfg.udf_type == "abs" else
+         2.0 * h[:, :1] if cfg.udf_type == "square" else torch.ones_like(h[:, :1]))      # udf_out' (fields.py:184-190)
     delta = s * Ws[-1][0:1, :] / cfg.scale                           # d udf / d h_last
     d_emb = torch.zeros_like(emb)
     for l in range(cfg.n_lin - 2, -1, -1):

@@ -23,14 +23,15 @@ CONF = dict(
 )
 
 
-def build_modules(fields_mod, seed=0):
-    """Instantiate the five networks in the runner's order (exp_runner_blending.py:125-129)."""
+def build_modules(fields_mod, seed=0, udf_type="abs"):
+    """Instantiate the five networks in the runner's order (exp_runner_blending.py:125-129).  `udf_type` does not enter the
+    initialisation: the same seed gives the same weights for 'abs', 'square' and 'sdf'."""
     import contextlib
     import io
     torch.manual_seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
         nerf = fields_mod.NeRF(**CONF["nerf"])
-        udf = fields_mod.UDFNetwork(**CONF["udf"])
+        udf = fields_mod.UDFNetwork(**{**CONF["udf"], "udf_type": udf_type})
         var = fields_mod.SingleVarianceNetwork(**CONF["var"])
         color = fields_mod.ResidualRenderingNetwork(**CONF["color"])
         beta = fields_mod.BetaNetwork(**CONF["beta"])

@@ -29,6 +29,11 @@ CASES = {
     # the reference's other sdf2alpha branch ('theorical', udf_renderer_blending.py:321-323): core + up-sampling
     "theorical_bg": dict(n_rays=32, kw=dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, perturb=1.0,
                                             sdf2alpha_type="theorical")),
+    # the reference's other udf_out branches (fields.py:184-190); same weights, the head differs
+    "square_bg": dict(n_rays=32, udf_type="square",
+                      kw=dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, perturb=1.0)),
+    # ('sdf' is pinned at the network level only, tests/test_gpu_kernels.py: with it the reference's own up-sampling
+    # produces NaN samples on these weights -- negative "udf" inside the surface -- and stops in pdb, :97-101)
     "mix_blend": dict(n_rays=24, kw=dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, perturb=1.0,
                                          upsampling_type="mix", use_norm_grad_for_cosine=True, h_patch_size=3),
                       blend=True),
@@ -51,6 +56,7 @@ def main():
         for m in mods.values():
             m.zero_grad()
         n = case["n_rays"]
+        mods["udf"].udf_type = case.get("udf_type", "abs")      # read at call time by UDFNetwork.udf_out
         rays = synth.make_rays(scene, 0, n, seed=5, margin=6)
         r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **case["kw"])
         kw = {}

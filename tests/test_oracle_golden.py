@@ -16,6 +16,7 @@ CASES = {
     "cfg1_flat": dict(n_samples=32, n_importance=0, n_outside=0, up_sample_steps=1),
     "classical_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5),
     "theorical_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, sdf2alpha_type="theorical"),
+    "square_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, udf=O.UDFCfg(udf_type="square")),
     "mix_blend": dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, upsampling_type="mix",
                       use_norm_grad_for_cosine=True, h_patch_size=3),
 }
