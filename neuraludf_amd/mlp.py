@@ -988,19 +988,19 @@ def relu_chain_bwd(layers, inputs, outs, D_last, P, first_needs_input_grad, add_
 
 
 class ColorEngine:
-    """ResidualRenderingNetwork, mode 'no_normal' (the only mode the shipped confs use)."""
+    """ResidualRenderingNetwork: mode 'no_normal' (every shipped conf) and the reference's other branch (any other mode
+    string, fields.py:456-461): the base input also carries the DETACHED unit normal and its negative."""
 
     def __init__(self, net):
         self.net = net
-        if net.mode != "no_normal":
-            raise NotImplementedError("ResidualRenderingNetwork mode %r (confs use 'no_normal')" % net.mode)
         n = net.num_layers - 1
         self.n = n
         F, H, dout = net.d_feature, net.d_hidden, net.d_out
         self.F, self.H, self.dout = F, H, dout
         self.npe = net.view_dim                        # width of PE(view_dirs)
-        # base input buffer [feat F | pts 3]; reference order is [pts 3, feat F]
-        perm_b0 = [F + i for i in range(3)] + list(range(F))
+        self.nrm = 0 if net.mode == "no_normal" else 6 # [normals 3 | -normals 3] behind the points
+        # base input buffer [feat F | pts 3 (| n 3 | -n 3)]; reference order is [pts 3, (n 3, -n 3,) feat F]
+        perm_b0 = [F + i for i in range(3 + self.nrm)] + list(range(F))
         # view input buffer [hidden H | PE(dir) | color_base dout]; reference order [PE(dir), color_base, hidden]
         perm_v0 = [H + i for i in range(self.npe)] + [H + self.npe + j for j in range(dout)] + list(range(H))
         self.base = [PackedLinear(getattr(net, f"lin_base{l}"), perm_b0 if l == 0 else None) for l in range(n)]
@@ -1018,7 +1018,7 @@ class ColorEngine:
 
     @property
     def cin_ld(self):
-        return pad32(self.F + 3)
+        return pad32(self.F + 3 + self.nrm)
 
     # -- dispatch: fused LDS-resident chains (default) or per-layer GEMM launches -------------------
     def _chain_ok(self):

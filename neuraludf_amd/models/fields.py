@@ -36,7 +36,7 @@ class _UDFEvalFn(torch.autograd.Function):
     colour network's base input ([feat F | pts 3 | zero pad], see mlp.ColorEngine)."""
 
     @staticmethod
-    def forward(ctx, engine, x, want_grad, feat_ld, *params):
+    def forward(ctx, engine, x, want_grad, feat_ld, normals_col, *params):
         ctx.set_materialize_grads(False)     # unused outputs arrive as None, not as zero-filled tensors
         x = x.detach().contiguous()
         need_state = any(ctx.needs_input_grad)      # all False under no_grad (grad mode is off inside forward)
@@ -44,6 +44,13 @@ class _UDFEvalFn(torch.autograd.Function):
         g = DA = None
         if want_grad:
             g, DA = engine.gradient(x, st)
+            if normals_col >= 0:
+                # colour-net modes that see the normal (fields.py:456-461): gradients / (|gradients| + 1e-5)
+                # (udf_renderer_blending.py:371) and its negative go behind the points of the colour net's base input.
+                # The reference DETACHES them, so they are constants of this evaluation: written here, no adjoint.
+                gn = g / (torch.linalg.norm(g, ord=2, dim=-1, keepdim=True) + 1e-5)
+                st["feat"][:, normals_col:normals_col + 3] = gn
+                st["feat"][:, normals_col + 3:normals_col + 6] = -gn
         ctx.engine, ctx.x = engine, x
         ctx.st, ctx.DA = (st if need_state else None), (DA if need_state else None)
         # udf_type 'square': d udf / dx = 2 h0 grad h0 depends on h0 a second time (f'' = 2); the backward needs the
@@ -55,7 +62,7 @@ class _UDFEvalFn(torch.autograd.Function):
     def backward(ctx, d_udf, d_feat, d_g):
         engine, st = ctx.engine, ctx.st
         if d_udf is None and d_feat is None and (d_g is None or d_g.numel() == 0):
-            return (None, None, None, None) + (None,) * len(engine.params())
+            return (None, None, None, None, None) + (None,) * len(engine.params())
         if st is None:
             raise RuntimeError("UDF evaluation was run without gradient state")
         if d_g is not None and d_g.numel() == 0:
@@ -75,7 +82,7 @@ class _UDFEvalFn(torch.autograd.Function):
         grads = engine.backward(ctx.x, st, ctx.DA, d_udf.contiguous() if d_udf is not None else None,
                                 d_feat, ldf, d_g.contiguous() if d_g is not None else None)
         ctx.st = ctx.DA = None
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class UDFNetwork(nn.Module):
@@ -133,10 +140,11 @@ class UDFNetwork(nn.Module):
         if self._engine is not None:
             self._engine.invalidate()
 
-    def evaluate(self, x, want_grad=True, feat_ld=0):
-        """fused value + spatial gradient: -> (udf [P], featbuf [P, max(feat_ld, F)], grad [P,3] or empty)."""
+    def evaluate(self, x, want_grad=True, feat_ld=0, normals_col=-1):
+        """fused value + spatial gradient: -> (udf [P], featbuf [P, max(feat_ld, F)], grad [P,3] or empty).
+        normals_col >= 0: also write the detached unit normal and its negative at these 6 columns of featbuf."""
         eng = self.engine()
-        return _UDFEvalFn.apply(eng, x, want_grad, feat_ld, *eng.params())
+        return _UDFEvalFn.apply(eng, x, want_grad, feat_ld, normals_col, *eng.params())
 
     @property
     def n_feature(self):
@@ -239,7 +247,8 @@ class ResidualRenderingNetwork(nn.Module):
             self._engine.invalidate()
 
     def evaluate(self, CIN, rays_d, S):
-        """CIN: [P, pad(F+3)] = [feat | pts | 0] as produced by UDFNetwork.evaluate(feat_ld=engine.cin_ld)."""
+        """CIN: [P, pad(F+3(+6))] = [feat | pts (| n | -n) | 0]: UDFNetwork.evaluate(feat_ld=engine.cin_ld) produces
+        [feat | pts | 0], with normals_col = F + 3 also the unit normals of the modes that use them."""
         eng = self.engine()
         return _ColorFn.apply(eng, CIN, rays_d, S, *eng.params())
 
@@ -247,8 +256,12 @@ class ResidualRenderingNetwork(nn.Module):
         """reference call surface (fields.py:452-495); view_dirs is per point here."""
         eng = self.engine()
         P = points.shape[0]
-        pad = eng.cin_ld - eng.F - 3
-        CIN = torch.cat([feature_vectors, points.detach(), points.new_zeros(P, pad)], dim=1)   # layout plumbing
+        cols = [feature_vectors, points.detach()]
+        if eng.nrm:                                     # every mode but 'no_normal' (fields.py:459-461): detached normals
+            nd = normals.detach()
+            cols += [nd, -nd]
+        cols.append(points.new_zeros(P, eng.cin_ld - eng.F - 3 - eng.nrm))
+        CIN = torch.cat(cols, dim=1)                    # layout plumbing
         cb, col, logits = _ColorFn.apply(eng, CIN, view_dirs.contiguous(), 1, *eng.params())
         if self.if_blending:
             return cb, col, logits

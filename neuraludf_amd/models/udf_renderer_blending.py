@@ -373,7 +373,9 @@ class UDFRendererBlending:
         pts = torch.empty(P, 3, device=dev)
         call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z_vals), ptr(sample_dist), N, S, 1, ptr(pts))
         ceng = self.color_network.engine()
-        udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld)
+        # (colour-net modes that see the detached unit normal, :371, :425: it rides in the same buffer)
+        udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld,
+                                                   normals_col=(ceng.F + 3) if ceng.nrm else -1)
         cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
         scal, recip = self._scalars(dev)
         c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,

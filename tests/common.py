@@ -23,7 +23,7 @@ CONF = dict(
 )
 
 
-def build_modules(fields_mod, seed=0, udf_type="abs"):
+def build_modules(fields_mod, seed=0, udf_type="abs", color_mode="no_normal"):
     """Instantiate the five networks in the runner's order (exp_runner_blending.py:125-129).  `udf_type` does not enter the
     initialisation: the same seed gives the same weights for 'abs', 'square' and 'sdf'."""
     import contextlib
@@ -33,7 +33,10 @@ def build_modules(fields_mod, seed=0, udf_type="abs"):
         nerf = fields_mod.NeRF(**CONF["nerf"])
         udf = fields_mod.UDFNetwork(**{**CONF["udf"], "udf_type": udf_type})
         var = fields_mod.SingleVarianceNetwork(**CONF["var"])
-        color = fields_mod.ResidualRenderingNetwork(**CONF["color"])
+        cc = dict(CONF["color"])
+        if color_mode != "no_normal":     # fields.py:456-461: base input = [pts, n, -n, feat] -> d_in - 3 = 9
+            cc.update(mode=color_mode, d_in=12)
+        color = fields_mod.ResidualRenderingNetwork(**cc)
         beta = fields_mod.BetaNetwork(**CONF["beta"])
     return dict(nerf=nerf, udf=udf, var=var, color=color, beta=beta)
 

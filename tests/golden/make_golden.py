@@ -34,6 +34,9 @@ CASES = {
                       kw=dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, perturb=1.0)),
     # ('sdf' is pinned at the network level only, tests/test_gpu_kernels.py: with it the reference's own up-sampling
     # produces NaN samples on these weights -- negative "udf" inside the surface -- and stops in pdb, :97-101)
+    # the colour network's other branch (any mode but 'no_normal', fields.py:456-461): detached unit normals in its input
+    "idr_bg": dict(n_rays=32, build=dict(color_mode="idr"),
+                   kw=dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, perturb=1.0)),
     "mix_blend": dict(n_rays=24, kw=dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, perturb=1.0,
                                          upsampling_type="mix", use_norm_grad_for_cosine=True, h_patch_size=3),
                       blend=True),
@@ -46,13 +49,17 @@ GRAD_KEYS = [("udf", "lin0.weight_v"), ("udf", "lin4.weight_g"), ("udf", "lin8.b
 
 def main():
     rf, rr, rl = load_reference()
-    mods = perturb_(build_modules(rf, seed=0))
-    sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
+    mods0 = perturb_(build_modules(rf, seed=0))
+    sums0 = {k: checksum(v) for k, v in state_dicts(mods0).items()}
     scene = synth.make_scene("tiny")
     only = sys.argv[1:]
     for name, case in CASES.items():
         if only and name not in only:
             continue
+        mods, sums = mods0, sums0
+        if case.get("build"):
+            mods = perturb_(build_modules(rf, seed=0, **case["build"]))
+            sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
         for m in mods.values():
             m.zero_grad()
         n = case["n_rays"]

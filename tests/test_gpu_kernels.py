@@ -270,6 +270,42 @@ def test_udf_forward_gradient_and_param_grads(dev, nets):
         assert rel(net.udf_only(x.to(dev)), y_ref[:, 0]) < VTOL
 
 
+@pytest.mark.parametrize("path", ["chain", "layers"])
+def test_color_network_with_normals(dev, path):
+    """ResidualRenderingNetwork in any mode but 'no_normal' (fields.py:456-461): base input [pts, n, -n, feat] with the
+    normals detached -- reference call surface against the oracle, values and every parameter gradient."""
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = perturb_(build_modules(fields, seed=0, color_mode="idr"))
+    sds = state_dicts(mods)
+    net = mods["color"].to(dev)
+    g = torch.Generator().manual_seed(6)
+    P = 900
+    pts, dirs = torch.randn(P, 3, generator=g) * 0.6, torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    nrm = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    feat = torch.randn(P, 256, generator=g) * 0.3
+    w = [torch.randn(P, 3, generator=g), torch.randn(P, 3, generator=g), torch.randn(P, 10, generator=g)]
+    on = oracle_nets(sds, requires_grad=True)
+    fr = feat.clone().requires_grad_(True)
+    ref = O.color_forward(on.color, pts, nrm, dirs, fr, O.ColorCfg(mode="idr", d_in=12))
+    sum((a * b).sum() for a, b in zip(ref, w)).backward()
+    try:
+        if path == "layers":
+            mlp.USE_CHAIN = False
+        net.zero_grad()
+        fd = feat.to(dev).requires_grad_(True)
+        out = net(pts.to(dev), nrm.to(dev), dirs.to(dev), fd)
+        for a, b in zip(out, ref):
+            assert rel(a, b) < VTOL
+        sum((a * b.to(dev)).sum() for a, b in zip(out, w)).backward()
+    finally:
+        mlp.USE_CHAIN = True
+    assert rel(fd.grad, fr.grad) < GTOL
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        assert rel(p.grad, on.color[n].grad) < GTOL, n
+
+
 @pytest.mark.parametrize("udf_type", ["square", "sdf"])
 @pytest.mark.parametrize("path", ["chain", "chain_tq", "layers"])
 def test_udf_type_variants(dev, udf_type, path):
@@ -572,9 +608,15 @@ def test_upsample_and_merge_stagewise(dev, nets, kind):
     assert n_bad <= max(2, len(trace) * 53 // (12 if a_kind == "theorical" else 20)), n_bad
 
 
-@pytest.mark.parametrize("case", ["cfg1_flat", "classical_bg", "mix", "theorical_bg", "square_bg"])
+@pytest.mark.parametrize("case", ["cfg1_flat", "classical_bg", "mix", "theorical_bg", "square_bg", "idr_bg"])
 def test_render_end_to_end_and_param_grads(dev, nets, case):
     mods, sds = nets
+    if case == "idr_bg":             # colour network with the (detached) unit normals in its input (fields.py:456-461)
+        from neuraludf_amd.models import fields
+        mods = perturb_(build_modules(fields, seed=0, color_mode="idr"))
+        sds = state_dicts(mods)
+        for m in mods.values():
+            m.to(dev)
     if case == "square_bg":          # udf_type 'square': same weights, another head (own modules: the engine reads the type)
         from neuraludf_amd.models import fields
         mods = perturb_(build_modules(fields, seed=0, udf_type="square"))
@@ -589,7 +631,7 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
         kw = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5)
     elif case == "theorical_bg":     # the reference's other sdf2alpha branch, core and up-sampling
         kw = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, sdf2alpha_type="theorical")
-    elif case == "square_bg":
+    elif case in ("square_bg", "idr_bg"):
         kw = dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5)
     else:
         kw = dict(n_samples=64, n_importance=78, n_outside=0, up_sample_steps=5, upsampling_type="mix",
@@ -597,6 +639,8 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
     cfg = O.RenderCfg(**{k: v for k, v in kw.items()})
     if case == "square_bg":
         cfg.udf = O.UDFCfg(udf_type="square")
+    if case == "idr_bg":
+        cfg.color = O.ColorCfg(mode="idr", d_in=12)
     on = oracle_nets(sds, requires_grad=True)
     ref = O.render(on, cfg, r["rays_o"], r["rays_d"], r["near"], r["far"], cos_anneal_ratio=0.8, flip_saturation=0.9)
     rend = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], perturb=1.0, **kw)

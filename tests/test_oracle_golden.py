@@ -17,6 +17,7 @@ CASES = {
     "classical_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5),
     "theorical_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, sdf2alpha_type="theorical"),
     "square_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, udf=O.UDFCfg(udf_type="square")),
+    "idr_bg": dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, color=O.ColorCfg(mode="idr", d_in=12)),
     "mix_blend": dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, upsampling_type="mix",
                       use_norm_grad_for_cosine=True, h_patch_size=3),
 }
@@ -36,6 +37,9 @@ def sds():
 @pytest.mark.parametrize("name", list(CASES))
 def test_oracle_reproduces_reference_outputs(sds, name):
     gold = np.load(os.path.join(HERE, "golden", f"ref_{name}.npz"))
+    if name == "idr_bg":        # another first layer of the colour net: its own seeded modules
+        from neuraludf_amd.models import fields
+        sds = state_dicts(perturb_(build_modules(fields, seed=0, color_mode="idr")))
     for k, sd in sds.items():
         assert abs(checksum(sd) - float(gold["wsum_" + k])) < 1e-6 * max(1.0, abs(float(gold["wsum_" + k]))), k
     rays = {k[4:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("ray_")}
