@@ -178,7 +178,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
+    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_gemm_tn_grouped_plan", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
     "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
@@ -198,6 +198,7 @@ _ARGTYPES = {
     "nudf_gemm_tn": [C.POINTER(GemmTN), _P],
     "nudf_gemm_tn_grouped": [C.POINTER(GemmTNGroup), _P],
     "nudf_gemm_tn_grouped_workspace": [C.POINTER(GemmTNGroup)],
+    "nudf_gemm_tn_grouped_plan": [C.POINTER(GemmTNGroup), C.POINTER(C.c_int32), i32],
     "nudf_set_tn_flags": [i32],
     "nudf_set_tn_debug": [_P],
     "nudf_composite_fwd": [C.POINTER(Composite), _P],

@@ -71,14 +71,14 @@ __device__ __forceinline__ int tn_jsub(int layout, int wave, int s) {
 // the tiles of one problem that read the same rows (same chunk; tiles of a tile row share the A panel, of a tile column
 // the B panel) are put on the SAME XCD -- within a tile group, blockIdx = first + (chunk / 8) * 8 T + tile * 8 + chunk % 8
 // (T tiles; the last chunk % 8 columns are narrower).  Workspace slots stay tile-major (tile.blk_start + chunk).
-__device__ __forceinline__ void tn_decode(const TnPlan& g, int& t, int& chunk) {
+__host__ __device__ __forceinline__ void tn_decode_block(const TnPlan& g, int block, int& t, int& chunk) {
   t = 0;
-  while (t + 1 < g.n_tiles && g.tile[t + 1].blk_start <= (int)blockIdx.x) ++t;
-  chunk = blockIdx.x - g.tile[t].blk_start;
+  while (t + 1 < g.n_tiles && g.tile[t + 1].blk_start <= block) ++t;
+  chunk = block - g.tile[t].blk_start;
   if (!(g.flags & TNF_NO_XCD_MAP) && g.tile[t].gn > 1) {
     const int gf = g.tile[t].gfirst, T = g.tile[gf].gn;
     const int C = g.tile[gf + 1].blk_start - g.tile[gf].blk_start;
-    const int o = blockIdx.x - g.tile[gf].blk_start;
+    const int o = block - g.tile[gf].blk_start;
     const int c_hi = o / (8 * T), rem = o - c_hi * 8 * T;
     const int w = (c_hi < (C >> 3)) ? 8 : (C & 7);
     const int k = rem / w;
@@ -86,6 +86,7 @@ __device__ __forceinline__ void tn_decode(const TnPlan& g, int& t, int& chunk) {
     chunk = c_hi * 8 + (rem - k * w);
   }
 }
+__device__ __forceinline__ void tn_decode(const TnPlan& g, int& t, int& chunk) { tn_decode_block(g, (int)blockIdx.x, t, chunk); }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   __shared__ __attribute__((aligned(16))) float smem[4 * T_TILE];
@@ -977,6 +978,22 @@ extern "C" int64_t nudf_gemm_tn_grouped_workspace(const NudfGemmTNGroup* args) {
   const int blocks = tn_plan(*args, pl);
   pl.dbg = nullptr;
   return blocks <= 0 ? (int64_t)blocks : (int64_t)blocks * TN_WS_TILE;
+}
+
+// host mirror of the kernels' blockIdx -> (tile, chunk) decode, for tests of the plan: out[4 b ..] = {problem, tile row *
+// 256 + tile column, row chunk, workspace slot} of workgroup b; returns the number of workgroups (<= capacity written)
+extern "C" int nudf_gemm_tn_grouped_plan(const NudfGemmTNGroup* args, int32_t* out, int capacity) {
+  TnPlan pl;
+  const int blocks = tn_plan(*args, pl);
+  for (int b = 0; b < blocks && b < capacity; ++b) {
+    int t, chunk;
+    tn_decode_block(pl, b, t, chunk);
+    out[4 * b] = pl.tile[t].prob;
+    out[4 * b + 1] = pl.tile[t].ti * 256 + pl.tile[t].tj;
+    out[4 * b + 2] = chunk;
+    out[4 * b + 3] = pl.tile[t].blk_start + chunk;
+  }
+  return blocks;
 }
 
 extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {

@@ -78,6 +78,46 @@ def test_weight_gradient_gemm_plan_host_logic():
     assert 0 < lib.nudf_gemm_tn_grouped_workspace(C.byref(g16)) // SLOT <= 512
 
 
+def test_weight_gradient_gemm_workgroup_order_host_logic():
+    """blockIdx -> (tile, row chunk) of nudf_gemm_tn_grouped (host mirror of the kernels' decode): a bijection onto the
+    workspace slots, and the tiles of a problem that read the same row chunk share blockIdx % 8 = the XCD (every chunk
+    column of eight; the narrower last column is exempt)."""
+    import collections
+    import ctypes as C
+    from neuraludf_amd import _lib
+    lib = _lib.lib()
+
+    def plan(shapes, M, flags=0, prec=0, ld=None):
+        g = _lib.GemmTNGroup()
+        g.n_problems, g.M, g.rows_per_block, g.prec = len(shapes), M, 0, prec
+        for i, (NA, NB) in enumerate(shapes):
+            q = g.prob[i]
+            q.A1, q.B1, q.C = 4096, 8192, 16384
+            q.lda1, q.ldb1, q.ldc = ld or (NA + 3) // 4 * 4, ld or (NB + 3) // 4 * 4, NB
+            q.NA, q.NB, q.flags = NA, NB, flags
+        out = (C.c_int32 * (4 * 1024))()
+        n = lib.nudf_gemm_tn_grouped_plan(C.byref(g), out, 1024)
+        assert 0 < n <= 512
+        return [tuple(out[4 * b:4 * b + 4]) for b in range(n)]
+
+    udf = [(256, 40)] + [(256, 256)] * 3 + [(217, 256)] + [(256, 256)] * 3 + [(256, 256), (1, 256)]
+    for shapes, M, kw in [(udf, 65536, {}), (udf, 5000, {}), ([(129, 72), (3, 128), (256, 256)], 777, {}),
+                          (udf, 262144, dict(flags=3, prec=2, ld=256))]:
+        blocks = plan(shapes, M, **kw)
+        assert sorted(b[3] for b in blocks) == list(range(len(blocks)))                      # every slot exactly once
+        chunks_of = collections.Counter((b[0], b[1]) for b in blocks)
+        per_chunk = collections.defaultdict(set)
+        for bid, (prob, tile, chunk, _) in enumerate(blocks):
+            per_chunk[(prob, chunks_of[(prob, tile)], chunk)].add((tile, bid % 8))
+        shared = 0
+        for (prob, n_chunks, chunk), members in per_chunk.items():
+            if chunk < (n_chunks // 8) * 8 and len(members) > 1:                            # a full column of eight chunks
+                assert len({x for _, x in members}) == 1, (prob, chunk, members)
+                shared += 1
+        if M >= 5000:
+            assert shared > 0
+
+
 def test_blocked_layout_helpers_are_inverse():
     from neuraludf_amd import mlp
     t = torch.arange(128 * 24, dtype=torch.float32).reshape(128, 24)
