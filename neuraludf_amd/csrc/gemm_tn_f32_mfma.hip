@@ -13,7 +13,12 @@
 //     tile costs n in 1..4 units instead of always 4, and the row chunks are sized per tile so that every workgroup
 //     gets the same number of MFMAs (cost-weighted split);
 //   * partial tiles go to a workspace with plain stores and a second kernel adds them up in a fixed order: run-to-run
-//     identical gradients, no fp32 atomics (atomics remain the fallback when the caller passes no workspace).
+//     identical gradients, no fp32 atomics (atomics remain the fallback when the caller passes no workspace);
+//   * full tiles with fp32 operands (85 % of a step's work) run kloop_full: one LDS read behind every MFMA, the LDS writes
+//     and global loads spread over the MFMA groups, the barrier inside the MFMA block -- a wave never issues a long run of
+//     non-MFMA instructions (scripts/ubench/mfma_pair.hip; 79 % MFMA-busy, profiles/r02_pmc_gemm_tn.txt);
+//   * blockIdx -> (tile, chunk) keeps the tiles that read the same rows on one XCD / L2 (tn_decode_block);
+//   * the 16-bit MFMA mode (config 5) has its own kernel, gemm_tn16_group_kernel: LDS image = bf16 k-pairs.
 #include "nudf_common.h"
 #include "nudf_gemm.h"
 #include <stdio.h>
