@@ -44,6 +44,45 @@ def test_ctypes_structs_match_header_field_counts():
         assert names == [f[0] for f in st._fields_], cname
 
 
+def test_ctypes_struct_layouts_match_a_c_compile_of_the_header(tmp_path):
+    """sizeof and every field offset of the by-value argument structs, as gcc lays out include/nudf.h, against the ctypes
+    mirrors of neuraludf_amd/_lib.py (the field-name test above cannot see padding or type widths)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from neuraludf_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    pairs = [("NudfGemmNN", _lib.GemmNN), ("NudfGemmTN", _lib.GemmTN), ("NudfGemmTNProblem", _lib.GemmTNProblem),
+             ("NudfGemmTNGroup", _lib.GemmTNGroup), ("NudfComposite", _lib.Composite), ("NudfCompositeGrad", _lib.CompositeGrad),
+             ("NudfUpsample", _lib.Upsample), ("NudfPixelBlend", _lib.PixelBlend), ("NudfPixelComposite", _lib.PixelComposite),
+             ("NudfPatchBlend", _lib.PatchBlend), ("NudfPatchWarp", _lib.PatchWarp), ("NudfAdamTensor", _lib.AdamTensor),
+             ("NudfAdamGroup", _lib.AdamGroup), ("NudfChainStep", _lib.ChainStep), ("NudfChain", _lib.Chain),
+             ("NudfRayBatch", _lib.RayBatch), ("NudfAdam", _lib.Adam), ("NudfPackFrag", _lib.PackFrag),
+             ("NudfPackLayer", _lib.PackLayer), ("NudfPackMulti", _lib.PackMulti), ("NudfUnpackLayer", _lib.UnpackLayer),
+             ("NudfUnpackMulti", _lib.UnpackMulti)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nudf.h"', 'int main(void) {']
+    for cname, st in pairs:
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in st._fields_:
+            cfield = f[0].rstrip("_")        # `in` is a Python keyword: the mirrors call that field in_
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, cfield))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        a, b, c = ln.split()
+        got[(a, b)] = int(c)
+    for cname, st in pairs:
+        assert got[(cname, "sizeof")] == C.sizeof(st), cname
+        for f in st._fields_:
+            assert got[(cname, f[0])] == getattr(st, f[0]).offset, (cname, f[0])
+
+
 def test_weight_gradient_gemm_plan_host_logic():
     """the planner of nudf_gemm_tn_grouped is host code: workspace sizes (= workgroups x slot) of known groups, one
     resident wave of <= 512 workgroups, argument errors -- no GPU involved."""
