@@ -66,7 +66,7 @@ def test_ctypes_struct_layouts_match_a_c_compile_of_the_header(tmp_path):
     for cname, st in pairs:
         lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
         for f in st._fields_:
-            cfield = f[0].rstrip("_")        # `in` is a Python keyword: the mirrors call that field in_
+            cfield = "in" if f[0] == "in_" else f[0]        # `in` is a Python keyword: the mirrors call that field in_
             lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, cfield))
     lines += ['  return 0;', '}']
     src = tmp_path / "layout.c"
