@@ -35,7 +35,18 @@ CASES = {
     "cfg5_shape": dict(n_samples=128, n_importance=128, n_outside=0, up_sample_steps=4, perturb=1.0),
     "cfg3_blend": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
                        use_norm_grad_for_cosine=True, h_patch_size=3),
+    # BASELINE config 3 at its REAL geometry ("DeepFashion3D scan320-shaped"): 1024 rays, 8 source
+    # views of 1024 x 1024 at f = 886.8 (pixel coordinates ~10x those of the "tiny" scene: projection, homography validity
+    # tests and bilinear taps at x ~ 1e3), same pipeline as cfg3_blend: file ref_cfg3_garment_full.npz.  The 100 MB of
+    # source images are not stored: common.smooth_images(8, 1024, 1024) regenerates them from the seed.
+    "cfg3_garment": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
+                         use_norm_grad_for_cosine=True, h_patch_size=3),
 }
+SCENE = {"cfg3_garment": "garment"}
+RAYS = {"cfg5_shape": 1024, "cfg3_garment": 1024}
+# garment scene: fov 60 deg from radius 2.2 -- the central 424 x 424 pixels see the object (elsewhere weight_sum ~ 0 and
+# the blending terms would be compared on empty rays)
+MARGIN = {"cfg3_garment": 300}
 KW = CASES["cfg2"]
 N_RAYS = 512
 KEYS = ["z_vals", "color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum",
@@ -57,9 +68,9 @@ def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     mods = perturb_(build_modules(rf, seed=0))
     sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
-    scene = synth.make_scene("tiny")
-    n_rays = 1024 if case == "cfg5_shape" else N_RAYS
-    rays = synth.make_rays(scene, 0, n_rays, seed=11, margin=6)
+    scene = synth.make_scene(SCENE.get(case, "tiny"))
+    n_rays = RAYS.get(case, N_RAYS)
+    rays = synth.make_rays(scene, 0, n_rays, seed=11, margin=MARGIN.get(case, 6))
     r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
     t0 = time.time()
     bkw, keys = {}, list(KEYS)
@@ -91,6 +102,9 @@ def main():
     if case == "cfg5_shape":      # keep the file small: per-ray outputs, sample positions and weights only
         keys = ["z_vals", "color", "color_base", "weights", "depth", "weight_sum", "gradient_error",
                 "gradient_error_near_surface", "sparse_error"]
+    if case == "cfg3_garment":    # per-ray outputs, sample positions, weights and udf (no [N,S,3] arrays)
+        keys = ["z_vals", "color", "color_base", "weights", "depth", "udf", "normals", "weight_sum", "gradient_error",
+                "gradient_error_near_surface", "sparse_error", "color_pixel", "patch_colors", "patch_mask"]
     data.update({"out_" + k: out[k].detach().numpy().astype(np.float32) for k in keys})
     data.update(extra)
     data["loss"] = np.float64(loss.item())

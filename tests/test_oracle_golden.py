@@ -72,3 +72,32 @@ def test_oracle_reproduces_reference_outputs(sds, name):
             g = getattr(nets, net)[pn].grad
             assert g is not None, k
             assert _maxrel(g, gold[k]) < 5e-5, k
+
+
+def test_oracle_at_garment_geometry_ray_subset(sds):
+    """BASELINE config 3's real geometry (1024 x 1024 source views at f = 886.8, pixel coordinates ~1e3): the oracle's
+    render_core + blending on the first 48 rays of the reference fixture ref_cfg3_garment_full.npz, at the reference's own
+    sample positions, against the reference's per-ray outputs (rays are independent, so a subset pins the same code)."""
+    from common import smooth_images
+    gold = np.load(os.path.join(HERE, "golden", "ref_cfg3_garment_full.npz"))
+    for k, sd in sds.items():
+        assert abs(checksum(sd) - float(gold["wsum_" + k])) < 1e-6 * max(1.0, abs(float(gold["wsum_" + k]))), k
+    n = 48
+    rays = {k[4:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("ray_")}
+    assert rays["rays_o"].shape[0] == 1024
+    scene = synth.make_scene("garment")
+    src = synth.make_source_views(scene, 0, 8)
+    blend = dict(color_maps=smooth_images(8, scene.H, scene.W), w2cs=src["w2cs"], intrinsics=src["intrinsics"],
+                 query_c2w=src["query_c2w"], rays_uv=rays["rays_uv"][:n].clone())
+    cfg = O.RenderCfg(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, upsampling_type="mix",
+                      use_norm_grad_for_cosine=True, h_patch_size=3)
+    sd_mean = float(((rays["far"] - rays["near"]) / cfg.n_samples).mean())     # batch constant of the FULL batch (:605)
+    z = torch.from_numpy(gold["out_z_vals"])[:n]
+    with torch.no_grad():
+        out = O.render_core(oracle_nets(sds), cfg, rays["rays_o"][:n], rays["rays_d"][:n], z, sd_mean, 0.7, None, None,
+                            None, 0.9, blend)
+    pm = out["patch_mask"].reshape(n, -1)[:, 0] if out["patch_mask"].dim() > 1 else out["patch_mask"]
+    assert float((pm - torch.from_numpy(gold["out_patch_mask"])[:n]).abs().max()) < 1e-4
+    for k in ["color", "color_base", "weights", "depth", "udf", "normals", "color_pixel", "patch_colors"]:
+        ref = torch.from_numpy(gold["out_" + k])[:n]
+        assert _maxrel(out[k].detach().reshape(ref.shape), ref) < 2e-5, k
