@@ -101,7 +101,11 @@ typedef struct NudfGemmTNGroup {
                                                    16-byte aligned scratch of >= nudf_gemm_tn_grouped_workspace()
                                                    floats: every workgroup stores its partial tile there and a second
                                                    kernel adds them to C / dbias in a FIXED order (run-to-run identical
-                                                   results).  Must not be shared by launches that can overlap.        */
+                                                   results).  Must not be shared by launches that can overlap.  With a
+                                                   workspace the problems of ONE group must write pairwise disjoint C
+                                                   and dbias ranges (that reduction is not atomic; overlapping groups
+                                                   are refused with hipErrorInvalidValue); consecutive launches may
+                                                   accumulate into the same C.                                       */
   int64_t workspace_floats;
 } NudfGemmTNGroup;
 int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);

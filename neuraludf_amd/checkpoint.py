@@ -43,12 +43,37 @@ def latest_checkpoint(base_exp_dir, end_iter=None):
     return names[-1] if names else None
 
 
+def _load_ckpt(path, map_location, allow_pickle):
+    """torch.load restricted to tensors / containers plus the numpy scalar types the reference runner leaves in the
+    optimizer state (its learning rates are numpy floats); arbitrary pickles (code execution on load) only on explicit
+    opt-in: `allow_pickle=True` or NUDF_CKPT_ALLOW_PICKLE=1."""
+    import numpy as np
+    safe = [np.dtype, np.float64, np.float32, np.int64, np.int32, np.bool_, np.ndarray]
+    core = getattr(np, "_core", None) or getattr(np, "core")         # numpy >= 2 renamed numpy.core
+    for name in ("scalar", "_reconstruct"):
+        if hasattr(core.multiarray, name):
+            safe.append(getattr(core.multiarray, name))
+    try:
+        from numpy import dtypes as _dt
+        safe += [getattr(_dt, n) for n in ("Float64DType", "Float32DType", "Int64DType", "Int32DType", "BoolDType")
+                 if hasattr(_dt, n)]
+    except ImportError:
+        pass
+    try:
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:          # pickle.UnpicklingError and friends: something beyond tensors + numpy scalars
+        if allow_pickle or os.environ.get("NUDF_CKPT_ALLOW_PICKLE", "0") == "1":
+            return torch.load(path, map_location=map_location, weights_only=False)
+        raise RuntimeError("checkpoint %s holds objects beyond tensors and numpy scalars (%s); pass allow_pickle=True (or "
+                           "NUDF_CKPT_ALLOW_PICKLE=1) only for files you trust" % (path, e)) from e
+
+
 def load_checkpoint(path, nerf, udf_network, variance_network, color_network, beta_network, optimizer=None,
-                    map_location=None, is_finetune=False):
+                    map_location=None, is_finetune=False, allow_pickle=False):
     """-> iter_step (0 when fine-tuning, :483-484).  Loading bumps the parameters' version counters (load_state_dict
     copies in place), which is what invalidates the packed-weight caches of the MLP engines."""
-    # weights_only=False: the reference runner stores numpy floats (its learning rates) in the optimizer state
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    ckpt = _load_ckpt(path, map_location, allow_pickle)
     nerf.load_state_dict(ckpt["nerf"])
     udf_network.load_state_dict(ckpt["udf_network_fine"])
     variance_network.load_state_dict(ckpt["variance_network_fine"])

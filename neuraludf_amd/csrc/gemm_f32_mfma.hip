@@ -9,7 +9,7 @@
 // models/fields.py:192-231 (UDFNetwork), :452-495 (ResidualRenderingNetwork), :599-628 (NeRF)
 // and their (double-)backward.  MFMA peak for this instruction: 157.3 TFLOP/s.
 #include "nudf_common.h"
-#include "nudf_gemm.h"
+#include "../../include/nudf.h"
 #include <stdlib.h>
 #include <type_traits>
 

@@ -20,7 +20,7 @@
 //   * blockIdx -> (tile, chunk) keeps the tiles that read the same rows on one XCD / L2 (tn_decode_block);
 //   * the 16-bit MFMA mode (config 5) has its own kernel, gemm_tn16_group_kernel: LDS image = bf16 k-pairs.
 #include "nudf_common.h"
-#include "nudf_gemm.h"
+#include "../../include/nudf.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -914,6 +914,23 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
           tl.n = 4;                                                     // operand columns make the dead sub-tiles exact 0)
         }
         cost[nt++] = tn_cost(tl.n);
+      }
+  }
+  // With a workspace the reduce kernel adds the partial tiles into C / dbias with plain (non-atomic) read-modify-writes,
+  // one workgroup per output tile: two problems of a group that write overlapping C rows or dbias entries would race.
+  if (g.workspace && !(flags & TNF_ATOMICS)) {
+    for (int i = 0; i < g.n_problems; ++i)
+      for (int j = i + 1; j < g.n_problems; ++j) {
+        const NudfGemmTNProblem &a = g.prob[i], &b = g.prob[j];
+        const float *a0 = a.C, *a1 = a.C + (size_t)(a.NA - 1) * a.ldc + a.NB;
+        const float *b0 = b.C, *b1 = b.C + (size_t)(b.NA - 1) * b.ldc + b.NB;
+        const bool c_overlap = a0 < b1 && b0 < a1;
+        const bool d_overlap = a.dbias && b.dbias && a.dbias < b.dbias + b.NA && b.dbias < a.dbias + a.NA;
+        if (c_overlap || d_overlap) {
+          nudf_set_error("nudf_gemm_tn_grouped: with a workspace the problems of a group must write disjoint C / dbias "
+                         "ranges (the fixed-order reduction is not atomic)", hipErrorInvalidValue);
+          return -1;
+        }
       }
   }
   pl.n_tiles = nt;

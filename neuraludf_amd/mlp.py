@@ -140,6 +140,13 @@ def _timed(name, flops, fn):
 
 
 def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
+    # nudf_gemm_tn reads its operands as row-major fp32: bf16-stored (mixed16 state) or blocked-layout buffers carry their
+    # format only through gemm_tn_grouped's per-problem flags
+    for t in (A1, B1, A2, B2):
+        if t is not None and (_is16(t) or _isblk(t)):
+            raise _lib.NudfError("gemm_tn: bf16-stored / blocked-layout operands need gemm_tn_grouped (per-problem "
+                                 "NUDF_TN_A16 / _B16 / _A_BLK / _B_BLK flags); set NUDF_STATE16=0 / NUDF_BLOCKED_STATE=0 "
+                                 "with NUDF_UDF_TN_GROUPED=0")
     a = GemmTN()
     a.A1, a.lda1, a.na1 = ptr(A1), A1.shape[1], na1
     a.B1, a.ldb1 = ptr(B1), B1.shape[1]
@@ -543,6 +550,32 @@ def pack_group(layers, kinds=None):
         pl._ver = pl._new_ver
 
 
+def claim_grad_slot(engine, layers):
+    """The engine's segment of the data-parallel gradient bucket (dist.GradBucket) if this backward may write into it,
+    else None (fresh gradient tensors, which autograd then ADDS to whatever is there).  The segment is persistent and
+    autograd installs views of it as `p.grad`, so it can be written at most once between two resets of the gradients:
+      * a second backward of the same engine inside ONE autograd pass (two evaluations of a network in one graph) finds
+        `_slot_inflight` set -- autograd has not installed the first result yet, it would sum the aliased views;
+      * a backward while some parameter's `.grad` still lives in the segment (gradient accumulation,
+        zero_grad(set_to_none=False)) would overwrite that gradient and AccumulateGrad would add the tensor to itself.
+    Trainer.step (one evaluation per network, zero_grad(set_to_none=True)) always gets the segment."""
+    slot = getattr(engine, "grad_slot", None)
+    if slot is None or getattr(engine, "_slot_inflight", False):
+        return None
+    lo, hi = slot.data_ptr(), slot.data_ptr() + 4 * slot.numel()
+    for pl in layers:
+        for p in pl.params():
+            g = p.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                return None
+    try:     # cleared when the running autograd pass ends; outside a backward pass nothing accumulates
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: setattr(engine, "_slot_inflight", False))
+        engine._slot_inflight = True
+    except RuntimeError:
+        pass
+    return slot
+
+
 def unpack_group(layers, grads, slot=None):
     """packed (dW, db) per layer -> parameter gradients in params() order, ONE launch per <= 16 layers.
     `slot`: optional flat fp32 tensor of exactly sum(p.numel() for the layers' params) elements (a segment of the
@@ -842,14 +875,14 @@ class UDFEngine:
                     sg4[:P, 0] = sign * inv_scale  # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
                     jobs.append((sg4, 1, R[L], plL.in_pad, dWL[:1], None))
                 gemm_tn_grouped(jobs, P)
-            return unpack_group(layers, grads, getattr(self, "grad_slot", None))
+            return unpack_group(layers, grads, claim_grad_slot(self, layers))
         for l, pl in enumerate(layers):
             dW, db = grads[l]
             if second and l < L:
                 gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db, A2=DA[l], na2=pl.out, B2=R[l])
             else:
                 gemm_tn(ABAR[l], pl.out, X[l], dW, pl.out, pl.in_pad, P, dbias=db)
-        return unpack_group(layers, grads, getattr(self, "grad_slot", None))
+        return unpack_group(layers, grads, claim_grad_slot(self, layers))
 
     def _forward_layers(self, x, need_grad_state, feat_ld=0, udf_only=False):
         """per-layer GEMM launches.  x [P,3] -> dict(udf [P], sign [P], feat [P, max(feat_ld, F)], state...).
@@ -1126,7 +1159,7 @@ class ColorEngine:
         for i, pl in enumerate(self.base):
             jobs.append((Db[i], pl.out, HB[i], pl.in_pad, grads[n + i][0], grads[n + i][1]))
         gemm_tn_grouped(jobs, P)
-        return unpack_group(self.view + self.base, grads, getattr(self, "grad_slot", None)), dCIN[:P]
+        return unpack_group(self.view + self.base, grads, claim_grad_slot(self, self.view + self.base)), dCIN[:P]
 
     def _forward_layers(self, CIN, rays_d, S, P, keep_state=True):
         """CIN [P, pad(F+3)] = [feature F | pts 3 | 0] (written by the UDF head + nudf_copy_cols)."""
@@ -1409,7 +1442,7 @@ class NerfEngine:
         jobs.append((Dsig, 1, h_last, self.alpha.in_pad, grads[D + 2][0], grads[D + 2][1]))
         jobs.append((Drgb, 3, hv, self.rgb.in_pad, grads[D + 3][0], grads[D + 3][1]))
         gemm_tn_grouped(jobs, P)
-        return unpack_group(layers, grads, getattr(self, "grad_slot", None))
+        return unpack_group(layers, grads, claim_grad_slot(self, layers))
 
     def _forward_layers(self, pts4, rays_d, S, P, keep_state=True):
         dev = pts4.device

@@ -76,7 +76,12 @@ class _UDFEvalFn(torch.autograd.Function):
             # = 2 (g_bar . g) / f'.  The head's adjoint is f' * d_udf / scale, so the term rides in d_udf.
             mult = st["sign"]
             dot = (d_g * ctx.g).sum(-1)
-            extra = torch.where(mult != 0, 2.0 * dot / (mult * mult), torch.zeros_like(dot)) * float(engine.net.scale)
+            # dot = mult * (g_bar . grad_u h0) is a product divided by its own factor (well conditioned); dividing twice
+            # instead of by mult * mult keeps the intermediate out of the denormals near the surface (h0 -> 0, where
+            # samples concentrate: mult^2 underflows at |h0| ~ 1e-19 and the term became inf * 0 = NaN).
+            ok = mult.abs() > 1e-30
+            safe = torch.where(ok, mult, torch.ones_like(mult))
+            extra = torch.where(ok, 2.0 * (dot / safe) / safe, torch.zeros_like(dot)) * float(engine.net.scale)
             d_udf = extra if d_udf is None else d_udf.reshape(-1) + extra
         ctx.g = None
         grads = engine.backward(ctx.x, st, ctx.DA, d_udf.contiguous() if d_udf is not None else None,

@@ -173,24 +173,26 @@ class Trainer:
             blend = dict(color_maps=src_images, w2cs=torch.inverse(src_c2ws), intrinsics=src_intr, query_c2w=ref_c2w)
         loss, out = self.step(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
                               blend=blend)
-        self._trainability_toggles(out, iter_step + 1)
+        self._trainability_toggles(out, iter_step)
         return loss, out, s
 
-    def _trainability_toggles(self, out, iter_step, check_every=100):
-        """exp_runner_blending.py:352-358: once the variance has dropped below 2 beta and 0.01, beta becomes trainable;
-        a frozen variance becomes trainable after 20 000 iterations.  Both are no-ops for the shipped confs (beta and
-        the variance are trainable from the start).  The first test reads two device scalars, so it is evaluated every
-        `check_every` iterations only (the reference syncs on it every iteration)."""
+    def _trainability_toggles(self, out, iter_step):
+        """exp_runner_blending.py:352-358, evaluated on this iteration's render output like there: once the variance has
+        dropped below 2 beta and 0.01, beta becomes trainable (takes effect from the next iteration's graph on, as in the
+        reference, where the flag flips after the forward pass); a frozen variance becomes trainable once
+        iter_step > 20 000.  The first test reads two device scalars (a host sync the reference pays every iteration):
+        it is evaluated every iteration, but only while beta is still frozen -- confs whose beta is trainable from the
+        start (all shipped ones: set_beta_trainable would be a no-op) never sync."""
         var_p = getattr(self.var, "variance", None)
-        if var_p is not None and var_p.requires_grad is False and iter_step > 20000:
-            self.var.set_trainable()
         beta_p = getattr(self.beta, "beta", None)
-        if (self._beta_flag and beta_p is not None and not beta_p.requires_grad and var_p is not None and var_p.requires_grad
-                and iter_step % check_every == 0):
+        if (self._beta_flag and beta_p is not None and not beta_p.requires_grad and var_p is not None
+                and var_p.requires_grad):
             variance, beta = float(out["variance"].mean()), float(out["beta"].reshape(-1)[0])
             if variance < 2 * beta and variance < 0.01:
                 self.beta.set_beta_trainable()
                 self._beta_flag = False
+        if var_p is not None and var_p.requires_grad is False and iter_step > 20000:
+            self.var.set_trainable()
 
     @torch.no_grad()
     def render_image(self, source, img_idx, resolution_level=4, chunk=65536, cos_anneal_ratio=1.0):

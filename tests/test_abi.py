@@ -115,6 +115,32 @@ def test_weight_gradient_gemm_plan_host_logic():
     g16 = group(udf, 262144, flags=3, ld=256)
     g16.prec = 2
     assert 0 < lib.nudf_gemm_tn_grouped_workspace(C.byref(g16)) // SLOT <= 512
+    # with a workspace (fixed-order, non-atomic reduction) the problems of a group must write disjoint C / dbias ranges
+    g2 = group([(64, 64), (64, 64)], 4096)
+    g2.workspace = 1 << 20                                # fake non-NULL pointer: the planner never dereferences it
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(g2)) < 0           # both problems write C = 16384
+    assert b"disjoint" in lib.nudf_last_error()
+    g2.prob[1].C = 16384 + 4 * 64 * 64
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(g2)) > 0
+    g2.prob[0].dbias, g2.prob[1].dbias = 1 << 16, (1 << 16) + 4 * 32       # [NA = 64] ranges overlap by 32 entries
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(g2)) < 0
+    g2.prob[1].dbias = (1 << 16) + 4 * 64
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(g2)) > 0
+    g2.workspace = None                                   # atomics path: overlapping outputs are allowed
+    g2.prob[1].C = 16384
+    assert lib.nudf_gemm_tn_grouped_workspace(C.byref(g2)) > 0
+
+
+def test_per_layer_weight_gradient_gemm_refuses_formatted_operands():
+    """nudf_gemm_tn reads row-major fp32 only: the per-layer fallback must refuse bf16-stored / blocked-layout state
+    instead of producing silent garbage."""
+    from neuraludf_amd import mlp
+    from neuraludf_amd._lib import NudfError
+    a = torch.zeros(64, 32)
+    with pytest.raises(NudfError, match="gemm_tn_grouped"):
+        mlp.gemm_tn(a.to(torch.bfloat16), 32, a, torch.zeros(32, 32), 32, 32, 64)
+    with pytest.raises(NudfError, match="gemm_tn_grouped"):
+        mlp.gemm_tn(a, 32, mlp.block(a), torch.zeros(32, 32), 32, 32, 64)
 
 
 def test_weight_gradient_gemm_workgroup_order_host_logic():

@@ -1,0 +1,61 @@
+"""the data-parallel gradient bucket hands every MLP engine a persistent slot that its unpack kernel
+writes into and that autograd installs as `p.grad`.  A second backward through the same engine before the gradients are
+reset (two evaluations of one network in one graph, gradient accumulation, zero_grad(set_to_none=False)) must ADD to those
+gradients, not overwrite the memory that already is `p.grad` and then add it to itself."""
+import pytest
+import torch
+
+from common import build_modules, perturb_
+
+pytestmark = pytest.mark.gpu
+
+
+def _loss_two_evaluations(net, xa, xb, wa, wb):
+    ua, fa, ga = net.evaluate(xa, want_grad=True)
+    ub, fb, _ = net.evaluate(xb, want_grad=False)
+    return (ua * wa[:, 0]).sum() + (fa[:, :256] * wa[:, 1:257]).sum() + (ga * wa[:, 257:260]).sum() \
+        + (ub * wb[:, 0]).sum() + (fb[:, :256] * wb[:, 1:257]).sum()
+
+
+def test_udf_engine_twice_in_one_backward_under_a_grad_bucket():
+    from neuraludf_amd import dist as nd
+    from neuraludf_amd.models import fields
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    xa, xb = (torch.randn(700, 3, generator=g) * 0.6).to(dev), (torch.randn(300, 3, generator=g) * 0.6).to(dev)
+    wa, wb = torch.randn(700, 260, generator=g).to(dev), torch.randn(300, 257, generator=g).to(dev)
+
+    ref = perturb_(build_modules(fields, seed=0))["udf"].to(dev)          # no bucket: fresh gradient tensors per backward
+    _loss_two_evaluations(ref, xa, xb, wa, wb).backward()
+    want = {n: p.grad.clone() for n, p in ref.named_parameters()}
+
+    net = perturb_(build_modules(fields, seed=0))["udf"].to(dev)
+    eng = net.engine()
+    bucket = nd.GradBucket([(list(eng.params()), eng)], device=dev)
+    assert eng.grad_slot is not None and eng.grad_slot.data_ptr() == bucket.flat.data_ptr()
+
+    def check(scale, what):
+        for n, p in net.named_parameters():
+            err = float((p.grad - scale * want[n]).abs().max() / (scale * want[n]).abs().max().clamp(min=1e-6))
+            assert err < 2e-5, (what, n, err)
+
+    # (a) two evaluations of the network in ONE graph: the engine's backward runs twice in one autograd pass
+    _loss_two_evaluations(net, xa, xb, wa, wb).backward()
+    check(1.0, "two evaluations in one graph")
+    # (the first backward wrote into the bucket segment, the second had to fall back to fresh tensors; autograd summed them)
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
+    assert not eng._slot_inflight
+    # (b) gradient accumulation: a second backward without resetting the gradients
+    _loss_two_evaluations(net, xa, xb, wa, wb).backward()
+    check(2.0, "accumulation over two backward passes")
+    # (c) zero_grad(set_to_none=False) keeps the bucket views as p.grad: the next backward must still be right
+    for p in net.parameters():
+        p.grad.zero_()
+    _loss_two_evaluations(net, xa, xb, wa, wb).backward()
+    check(1.0, "after zero_grad(set_to_none=False)")
+    # (d) the fast path is back after a reset to None
+    for p in net.parameters():
+        p.grad = None
+    _loss_two_evaluations(net, xa, xb, wa, wb).backward()
+    check(1.0, "after set_to_none")
+    assert all(lo <= p.grad.data_ptr() < hi for p in net.parameters())

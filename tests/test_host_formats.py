@@ -281,3 +281,24 @@ def test_shipped_confs_construct_the_dropin_objects():
         assert n_par == 1291484, n_par          # 1 291 484 floats
         a = s.at(0)
         assert 0.0 <= a["cos_anneal_ratio"] <= 1.0
+
+
+def test_checkpoint_loader_refuses_arbitrary_pickles(tmp_path):
+    """load_checkpoint unpickles tensors, containers and the numpy scalars the reference runner leaves in its optimizer
+    state -- nothing else, unless the caller opts in (weights_only=False executes code on load)."""
+    import numpy as np
+    from neuraludf_amd import checkpoint as C
+    ok = tmp_path / "ok.pth"
+    torch.save({"w": torch.ones(3), "optimizer": {"param_groups": [{"lr": np.float64(5e-4) * 0.5}], "state": {}},
+                "iter_step": 7}, ok)
+    d = C._load_ckpt(str(ok), None, False)
+    assert d["iter_step"] == 7 and float(d["optimizer"]["param_groups"][0]["lr"]) == 2.5e-4
+
+    class Evil:
+        def __reduce__(self):
+            return (os.path.join, ("executed", "on", "load"))
+    bad = tmp_path / "bad.pth"
+    torch.save({"w": torch.ones(3), "x": Evil()}, bad)
+    with pytest.raises(RuntimeError, match="allow_pickle"):
+        C._load_ckpt(str(bad), None, False)
+    assert C._load_ckpt(str(bad), None, True)["x"] == os.path.join("executed", "on", "load")
