@@ -208,12 +208,18 @@ typedef struct NudfUpsample {
   const float* sample_dist;                    /* [1] device                                */
   const float* gamma_dev;                      /* [1] device gamma (mix schedule) or NULL   */
   int32_t N, M, K, mode;                       /* mode & 0xff: 0 up_sample_unbias, 1 up_sample_no_occ_aware;
-                                                  | NUDF_UP_THEORICAL: sdf2alpha_type 'theorical' in up_sample_unbias */
+                                                  | NUDF_UP_THEORICAL: sdf2alpha_type 'theorical' in up_sample_unbias
+                                                  | NUDF_UP_SERIAL | NUDF_UP_NOCONTRACT: see below */
   float inv_s, beta, gamma;
   float* z_new;                                /* [N,K] ascending                           */
   float* pts_new;                              /* [N*K,3] o + d*z_new, or NULL              */
 } NudfUpsample;
 #define NUDF_UP_THEORICAL 256
+#define NUDF_UP_SERIAL 512      /* the three scans in torch-CPU order: one running DOUBLE accumulator per row, every output
+                                   rounded to float (cumprod / cumsum of a float tensor on the CPU); default: wave-parallel
+                                   fp32 scans (what the same torch ops do on a GPU) */
+#define NUDF_UP_NOCONTRACT 1024 /* kernel build without floating-point contraction: every product / sum of the reference's
+                                   op chain rounded separately, as separate torch ops round them */
 int nudf_upsample(const NudfUpsample* args, void* stream);
 int nudf_merge(const float* z, const float* udf, const float* z_new, const float* udf_new, int N, int M,
                int K, float* z_out, float* udf_out, void* stream);

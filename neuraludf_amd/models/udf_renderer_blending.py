@@ -23,8 +23,17 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+import os
+
 from .._lib import Composite, CompositeGrad, Upsample, call, ptr
 from .. import dist as nudf_dist
+
+# Arithmetic of the up-sampling kernel (include/nudf.h): 512 = NUDF_UP_SERIAL, the three scans accumulated serially in
+# double like torch's CPU cumprod / cumsum; 1024 = NUDF_UP_NOCONTRACT, no floating-point contraction (separate torch ops
+# round separately).  Together they reproduce the CPU reference's weights on rays that miss the surface, whose pdf sits on
+# sample_pdf's 1e-5 floor and turns 1e-7 of scan noise into 1 % (profiles/r03_parity_localisation.txt).  NUDF_UP_FLAGS=0
+# restores the wave-parallel fp32 scans of rounds 1-2 (what the same ops do on a GPU).
+UPSAMPLE_FLAGS = int(os.environ.get("NUDF_UP_FLAGS", str(512 | 1024)))
 
 _DIAG = ["alpha", "alpha_plus", "alpha_minus", "vis_prob", "alpha_occ", "raw_occ", "true_cos", "grad_mag", "mid_z",
          "dists", "inside", "flip"]
@@ -293,7 +302,7 @@ class UDFRendererBlending:
         a = Upsample()
         a.rays_o, a.rays_d, a.z, a.udf = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf)
         a.u, a.sample_dist, a.gamma_dev = ptr(self._quantiles(k, dev)), ptr(sample_dist), ptr(gamma_dev)
-        a.N, a.M, a.K, a.mode = N, M, k, mode | (256 if self.sdf2alpha_type == 'theorical' else 0)   # NUDF_UP_THEORICAL
+        a.N, a.M, a.K, a.mode = N, M, k, mode | (256 if self.sdf2alpha_type == 'theorical' else 0) | UPSAMPLE_FLAGS
         a.inv_s, a.beta, a.gamma = float(inv_s), float(beta), float(gamma)
         z_new = torch.empty(N, k, device=dev)
         pts_new = torch.empty(N * k, 3, device=dev)

@@ -278,21 +278,28 @@ def test_cfg3_garment_geometry_1024_rays_vs_reference(dev):
 
 
 def test_cfg2_end_to_end_matching_rays_and_first_divergence(dev, setup):
+    from neuraludf_amd.models import udf_renderer_blending as urb
     fx, mods, sds, rend, rays = setup
     N = 512
-    with torch.no_grad():
-        out = rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
-                          perturb_overwrite=0, flip_saturation=0.9)
     z_ref = torch.from_numpy(fx["out_z_vals"])
-    zerr = (out["z_vals"].cpu() - z_ref).abs().max(dim=1)[0]
-    good = zerr < 1e-4
+    default_flags = urb.UPSAMPLE_FLAGS
+
+    def end_to_end():
+        with torch.no_grad():
+            out = rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                              perturb_overwrite=0, flip_saturation=0.9)
+        good = (out["z_vals"].cpu() - z_ref).abs().max(dim=1)[0] < 1e-4
+        mse = float(((out["color"].cpu() - torch.from_numpy(fx["out_color"])) ** 2).mean())
+        return out, good, 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-20))
+
+    out, good, psnr = end_to_end()
     frac = float(good.float().mean())
     for k in ["color", "color_base", "depth", "weight_sum"]:
         assert rel(out[k][good.to(dev)], torch.from_numpy(fx["out_" + k])[good]) < 1e-4, k
-    mse = float(((out["color"].cpu() - torch.from_numpy(fx["out_color"])) ** 2).mean())
-    psnr = 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-20))
+    wmax = float((out["weights"].cpu()[good] - torch.from_numpy(fx["out_weights"])[good]).abs().max())
 
-    # ---- localisation: replay every round of the oracle's trace ----
+    # ---- localisation: replay every round of the oracle's trace, for every arithmetic variant of the up-sampling
+    # kernel: scans (wave-parallel fp32 tree | serial double accumulator = torch CPU order) x contraction (on | off) ----
     cpu = {k: v.cpu() for k, v in rays.items()}
     cfg = O.RenderCfg(**{k: v for k, v in KW.items() if k != "perturb"})
     on = oracle_nets(sds)
@@ -305,27 +312,39 @@ def test_cfg2_end_to_end_matching_rays_and_first_divergence(dev, setup):
     # below uses this host's trace, which is self-consistent.
     host_ok = int(((z_oracle - z_ref).abs().max(dim=1)[0] < 1e-4).sum())
     sdd = torch.tensor([sd], device=dev)
-    lines = []
-    first = None
-    for i, t in enumerate(trace):
-        k = t["z_new"].shape[1]
-        mode = 0 if t["kind"] == "unbias" else 1
-        zt, ut = t["z"].to(dev), t["udf"].to(dev)
-        with torch.no_grad():
-            z_a, _ = rend._upsample(rays["rays_o"], rays["rays_d"], zt, ut, sdd, k, mode, t["inv_s"], t["beta"], t["gamma"])
-            u_hip = rend._udf_at(rays["rays_o"], rays["rays_d"], zt, sdd)
-            z_b, _ = rend._upsample(rays["rays_o"], rays["rays_d"], zt, u_hip, sdd, k, mode, t["inv_s"], t["beta"], t["gamma"])
-        bad_a = int(((z_a.cpu() - t["z_new"]).abs().max(dim=1)[0] > 1e-4).sum())
-        bad_b = int(((z_b.cpu() - t["z_new"]).abs().max(dim=1)[0] > 1e-4).sum())
-        du = float((u_hip.cpu() - t["udf"]).abs().max())
-        lines.append(f"round {i}: {zt.shape[1]:3d} -> +{k} samples | rays moved by the up-sampling kernel alone (oracle udf in): "
-                     f"{bad_a:3d} / {N} | with the HIP MLP's udf at the oracle's positions: {bad_b:3d} / {N} | max |udf_hip - udf_oracle| "
-                     f"{du:.2e}")
-        if first is None and (bad_a or bad_b):
-            first = i
-    report = [f"cfg2 512 x 128 end to end vs the reference: {int(good.sum())} / {N} rays with identical samples ({100 * frac:.1f} %), "
-              f"colour PSNR over all rays {psnr:.1f} dB, first diverging round: {first}",
-              f"the CPU oracle re-run on this host reproduces the fixture's samples on {host_ok} / {N} rays"] + lines
+    variants = [("tree scans, contraction on (rounds 1-2)", 0), ("serial double scans, contraction on", 512),
+                ("tree scans, contraction off", 1024), ("serial double scans, contraction off", 512 | 1024)]
+    report = [f"cfg2 512 x 128 end to end vs the reference (default flags {default_flags}): {int(good.sum())} / {N} rays with "
+              f"identical samples ({100 * frac:.1f} %), colour PSNR over all rays {psnr:.1f} dB, max |dweights| on those rays {wmax:.2e}",
+              f"the CPU oracle re-run on this host reproduces the fixture's samples on {host_ok} / {N} rays"]
+    moved_default = None
+    try:
+        for name, flags in variants:
+            urb.UPSAMPLE_FLAGS = flags
+            lines, worst = [], 0.0
+            for i, t in enumerate(trace):
+                k = t["z_new"].shape[1]
+                mode = 0 if t["kind"] == "unbias" else 1
+                zt, ut = t["z"].to(dev), t["udf"].to(dev)
+                with torch.no_grad():
+                    z_a, _ = rend._upsample(rays["rays_o"], rays["rays_d"], zt, ut, sdd, k, mode, t["inv_s"], t["beta"], t["gamma"])
+                    u_hip = rend._udf_at(rays["rays_o"], rays["rays_d"], zt, sdd)
+                    z_b, _ = rend._upsample(rays["rays_o"], rays["rays_d"], zt, u_hip, sdd, k, mode, t["inv_s"], t["beta"], t["gamma"])
+                da = (z_a.cpu() - t["z_new"]).abs().max(dim=1)[0]
+                bad_a, exact_a = int((da > 1e-4).sum()), int((da == 0).sum())
+                bad_b = int(((z_b.cpu() - t["z_new"]).abs().max(dim=1)[0] > 1e-4).sum())
+                du = float((u_hip.cpu() - t["udf"]).abs().max())
+                worst = max(worst, float(da.max()))
+                lines.append(f"   round {i}: {zt.shape[1]:3d} -> +{k} samples | oracle udf in: {bad_a:3d} / {N} rays moved > 1e-4, {exact_a:3d} "
+                             f"bit-identical | HIP MLP's udf at the oracle's positions: {bad_b:3d} moved | max |udf_hip - udf_oracle| {du:.2e}")
+                if flags == default_flags and i == 0:
+                    moved_default = bad_a
+            _, g2, p2 = end_to_end()
+            report.append(f"{name} (flags {flags}): end to end {int(g2.sum())} / {N} rays identical, PSNR {p2:.1f} dB, worst |dz| with the "
+                          f"oracle's udf {worst:.2e}")
+            report += lines
+    finally:
+        urb.UPSAMPLE_FLAGS = default_flags
     print("\n".join(report))
     try:
         os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
