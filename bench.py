@@ -18,8 +18,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
                   committed rocprofv3 PMC passes over this command (profiles/r02_traffic_mlp_chain.json).
   roofline_composite -- the fused sample+composite kernels against the 8 TB/s HBM roof
                   (48 B/sample + 68 B/ray forward, 84 B/sample + 68 B/ray backward).
-  cpu_baseline -- the CPU oracle (a port of the reference's PyTorch path) timed on this host's
-                  cores on a bounded sample of the same workload.
+  cpu_baseline -- the reference's own classes (oracle/_ref/reference_tree, kind "reference"; the oracle's port when that
+                  tree is absent) timed on this host's cores, one pinned thread per physical core, on a bounded sample of
+                  the same workload.
 """
 import argparse
 import json
@@ -54,12 +55,40 @@ WORKLOADS = {
 BLEND_WORKLOADS = {"garment_blend_1024x128": dict(color_pixel_weight=0.5, color_patch_weight=0.1)}
 
 
+def _cpu_info():
+    """(cpu model string, logical CPUs one per physical core within this process's affinity)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    firsts, seen = [], set()
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            firsts.append(c)
+    return model, firsts
+
+
 def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_rays=None):
-    """the oracle's full train step (fwd + loss + bwd + Adam) on the host cores, bounded sample; and, with `dev`, the
-    second half of BASELINE's metric: PSNR of the HIP path's colours against the oracle's on the same rays and weights
-    (the oracle is the checker here, nothing else)."""
+    """The CPU leg of BASELINE's metric: one full train step (render + loss + backward + Adam) on the host cores, on a
+    bounded sample of the timed workload.  kind "reference": the reference's OWN UDFRendererBlending / ColorLoss classes
+    + torch.optim.Adam, imported from oracle/_ref/reference_tree (the git-ignored copy oracle/make_ref_tree.py stages in
+    the build container; it travels with the gpurun snapshot -- /root/reference itself is never read here); kind "port":
+    the oracle's restatement, when that tree is absent.  Threads are pinned one per physical core (<= 32, the fastest of a
+    few counts on a probe pass: more threads than that only slow these small ops down).  With `dev` also the second half of
+    the metric: PSNR of the HIP path's colours (and the weights) against the oracle's on the same rays and weights (the
+    oracle is the checker here, nothing else)."""
     from neuraludf_amd import synth
-    from neuraludf_amd.train import DTU_MODEL_CONF  # noqa: F401
+    from neuraludf_amd.train import DTU_MODEL_CONF
     from oracle import udf_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     rays_cfg, rconf, scene_kind = WORKLOADS[workload]
@@ -74,8 +103,6 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
                      for k in ("udf", "color", "var", "beta", "nerf")})
     nets.beta["gamma"].requires_grad_(False)
     nets.beta["zeta"].requires_grad_(False)
-    params = [t for d in (nets.udf, nets.color, nets.var, nets.beta, nets.nerf) for t in d.values() if t.requires_grad]
-    opt = torch.optim.Adam(params, lr=5e-4)
     cfg = O.RenderCfg(**{k: v for k, v in rconf.items() if k != "perturb"})
     scene = synth.make_scene(scene_kind)
     rays = synth.make_rays(scene, 0, n_rays, seed=1234)
@@ -90,56 +117,119 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
         with torch.no_grad():
             got = rend.render(rays["rays_o"].to(dev), rays["rays_d"].to(dev), rays["near"].to(dev), rays["far"].to(dev),
                               cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
-            got = {k: got[k].cpu() for k in ("color", "z_vals")}
+            got = {k: got[k].cpu() for k in ("color", "z_vals", "weights")}
             ref = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
                            flip_saturation=1.0)
         mse = float(((got["color"] - ref["color"]) ** 2).mean())          # exp_runner_blending.py:341-342 with mask = 1
-        same = (got["z_vals"] - ref["z_vals"]).abs().max(dim=1)[0] < 1e-4
+        dz = (got["z_vals"] - ref["z_vals"]).abs()
+        same = dz.max(dim=1)[0] < 1e-4
+        dw = (got["weights"] - ref["weights"]).abs()
+        moved = dz >= 1e-4                                                 # individual samples at other positions
+        wsum = float(ref["weights"].sum())
         psnr = {"value_db": 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-30)),
                 "max_abs_diff": float((got["color"] - ref["color"]).abs().max()),
                 "max_abs_diff_on_rays_with_identical_samples": float((got["color"] - ref["color"])[same].abs().max()) if bool(same.any()) else None,
+                "weights_max_abs_diff_on_rays_with_identical_samples": float(dw[same].max()) if bool(same.any()) else None,
+                "weights_max_abs_diff": float(dw.max()),
+                "weight_mass_on_moved_samples": (float(ref["weights"][:, :moved.shape[1]][moved].sum()) / wsum) if wsum > 0 else None,
                 "rays": n_rays, "rays_with_identical_samples": int(same.sum()), "samples_per_ray": s_core, "precision": precision,
-                "what": "HIP colours vs oracle colours END TO END on identical rays / weights: the hierarchical sampling runs "
-                        "on both sides, so rays whose quantile bins flip (tests/test_gpu_fullsize_parity.py) enter with "
-                        "different sample positions"}
+                "what": "HIP colours / weights vs the oracle's END TO END on identical rays / network weights: the hierarchical "
+                        "sampling runs on both sides, so rays whose quantile bins flip (tests/test_gpu_fullsize_parity.py) enter "
+                        "with different sample positions; weight_mass_on_moved_samples = share of the reference's total "
+                        "compositing weight that sits on samples whose position differs by >= 1e-4"}
 
-    def step():
-        t_rand = torch.rand(n_rays, 1) - 0.5
-        out = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
-                       flip_saturation=1.0, t_rand=t_rand,
-                       t_rand_out=torch.rand(cfg.n_outside) if cfg.n_outside else None)
-        cl = O.color_loss(0.01, 1.0, 0.0, 0.0, 3, out["color_base"], out["color"], rays["true_rgb"], None, None,
-                          None, None, None)
-        loss = cl["loss"] + 0.1 * out["gradient_error"]
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+    # ---- the timed CPU step ----
+    import refload
+    kind = "reference" if refload.have_reference(refload.REF_TREE) else "port"
+    if kind == "reference":
+        import contextlib
+        import io
+        rf, rr, rl = refload.load_reference(refload.REF_TREE)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rmods = build_modules(rf, seed=0)                # the reference's own classes, the runner's order and seed
+            rrend = rr.UDFRendererBlending(rmods["nerf"], rmods["udf"], rmods["var"], rmods["color"], rmods["beta"], **rconf)
+            crit = rl.ColorLoss(color_base_weight=0.01, color_weight=1.0, color_pixel_weight=0.0, color_patch_weight=0.0,
+                                pixel_loss_type="l1", patch_loss_type="ssim", h_patch_size=3)
+        geo = list(rmods["udf"].parameters())
+        other = list(rmods["var"].parameters()) + list(rmods["color"].parameters()) + list(rmods["beta"].parameters())
+        opt = torch.optim.Adam([{"params": geo, "lr": 1e-4}, {"params": other}, {"params": list(rmods["nerf"].parameters())}],
+                               lr=5e-4)                      # exp_runner_blending.py:136-139
 
-    # thread count: all cores is pathological for these small ops on a many-core host (256 threads ->
-    # >100 s/step measured); pick the fastest of a few settings on one forward pass, then time full steps
+        def step():
+            with contextlib.redirect_stdout(io.StringIO()):
+                out = rrend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
+                                   flip_saturation=1.0)
+                cl = crit(out["color_base"], out["color"], rays["true_rgb"], out["color_pixel"], None, out["patch_colors"],
+                          None, None)
+            loss = cl["loss"] + 0.1 * out["gradient_error"]   # exp_runner_blending.py:367-371 with the bench's weights
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        def probe():          # (the reference's render differentiates inside: no no_grad here)
+            with contextlib.redirect_stdout(io.StringIO()):
+                rrend.render(rays["rays_o"][:16], rays["rays_d"][:16], rays["near"][:16], rays["far"][:16],
+                             cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
+        what = "oracle/_ref/reference_tree: the reference's UDFRendererBlending + ColorLoss + torch.optim.Adam"
+    else:
+        params = [t for d in (nets.udf, nets.color, nets.var, nets.beta, nets.nerf) for t in d.values() if t.requires_grad]
+        opt = torch.optim.Adam(params, lr=5e-4)
+
+        def step():
+            t_rand = torch.rand(n_rays, 1) - 0.5
+            out = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
+                           flip_saturation=1.0, t_rand=t_rand,
+                           t_rand_out=torch.rand(cfg.n_outside) if cfg.n_outside else None)
+            cl = O.color_loss(0.01, 1.0, 0.0, 0.0, 3, out["color_base"], out["color"], rays["true_rgb"], None, None,
+                              None, None, None)
+            loss = cl["loss"] + 0.1 * out["gradient_error"]
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        def probe():
+            with torch.no_grad():
+                O.render(nets, cfg, rays["rays_o"][:16], rays["rays_d"][:16], rays["near"][:16], rays["far"][:16],
+                         cos_anneal_ratio=1.0, flip_saturation=1.0)
+        what = "oracle/udf_oracle.py (a port of the reference's PyTorch path; oracle/_ref/reference_tree absent)"
+
+    # one thread per PHYSICAL core, pinned; all cores is pathological for these small ops on a many-core host (256 threads
+    # -> > 100 s/step measured), so the fastest of a few counts on a probe pass is used
+    model, cores = _cpu_info()
+    old_aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    old_threads = torch.get_num_threads()
     best = None
-    for nt in sorted({min(os.cpu_count() or 1, c) for c in (8, 16, 32, 64)}):
-        torch.set_num_threads(nt)
-        with torch.no_grad():
+    try:
+        for nt in sorted({min(len(cores), c) for c in (8, 16, 32)}):
+            if old_aff is not None:
+                os.sched_setaffinity(0, set(cores[:nt]))
+            torch.set_num_threads(nt)
+            probe()
             t0 = time.time()
-            O.render(nets, cfg, rays["rays_o"][:16], rays["rays_d"][:16], rays["near"][:16], rays["far"][:16],
-                     cos_anneal_ratio=1.0, flip_saturation=1.0)
+            probe()
             dtt = time.time() - t0
-        if best is None or dtt < best[0]:
-            best = (dtt, nt)
-    torch.set_num_threads(best[1])
-    step()  # warm-up
-    times = []
-    t_start = time.time()
-    while len(times) < 40 and (len(times) < 3 or (time.time() - t_start) < seconds_budget):
-        t0 = time.time()
-        step()
-        times.append(time.time() - t0)
+            if best is None or dtt < best[0]:
+                best = (dtt, nt)
+        nt = best[1]
+        if old_aff is not None:
+            os.sched_setaffinity(0, set(cores[:nt]))
+        torch.set_num_threads(nt)
+        step()  # warm-up
+        times = []
+        t_start = time.time()
+        while len(times) < 40 and (len(times) < 3 or (time.time() - t_start) < seconds_budget):
+            t0 = time.time()
+            step()
+            times.append(time.time() - t0)
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
+        torch.set_num_threads(old_threads)
     times.sort()
     med = times[len(times) // 2]
-    res = {"value": n_rays * s_core / med, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
-           "kind": "port", "rays": n_rays, "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps "
-                                     f"(oracle/udf_oracle.py, fp32, median {med:.3f} s/step)"}
+    res = {"value": n_rays * s_core / med, "unit": "ray-samples/s", "cores": nt, "kind": kind, "rays": n_rays,
+           "cpu_model": model, "physical_cores_available": len(cores), "pinned": old_aff is not None,
+           "sample": f"{n_rays} rays x {s_core} samples, {len(times)} full train steps, fp32, median {med:.3f} s/step ({what})"}
     return res, psnr
 
 
@@ -284,12 +374,18 @@ def main():
         barrier()
         prof, mlp.PROFILE = mlp.PROFILE, None
     if rank == 0 and not args.no_roofline:
-        agg = {}
-        for name, flops, s, e in prof:
+        agg, per = {}, {}
+        for name, flops, s, e, detail, nbytes in prof:
+            dur = s.elapsed_time(e) * 1e-3
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
-            a[2] += s.elapsed_time(e) * 1e-3
+            a[2] += dur
+            b = per.setdefault(detail, [name, 0, 0.0, 0.0, 0.0])
+            b[1] += 1
+            b[2] += flops
+            b[3] += dur
+            b[4] += nbytes
         dom = max(agg, key=lambda k: agg[k][2])
         n, fl, sec = agg[dom]
         peak = MFMA_F32_PEAK_TFLOPS if (args.precision == "fp32" or dom != "mlp_chain") else MFMA_F16_PEAK_TFLOPS
@@ -301,6 +397,19 @@ def main():
             # the class is several instantiations in a rocprofv3 summary: sum them when comparing the average duration
             result["roofline"]["kernel_names"] = ["mlp_chain_tq_kernel<0|1|2> (UDF sweeps, > 16384 points, fp32)",
                                                   "mlp_chain_kernel<64|32, false|true> (all other chain launches)"]
+        # every MFMA launch class of the step on its own: instantiation + sweep + size, launches, algorithmic GFLOP, summed
+        # HIP-event time, and BOTH roofs -- MFMA (fp32 157.3 TFLOP/s, or 2.5 PFLOP/s for 16-bit chains) and HBM (the
+        # launch's algorithmic stored-state bytes, every operand / output array once, against 8 TB/s); "binding" names the
+        # larger of the two floors, i.e. the roof that launch could at best run into
+        pk = []
+        for detail, (name, cnt, f, t, by) in sorted(per.items(), key=lambda kv: -kv[1][3]):
+            pkp = MFMA_F32_PEAK_TFLOPS if (args.precision == "fp32" or name != "mlp_chain") else MFMA_F16_PEAK_TFLOPS
+            t_mfma, t_hbm = f / (pkp * 1e12), by / (HBM_PEAK_GBS * 1e9)
+            pk.append({"kernel": detail, "class": name, "launches": cnt, "gflop": f / 1e9, "us": t * 1e6,
+                       "tflops": f / t / 1e12, "frac_mfma": f / t / 1e12 / pkp,
+                       "algorithmic_mb": by / 1e6, "gbs": by / t / 1e9, "frac_hbm": by / t / 1e9 / HBM_PEAK_GBS,
+                       "binding": "hbm" if t_hbm > t_mfma else "mfma", "frac_of_binding_roof": max(t_mfma, t_hbm) / t})
+        result["roofline"]["per_kernel"] = pk
         result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
                                  "tflops": v[1] / v[2] / 1e12} for k, v in agg.items()}
         result["roofline"]["traffic"] = pmc_traffic(dom, args.workload, args.precision)
@@ -338,7 +447,7 @@ def pmc_traffic(kernel, workload, precision="fp32"):
     timed process from inside, so the counters are collected beforehand; corrected as MI355X_MICROARCH.md
     prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
     if (workload, precision) == ("dtu_scan24_512x128", "fp32"):
-        names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (2, 1)]
+        names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (3, 2, 1)]
     elif (workload, precision) == ("dtu_scan24_1024x256", "mixed16"):
         names = ["r02_traffic_%s_cfg5_mixed16.json" % kernel]
     else:

@@ -130,13 +130,15 @@ def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=
 PROFILE = None
 
 
-def _timed(name, flops, fn):
+def _timed(name, flops, fn, detail=None, nbytes=0.0):
+    """`detail`: which instantiation / sweep the launch is (bench.py's roofline.per_kernel); `nbytes`: the launch's
+    ALGORITHMIC HBM bytes (stored-state arrays it must read and write once), for the HBM side of its roofline."""
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
     s.record()
     fn()
     e.record()
-    PROFILE.append((name, flops, s, e))
+    PROFILE.append((name, flops, s, e, detail or name, nbytes))
 
 
 def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
@@ -193,6 +195,9 @@ class ChainBuilder:
         self.c.x_div = 1
         self.n = 0
         self.flops = 0.0
+        self.nbytes = 0.0          # algorithmic HBM bytes: every stored-state operand / output of every step, once
+        self.epis = []
+        self.blocked = False
         self.keep = []
 
     def _p(self, t, off=0):
@@ -259,16 +264,41 @@ class ChainBuilder:
         s.scale, s.xscale = scale, xscale
         self.n += 1
         self.flops += 2.0 * self.c.P * getattr(Bp, "k_true", K) * getattr(Bp, "n_true", N)
+        if PROFILE is not None:
+            n_true = getattr(Bp, "n_true", N)
+            for t in (X1, X2, C1, C2, pe_dst):
+                if t is not None:
+                    self.nbytes += float(self.c.P) * (min(n_true, t.shape[1]) if t.dim() == 2 else 1) * t.element_size()
+            self.epis.append(epi)
+            self.blocked = self.blocked or (s.layout & 31) != 0
 
     def launch(self):
         self.c.n_steps = self.n
         if CHAIN_DEBUG is not None:
             self.c.dbg = ptr(CHAIN_DEBUG)
         if PROFILE is not None:
-            _timed("mlp_chain", self.flops, lambda: call("nudf_mlp_chain", self.c))
+            _timed("mlp_chain", self.flops, lambda: call("nudf_mlp_chain", self.c), self._label(), self.nbytes)
         else:
             call("nudf_mlp_chain", self.c)
         self.keep = []
+
+    def _label(self):
+        """kernel instantiation nudf_mlp_chain dispatches this launch to (mirrors csrc/mlp_chain.hip) + the sweep."""
+        P, e = self.c.P, set(self.epis)
+        x1 = bool(e & {"MULSP", "TANGENT", "BWD", "MULMASK", "ADDMASK"})
+        x2 = bool(e & {"TANGENT", "BWD", "ADDMASK", "RELUADD"})
+        if self.blocked or self.c.tile_rows == 66:
+            kern = "mlp_chain_tq_kernel<%d>" % (2 if x2 else (1 if x1 else 0))
+        elif self.c.tile_rows == 128:
+            kern = "mlp_chain_rows_kernel"
+        else:
+            any16 = PRECISION != "fp32"
+            t32 = self.c.tile_rows == 32 or (self.c.tile_rows != 64 and P <= 256 * 64)
+            kern = "mlp_chain_kernel<%d, %s>" % (32 if t32 else 64, "true" if any16 else "false")
+        sweep = ("tangent" if "TANGENT" in e else "adjoint" if "BWD" in e else "input-gradient" if "MULSP" in e
+                 else "relu-backward" if e & {"MULMASK", "ADDMASK"} else "udf-forward" if "SOFTPLUS" in e
+                 else "relu-forward")
+        return "%s %s P=%d" % (kern, sweep, P)
 
 
 # scratch of the weight-gradient GEMMs' deterministic two-pass reduction (every workgroup's partial tile, ~33 MB at the
@@ -295,18 +325,20 @@ def gemm_tn_grouped(jobs, M):
         g = _lib.GemmTNGroup()
         g.n_problems, g.M, g.rows_per_block = len(chunk), M, 0
         g.prec = 0 if PRECISION == "fp32" else 2       # mixed16: bf16 operands for the weight gradients as well
-        flops = 0.0
+        flops = nbytes = 0.0
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
             q.A1, q.B1, q.C, q.dbias = ptr(A1), ptr(B1), ptr(Cm), ptr(db)
             q.flags = (1 if _is16(A1) else 0) | (2 if _is16(B1) else 0) | (4 if _isblk(A1) else 0) | (8 if _isblk(B1) else 0)
             q.lda1, q.ldb1, q.ldc, q.NA, q.NB = A1.shape[1], B1.shape[1], Cm.shape[1], NA, NB
             flops += 2.0 * M * NA * NB
+            nbytes += float(M) * (NA * A1.element_size() + NB * B1.element_size())
         if TN_DETERMINISTIC:
             ws, n = _tn_workspace(g, chunk[0][0].device)
             g.workspace, g.workspace_floats = ptr(ws), n
         if PROFILE is not None:
-            _timed("gemm_tn", flops, lambda: call("nudf_gemm_tn_grouped", g))
+            _timed("gemm_tn", flops, lambda: call("nudf_gemm_tn_grouped", g),
+                   "gemm_tn_group_kernel %d problems M=%d (%.1f GFLOP)" % (len(chunk), M, flops / 1e9), nbytes)
         else:
             call("nudf_gemm_tn_grouped", g)
 

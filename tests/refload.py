@@ -7,15 +7,19 @@ import types
 import warnings
 
 REF_ROOT = "/root/reference"
+# git-ignored copy of the reference's runner / models / loss made by oracle/make_ref_tree.py in the build container; it
+# travels to the GPU box with the gpurun snapshot (where /root/reference does not exist)
+REF_TREE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "reference_tree")
 
 
-def have_reference() -> bool:
-    return os.path.isdir(os.path.join(REF_ROOT, "models"))
+def have_reference(root=None) -> bool:
+    return os.path.isdir(os.path.join(root or REF_ROOT, "models"))
 
 
-def load_reference():
-    """Returns (fields_module, renderer_module, loss_module) of the reference."""
-    if not have_reference():
+def load_reference(root=None):
+    """Returns (fields_module, renderer_module, loss_module) of the reference under `root` (default /root/reference)."""
+    REF_ROOT = root or globals()["REF_ROOT"]
+    if not have_reference(REF_ROOT):
         raise RuntimeError("reference tree not present")
     warnings.filterwarnings("ignore")
     for name in ["mcubes", "icecream", "skimage", "skimage.measure", "termcolor"]:
