@@ -210,3 +210,16 @@ class RayBatchSource:
         src_idx = self.ref_src_pair[img_idx][:num]
         return (self.pose_all[img_idx], self.pose_all[src_idx], self.intrinsics_all[src_idx],
                 self.images[src_idx].permute(0, 3, 1, 2), [self.W, self.H])
+
+    def src_w2cs(self, img_idx, num=8):
+        """world-to-camera matrices of the `num` source views of image `img_idx`: the runner calls
+        ``torch.inverse(src_c2ws)`` every iteration (exp_runner_blending.py:283-285, flagged "very slow" there); the poses
+        are constants, so all of them are inverted ONCE (same torch.inverse, same values) and the per-iteration work is
+        an index select."""
+        if isinstance(img_idx, torch.Tensor):
+            img_idx = int(img_idx.item())
+        if getattr(self, "_w2c_all", None) is None or self._w2c_all.device != self.pose_all.device:
+            self._w2c_all = torch.inverse(self.pose_all)
+        if not hasattr(self, "ref_src_pair"):
+            self.prepare_ref_src_pairs()
+        return self._w2c_all[self.ref_src_pair[img_idx][:num]]

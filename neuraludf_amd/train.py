@@ -170,7 +170,7 @@ class Trainer:
         blend = None
         if a["color_pixel_weight"] > 0.0 or a["color_patch_weight"] > 0.0:
             ref_c2w, src_c2ws, src_intr, src_images, _ = source.get_ref_src_info(img_idx, num_src)
-            blend = dict(color_maps=src_images, w2cs=torch.inverse(src_c2ws), intrinsics=src_intr, query_c2w=ref_c2w)
+            blend = dict(color_maps=src_images, w2cs=source.src_w2cs(img_idx, num_src), intrinsics=src_intr, query_c2w=ref_c2w)
         loss, out = self.step(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
                               blend=blend)
         self._trainability_toggles(out, iter_step)

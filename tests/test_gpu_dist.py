@@ -112,3 +112,21 @@ def test_two_rank_step_rccl(tmp_path):
     assert abs(got["loss"] - loss) < 1e-5 * max(1.0, abs(loss)), (got["loss"], loss)
     assert float((got["grads"] - flat).abs().max()) < 2e-4 * float(flat.abs().max())
     assert got["collectives"] == {"all_reduce": 2, "all_gather": 0}, got["collectives"]
+
+
+def test_bench_two_rank_flow_rccl():
+    """the driver's 2-GPU launch line of bench.py over RCCL itself (backend "nccl"): needs two GPUs (skipped on one-GPU
+    boxes).  The line must say that both ranks ran over RCCL -- `rccl_ranks == n_gpus` -- so that the first SCALE run
+    checks itself, and hold exactly two collectives per step."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "nccl", d
+    assert d["config"]["global_rays"] == 1024 and d["scaling"] == "weak"
+    assert d["collectives_per_step"] == {"all_reduce": 2.0, "all_gather": 0.0}

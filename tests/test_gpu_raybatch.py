@@ -63,6 +63,11 @@ def test_ref_src_pairs_match_reference():
     ref_c2w, c2ws, intr, imgs, wh = src.get_ref_src_info(1, num=2)
     assert c2ws.shape == (2, 4, 4) and intr.shape == (2, 4, 4) and imgs.shape == (2, 3, src.H, src.W) and wh == [src.W, src.H]
     assert torch.equal(imgs[0].permute(1, 2, 0), src.images[pairs[1][0]])
+    # the cached world-to-camera matrices replace the runner's per-iteration torch.inverse(src_c2ws) (:283-285)
+    w2c = src.src_w2cs(1, num=2)
+    assert w2c.shape == (2, 4, 4) and float((w2c - torch.inverse(c2ws)).abs().max()) < 1e-6
+    assert float((w2c @ c2ws - torch.eye(4, device=w2c.device)).abs().max()) < 1e-5
+    assert src.src_w2cs(1, num=2).data_ptr() != 0 and src._w2c_all.shape == src.pose_all.shape
 
 
 def test_full_size_vs_oracle():
