@@ -53,9 +53,15 @@ def test_udf_engine_twice_in_one_backward_under_a_grad_bucket():
         p.grad.zero_()
     _loss_two_evaluations(net, xa, xb, wa, wb).backward()
     check(1.0, "after zero_grad(set_to_none=False)")
-    # (d) the fast path is back after a reset to None
+    # (d) the fast path is back after a reset to None: ONE evaluation per step (what Trainer.step does) writes straight
+    # into the bucket and autograd installs the views as p.grad
     for p in net.parameters():
         p.grad = None
-    _loss_two_evaluations(net, xa, xb, wa, wb).backward()
-    check(1.0, "after set_to_none")
+    ref.zero_grad(set_to_none=True)
+    ua, fa, ga = ref.evaluate(xa, want_grad=True)
+    ((ua * wa[:, 0]).sum() + (fa[:, :256] * wa[:, 1:257]).sum() + (ga * wa[:, 257:260]).sum()).backward()
+    ua, fa, ga = net.evaluate(xa, want_grad=True)
+    ((ua * wa[:, 0]).sum() + (fa[:, :256] * wa[:, 1:257]).sum() + (ga * wa[:, 257:260]).sum()).backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p.grad, q.grad), n              # same kernels, same order: bit-identical
     assert all(lo <= p.grad.data_ptr() < hi for p in net.parameters())

@@ -233,12 +233,22 @@ def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays):
     pm_ref = torch.from_numpy(fx["out_patch_mask"])                 # per-ray weight of the valid patch samples
     agree = float(((out["patch_mask"].detach().cpu().reshape(pm_ref.shape) - pm_ref).abs() < 1e-3).float().mean())
     assert agree > 0.995, agree                        # a sample exactly on a view's validity border may flip
+    # The alpha of a sample is a hard selection between two candidates (udf_renderer_blending.py:414-423): where they tie to
+    # an ulp, fp32 implementations may select differently and that ray's later weights shift by ~1e-3 (its colour by
+    # ~1e-5) -- see test_cfg5_shape_fp32_vs_reference.  Such rays are counted (<= 3), per-sample arrays compared on the rest.
+    wd = (out["weights"].detach().cpu() - torch.from_numpy(fx["out_weights"])).abs().max(dim=1)[0]
+    ok = wd < 1e-4
+    n_flip = int((~ok).sum())
+    assert n_flip <= 3, (n_flip, float(wd.max()))
     worst_v = ("", 0.0)
     for k in ["color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum", "gradient_error",
               "gradient_error_near_surface", "color_pixel", "patch_colors"]:
         if "out_" + k not in fx:
             continue          # the 1024-ray fixture holds no [N, S, 3] arrays
-        r = rel(out[k].reshape(fx["out_" + k].shape), fx["out_" + k])
+        a, b = out[k].detach().cpu().reshape(fx["out_" + k].shape), torch.from_numpy(fx["out_" + k])
+        if k in ("weights", "depth", "normals", "weight_sum") and n_flip:
+            a, b = a[ok], b[ok]
+        r = rel(a, b)
         if r > worst_v[1]:
             worst_v = (k, r)
         assert r < (3e-4 if k in ("color_pixel", "patch_colors") else VTOL), (k, r)
@@ -256,7 +266,8 @@ def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays):
                 worst = (key, r)
             assert r < 2e-3, (key, r)          # the trimmed patch loss drops / keeps whole rays: one flipped ray is ~1e-3
     assert n >= 50
-    print(f"cfg3 mix + blending, {n_rays} rays, scene '{scene_kind}' ({scene.H} x {scene.W}): patch-mask agreement {agree:.4f}, "
+    print(f"cfg3 mix + blending, {n_rays} rays, scene '{scene_kind}' ({scene.H} x {scene.W}): rays with a flipped alpha selection "
+          f"{n_flip}, patch-mask agreement {agree:.4f}, "
           f"worst value {worst_v[0]} {worst_v[1]:.2e}, {n} parameter gradients vs the reference, worst {worst[0]} {worst[1]:.2e}")
 
 
