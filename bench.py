@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the extra forward-only timing (profiling runs)")
     ap.add_argument("--fused-adam", type=int, default=1)
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("NUDF_BENCH_GRAPH", "1")),
+                    help="1: the timed steps are replays of the train step captured in a HIP graph (train.GraphedStep: "
+                         "bit-identical to eager steps, one graph launch per step); 0: eager launches")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "mixed16"],
                     help="fp32 = the parity path and the headline; mixed16 = BASELINE config 5 (16-bit MFMA operands, "
                          "fp32 accumulate) -- reported for reference only, never the headline number")
@@ -300,8 +303,16 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    from neuraludf_amd.train import GraphedStep
+    gstep = GraphedStep(tr, eager_steps=2) if args.graph else None
+    use_graph = bool(gstep is not None and gstep.enabled)
+    run_step = (lambda: gstep(batch, **step_kw)) if use_graph else (lambda: tr.step(batch, **step_kw))
+    if use_graph:                      # set-up, not warm-up: two eager steps, then the capture (+ its first replay)
+        for _ in range(3):
+            run_step()
+        assert gstep.replays == 1
     for _ in range(args.warmup):
-        tr.step(batch, **step_kw)
+        run_step()
     torch.cuda.synchronize()
     # A generation-2 pass of Python's cyclic GC over the ~10^6 objects a torch process holds takes ~80 ms of host time
     # (measured, scripts/fwd_only_probe.py: it is what made the forward-only figure of round 1 read 6.26 ms on one box
@@ -316,7 +327,7 @@ def main():
     nd.collective_counts(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.step(batch, **step_kw)
+        run_step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -339,7 +350,10 @@ def main():
         "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
                    "step": "render + L1/eikonal loss + backward + Adam", "parallelism": f"ray-sharded dp{world}",
-                   "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam"},
+                   "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam",
+                   "launch": ("HIP graph replay: one graph launch + one 0.8 KB H2D copy of the step's scalars per step "
+                              "(train.GraphedStep; replays are bit-identical to eager steps, tests/test_gpu_graph.py)")
+                   if use_graph else "eager launches"},
         # data-parallel exchange of the timed region (neuraludf_amd/dist.py): packed loss sums + gradient bucket
         "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend if world > 1 else None,
         "collectives_per_step": {k: v / args.steps for k, v in coll.items()} if world > 1 else None,

@@ -168,6 +168,10 @@ typedef struct NudfComposite {
   float* o_alpha; float* o_alpha_plus; float* o_alpha_minus; float* o_vis_prob;
   float* o_alpha_occ; float* o_raw_occ; float* o_true_cos; float* o_grad_mag;
   float* o_mid_z; float* o_dists; float* o_inside; float* o_flip;
+  const float* sched;                          /* [2] device {cos_anneal_ratio, flip_saturation} overriding the two by-value
+                                                  fields above, or NULL: lets a captured HIP graph of the train step (kernel
+                                                  arguments frozen at capture) follow the per-iteration schedules
+                                                  (exp_runner_blending.py:193-228); has_anneal stays by value            */
 } NudfComposite;
 
 typedef struct NudfCompositeGrad {
@@ -358,6 +362,10 @@ typedef struct NudfAdam {
   int32_t block_start[NUDF_ADAM_MAX_TENSORS + 1]; /* prefix sums of ceil(n / nudf_adam_chunk())  */
   int32_t pad2_;
   NudfAdamGroup group[NUDF_ADAM_MAX_GROUPS];
+  const float* dyn;                               /* NULL, or device [2 * n_tensors]: {neg_step_size, bc2_sqrt} of tensor i at
+                                                     dyn[2 i], dyn[2 i + 1], overriding the by-value fields: the two numbers
+                                                     that change every step (learning-rate schedule, bias corrections), so
+                                                     that a captured HIP graph of the step stays valid               */
 } NudfAdam;
 int nudf_adam_step(const NudfAdam* args, void* stream);
 int nudf_adam_chunk(void);                         /* elements one block updates                  */

@@ -67,7 +67,7 @@ class Composite(C.Structure):
                 ("out_normals", c_fp), ("out_wsum", c_fp), ("out_wsum_all", c_fp), ("sums", c_fp), ("ws", c_fp),
                 ("o_alpha", c_fp), ("o_alpha_plus", c_fp), ("o_alpha_minus", c_fp), ("o_vis_prob", c_fp),
                 ("o_alpha_occ", c_fp), ("o_raw_occ", c_fp), ("o_true_cos", c_fp), ("o_grad_mag", c_fp),
-                ("o_mid_z", c_fp), ("o_dists", c_fp), ("o_inside", c_fp), ("o_flip", c_fp)]
+                ("o_mid_z", c_fp), ("o_dists", c_fp), ("o_inside", c_fp), ("o_flip", c_fp), ("sched", c_fp)]
 
 
 class CompositeGrad(C.Structure):
@@ -122,7 +122,8 @@ class AdamGroup(C.Structure):
 
 class Adam(C.Structure):
     _fields_ = [("n_tensors", i32), ("pad_", i32), ("t", AdamTensor * ADAM_MAX_TENSORS),
-                ("block_start", i32 * (ADAM_MAX_TENSORS + 1)), ("pad2_", i32), ("group", AdamGroup * ADAM_MAX_GROUPS)]
+                ("block_start", i32 * (ADAM_MAX_TENSORS + 1)), ("pad2_", i32), ("group", AdamGroup * ADAM_MAX_GROUPS),
+                ("dyn", c_fp)]
 
 
 CH_MAX_STEPS = 14

@@ -144,8 +144,18 @@ __device__ __forceinline__ void eval_sample(const NudfComposite& p, const RayCon
 
 // FULL: S == 64 * NC, no outside samples, s_nominal >= S -- every lane of every chunk holds a live inside sample, so
 // none of the liveness selects / compares exist in that instantiation (cfg 2 and cfg 5 shapes).
+// Iteration schedules from device memory (NudfComposite.sched): the two by-value scalars that change from iteration to
+// iteration -- cos_anneal_ratio and flip_saturation -- are then read here, so a captured HIP graph of the train step
+// (kernel arguments frozen at capture) follows the schedules.  Uniform scalar loads, once per kernel.
+#define NUDF_COMPOSITE_SCHED(p)                \
+  if ((p).sched) {                             \
+    (p).cos_anneal = (p).sched[0];             \
+    (p).flip_saturation = (p).sched[1];        \
+  }
+
 template <int NC, bool DIAG, bool FULL>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
+  NUDF_COMPOSITE_SCHED(p)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   __shared__ float red[4][5];
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(1024) void partial_sums_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 template <int NC, bool FULL>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, NudfCompositeGrad g) {
+  NUDF_COMPOSITE_SCHED(p)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   __shared__ float red[4][3];
@@ -725,6 +736,7 @@ __device__ __forceinline__ void blk_excl_rsum(const float (&v)[PER], float (&out
 
 template <int PER>
 __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p) {
+  NUDF_COMPOSITE_SCHED(p)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   __shared__ float red[4][5];
@@ -829,6 +841,7 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p)
 
 template <int PER>
 __global__ __launch_bounds__(256) void composite_bwd_blk_kernel(NudfComposite p, NudfCompositeGrad g) {
+  NUDF_COMPOSITE_SCHED(p)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   __shared__ float red[4][3];

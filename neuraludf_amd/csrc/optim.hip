@@ -22,8 +22,12 @@ __global__ __launch_bounds__(ADAM_BLOCK) void adam_kernel(NudfAdam a) {
     const int mid = (lo + hi) >> 1;
     if (a.block_start[mid] <= b) lo = mid; else hi = mid;
   }
-  const NudfAdamTensor t = a.t[lo];
+  NudfAdamTensor t = a.t[lo];
   const NudfAdamGroup g = a.group[t.group];
+  if (a.dyn) {   // per-step scalars from device memory (graph replay): uniform loads
+    t.neg_step_size = a.dyn[2 * lo];
+    t.bc2_sqrt = a.dyn[2 * lo + 1];
+  }
   const int base = (b - a.block_start[lo]) * ADAM_CHUNK;
 #pragma unroll
   for (int k = 0; k < ADAM_PER_THREAD; ++k) {

@@ -129,7 +129,7 @@ class ColorPixelLoss(nn.Module):
                 packed = nudf_dist.all_reduce_sum(torch.stack([num, den]))
                 num, den = packed[0], packed[1]
             return num / (den + 1e-4)
-        cnt = torch.tensor(float(pred.numel()), device=pred.device)
+        cnt = torch.full((), float(pred.numel()), device=pred.device)      # a fill kernel: safe under graph capture
         if self.data_parallel:
             packed = nudf_dist.all_reduce_sum(torch.stack([num, cnt]))
             num, cnt = packed[0], packed[1]

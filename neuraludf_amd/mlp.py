@@ -686,6 +686,12 @@ class UDFEngine:
         for pl in self.layers:
             pl.invalidate()
 
+    def mark_stale(self):
+        """re-pack the weights at the next use, keeping the buffers (train.GraphedStep: the pack launch must be part of
+        the captured step even when a forward-only render packed the current weights just before the capture)."""
+        for pl in self.layers:
+            pl._ver = None
+
     def _embed(self, x, P, X, tangent=None):
         net = self.net
         # layer-0 input, plus the tail of every skip layer's input (cat([x, inputs])/sqrt(2), fields.py:202-203)
@@ -1081,6 +1087,10 @@ class ColorEngine:
         for pl in self.view + self.base:
             pl.invalidate()
 
+    def mark_stale(self):
+        for pl in self.view + self.base:
+            pl._ver = None
+
     @property
     def cin_ld(self):
         return pad32(self.F + 3 + self.nrm)
@@ -1351,6 +1361,10 @@ class NerfEngine:
     def invalidate(self):
         for pl in self._all():
             pl.invalidate()
+
+    def mark_stale(self):
+        for pl in self._all():
+            pl._ver = None
 
     # -- dispatch: fused LDS-resident chains (default) or per-layer GEMM launches -------------------
     def _skip_layer(self):

@@ -47,6 +47,7 @@ def _fill_composite(a, c, N, S, n_out):
     a.use_norm_grad = 1 if c["use_norm_grad"] else 0
     a.sparse_scale = float(c["sparse_scale"])
     a.alpha_type = int(c.get("alpha_type", 0))
+    a.sched = ptr(c.get("sched"))         # device {cos_anneal_ratio, flip_saturation} of a graph-captured step, or NULL
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -390,7 +391,8 @@ class UDFRendererBlending:
         c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,
                  flip_saturation=flip_saturation, use_norm_grad=self.use_norm_grad_for_cosine,
                  sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics,
-                 alpha_type=1 if self.sdf2alpha_type == 'theorical' else 0)
+                 alpha_type=1 if self.sdf2alpha_type == 'theorical' else 0,
+                 sched=getattr(self, "sched_scalars", None) if cos_anneal_ratio is not None else None)
         outs = _CompositeFn.apply(c, rays_o, rays_d, z_vals, sample_dist, background_rgb, udf.reshape(N, S),
                                   grad.reshape(N, S, 3), col.reshape(N, S, 3), cb.reshape(N, S, 3), bg_z, bg_sigma,
                                   bg_color, scal)

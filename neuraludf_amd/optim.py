@@ -24,6 +24,30 @@ class FusedAdam(torch.optim.Optimizer):
         if len(self.param_groups) > ADAM_MAX_GROUPS:
             raise NudfError("FusedAdam supports at most %d parameter groups" % ADAM_MAX_GROUPS)
         self._chunk = None
+        # graph capture (train.GraphedStep): device address of a float buffer that holds {neg_step_size, bc2_sqrt} per
+        # tensor of the launch order -- the two numbers of a step that depend on the iteration (learning-rate schedule,
+        # bias corrections).  None: they travel by value (eager steps).
+        self.dyn_base = None
+        self._order = []          # parameters of the last step() in launch order
+
+    def dyn_values(self):
+        """{neg_step_size, bc2_sqrt} of the NEXT step for the parameters of the last step(), in launch order (the layout of
+        the device buffer behind `dyn_base`), from the groups' current learning rates and the parameters' step counts."""
+        vals = []
+        for p, gi in self._order:
+            group = self.param_groups[gi]
+            step = float(self.state[p]["step"]) + 1.0
+            b1, b2 = group["betas"]
+            vals.append(-group["lr"] / (1.0 - b1 ** step))
+            vals.append(math.sqrt(1.0 - b2 ** step))
+        return vals
+
+    def advance(self):
+        """host bookkeeping of one replayed step (the kernels ran from a captured graph): step counts and version
+        counters of the parameters that took part, exactly what step() does after its launch."""
+        for p, _ in self._order:
+            self.state[p]["step"] += 1
+            torch.autograd.graph.increment_version(p)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -39,12 +63,18 @@ class FusedAdam(torch.optim.Optimizer):
         nt = 0
         blocks = 0
 
+        order = []
+        launched = 0            # tensors of earlier launches of this step (offset into the dynamic-scalar buffer)
+
         def flush():
-            nonlocal a, nt, blocks
+            nonlocal a, nt, blocks, launched
             if nt:
                 a.n_tensors = nt
                 a.block_start[nt] = blocks
+                if self.dyn_base is not None:
+                    a.dyn = self.dyn_base + 8 * launched
                 call("nudf_adam_step", a)
+            launched += nt
             a = Adam()
             self._fill_groups(a)
             nt = 0
@@ -80,14 +110,16 @@ class FusedAdam(torch.optim.Optimizer):
                 a.block_start[nt] = blocks
                 blocks += (p.numel() + chunk - 1) // chunk
                 nt += 1
+                order.append((p, gi))
         flush()
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is not None:
-                    self.state[p]["step"] += 1
-                    # the kernel wrote through a raw pointer: tell autograd (and every cache keyed on the version
-                    # counter, e.g. the packed weights of mlp.PackedLinear) that the tensor changed
-                    torch.autograd.graph.increment_version(p)
+        self._order = order
+        if torch.cuda.is_current_stream_capturing():
+            return loss         # nothing ran: train.GraphedStep replays the graph and calls advance() per step
+        for p, _ in order:
+            self.state[p]["step"] += 1
+            # the kernel wrote through a raw pointer: tell autograd (and every cache keyed on the version
+            # counter, e.g. the packed weights of mlp.PackedLinear) that the tensor changed
+            torch.autograd.graph.increment_version(p)
         return loss
 
     def _fill_groups(self, a):

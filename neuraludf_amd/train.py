@@ -32,6 +32,123 @@ DTU_MODEL_CONF = dict(
 )
 
 
+class StepScalars:
+    """The handful of per-iteration numbers a graph-captured step reads from device memory -- {cos_anneal_ratio,
+    flip_saturation} for the composite kernels (NudfComposite.sched) and {neg_step_size, bc2_sqrt} per tensor for the
+    fused Adam (NudfAdam.dyn) -- in ONE device buffer, refreshed by ONE asynchronous H2D copy per step from a ring of
+    pinned host slots (a slot is rewritten only after the copy that read it has completed, so the host may run several
+    steps ahead of the GPU)."""
+    SCHED, ADAM = 0, 8          # float offsets of the two regions
+
+    def __init__(self, device, n=8 + 2 * 96, slots=8):
+        self.dev = torch.zeros(n, device=device)
+        self.host = [torch.zeros(n).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.k = 0
+
+    def upload(self, sched, adam):
+        i = self.k % len(self.host)
+        self.k += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        h = self.host[i].numpy()
+        h[self.SCHED:self.SCHED + len(sched)] = sched
+        if len(adam) > h.shape[0] - self.ADAM:
+            raise ValueError("too many optimizer tensors for the step-scalar buffer")
+        h[self.ADAM:self.ADAM + len(adam)] = adam
+        self.dev.copy_(self.host[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
+
+
+class GraphedStep:
+    """`Trainer.step` captured once in a HIP graph and replayed: ~65-75 kernel launches (~50 us of Python + ctypes each,
+    3.5 ms per step) become one graph launch, so the host stays far ahead of the GPU and a host hiccup on one rank no
+    longer stalls a collective.  Every libnudf entry point takes the stream and never synchronises, torch's fills / cats /
+    random draws are graph-safe; what changes from iteration to iteration travels through device memory (StepScalars):
+    the learning rates and Adam's bias corrections, cos_anneal_ratio and flip_saturation.  Everything else that is a
+    kernel ARGUMENT -- tensor shapes, loss / regulariser weights, which networks take part -- is part of the capture key:
+    a new key runs `eager_steps` ordinary steps first (allocator and caches settle) and is captured on the next call.
+    Replays are bit-identical to eager steps (tests/test_gpu_graph.py).  Single process only: a data-parallel trainer
+    stays eager (its collectives have not been captured on hardware yet)."""
+
+    def __init__(self, trainer, eager_steps=2, max_graphs=4):
+        from .optim import FusedAdam
+        self.tr = trainer
+        self.eager_steps = eager_steps
+        self.max_graphs = max_graphs
+        self.graphs = {}
+        self.enabled = isinstance(trainer.optimizer, FusedAdam) and not trainer.data_parallel
+        self.scalars = None
+        self.replays = 0
+
+    def _key(self, batch, blend, has_anneal, perturb_overwrite):
+        tr = self.tr
+        sig = lambda d: tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in d.items() if torch.is_tensor(v)))
+        live = tuple(p.requires_grad for g in tr.param_groups for p in g)
+        return (sig(batch), sig(blend) if blend is not None else None, bool(has_anneal), perturb_overwrite,
+                tuple(sorted(tr.tc.items())), tuple(sorted((k, v) for k, v in tr.lc.items())), live)
+
+    def __call__(self, batch, cos_anneal_ratio=1.0, flip_saturation=1.0, blend=None, perturb_overwrite=-1):
+        tr = self.tr
+        kw = dict(cos_anneal_ratio=cos_anneal_ratio, flip_saturation=flip_saturation, blend=blend,
+                  perturb_overwrite=perturb_overwrite)
+        if not self.enabled:
+            return tr.step(batch, **kw)
+        key = self._key(batch, blend, cos_anneal_ratio is not None, perturb_overwrite)
+        ent = self.graphs.get(key)
+        if ent is None:
+            if len(self.graphs) >= self.max_graphs:          # schedules moved on: drop the oldest capture
+                self.graphs.pop(next(iter(self.graphs)))
+            ent = self.graphs[key] = dict(calls=0, graph=None)
+        ent["calls"] += 1
+        if ent["graph"] is None:
+            if ent["calls"] <= self.eager_steps:
+                return tr.step(batch, **kw)
+            self._capture(ent, batch, blend, cos_anneal_ratio is not None, flip_saturation, perturb_overwrite)
+        for k, v in ent["batch"].items():
+            if v is not batch[k]:
+                v.copy_(batch[k])
+        if blend is not None:
+            for k, v in ent["blend"].items():
+                if v is not blend[k]:
+                    v.copy_(blend[k])
+        self.scalars.upload([0.0 if cos_anneal_ratio is None else float(cos_anneal_ratio), float(flip_saturation)],
+                            tr.optimizer.dyn_values())
+        ent["graph"].replay()
+        tr.optimizer.advance()
+        self.replays += 1
+        return ent["loss"], ent["out"]
+
+    def _capture(self, ent, batch, blend, has_anneal, flip_saturation, perturb_overwrite):
+        tr = self.tr
+        dev = batch["rays_o"].device
+        if self.scalars is None:
+            self.scalars = StepScalars(dev)
+        ent["batch"] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        ent["blend"] = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in blend.items()}
+                        if blend is not None else None)
+        for m in tr.modules().values():                      # the weight-pack launches must be inside the capture
+            e = getattr(m, "_engine", None)
+            if e is not None and hasattr(e, "mark_stale"):
+                e.mark_stale()
+        sc = self.scalars
+        tr.renderer.sched_scalars = sc.dev[sc.SCHED:sc.SCHED + 2]
+        tr.optimizer.dyn_base = sc.dev.data_ptr() + 4 * sc.ADAM
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.graph(g):
+                loss, out = tr.step(ent["batch"], cos_anneal_ratio=(1.0 if has_anneal else None),
+                                    flip_saturation=flip_saturation, blend=ent["blend"],
+                                    perturb_overwrite=perturb_overwrite)
+        finally:
+            tr.renderer.sched_scalars = None
+            tr.optimizer.dyn_base = None
+        ent["graph"], ent["loss"], ent["out"] = g, loss, out
+
+
 class Trainer:
     def __init__(self, device, renderer_conf, color_loss_conf=None, train_conf=None, seed=0, data_parallel=False,
                  fields_mod=fields, renderer_cls=UDFRendererBlending, loss_cls=ColorLoss, fused_adam=False,
@@ -89,6 +206,11 @@ class Trainer:
     def modules(self):
         return dict(nerf=self.nerf, udf=self.udf, var=self.var, color=self.color, beta=self.beta)
 
+    def enable_graph(self, eager_steps=2):
+        """replay `step` from a captured HIP graph in `iteration` (see GraphedStep); -> the GraphedStep."""
+        self.graphed = GraphedStep(self, eager_steps=eager_steps)
+        return self.graphed
+
     def loss(self, batch, cos_anneal_ratio=1.0, flip_saturation=1.0, blend=None, perturb_overwrite=-1):
         """-> (loss, render_out)."""
         tc, lc = self.tc, self.lc
@@ -120,7 +242,7 @@ class Trainer:
             if fused:
                 parts.append(self.color_loss.local_sums(out["color_base"], out["color"], batch["true_rgb"], pixel_mask))
             if bce_sum is not None:
-                parts.append(torch.stack([bce_sum, bce_sum.new_tensor(float(weight_sum.numel()))]))
+                parts.append(torch.stack([bce_sum, torch.full_like(bce_sum, float(weight_sum.numel()))]))
             packed = nudf_dist.all_reduce_sum(torch.cat([p.reshape(-1) for p in parts]))
             ge, gens, se = self.renderer.errors_from_sums(packed[:5], weight_sum.shape[0])
             out["gradient_error"], out["gradient_error_near_surface"], out["sparse_error"] = ge, gens, se
@@ -148,7 +270,10 @@ class Trainer:
         if self.data_parallel:
             self.bucket.all_reduce()
         self.optimizer.step()
-        return loss.detach(), out
+        # detached: the autograd graph of the step is done with, and an `out` that kept it alive would also keep the
+        # parameters' AccumulateGrad nodes (and the stream they were created on) alive into the next iteration -- which
+        # breaks a later graph capture on another stream (GraphedStep)
+        return loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
 
     def iteration(self, source, iter_step, schedules, image_perm=None, batch_size=512, num_src=8):
         """one pass of the reference training loop body (exp_runner_blending.py:262-375) with every per-iteration
@@ -171,8 +296,9 @@ class Trainer:
         if a["color_pixel_weight"] > 0.0 or a["color_patch_weight"] > 0.0:
             ref_c2w, src_c2ws, src_intr, src_images, _ = source.get_ref_src_info(img_idx, num_src)
             blend = dict(color_maps=src_images, w2cs=source.src_w2cs(img_idx, num_src), intrinsics=src_intr, query_c2w=ref_c2w)
-        loss, out = self.step(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
-                              blend=blend)
+        stepper = self.graphed if getattr(self, "graphed", None) is not None else self.step
+        loss, out = stepper(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
+                            blend=blend)
         self._trainability_toggles(out, iter_step)
         return loss, out, s
 

@@ -1,0 +1,77 @@
+"""HIP-graph replay of the train step (train.GraphedStep): replay == eager TO THE BIT over consecutive steps -- render,
+losses, backward, fused Adam -- with the random jitter on, while the per-iteration scalars (learning rates, Adam's bias
+corrections, cos_anneal_ratio, flip_saturation) change every step through device memory."""
+import pytest
+import torch
+
+from neuraludf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RCONF = dict(n_samples=32, n_importance=32, n_outside=0, up_sample_steps=2, perturb=1.0)
+RCONF_BG = dict(n_samples=32, n_importance=16, n_outside=8, up_sample_steps=2, perturb=1.0)
+
+
+def _schedule(i):
+    return dict(cos_anneal_ratio=min(1.0, 0.3 + 0.1 * i), flip_saturation=(0.0 if i < 2 else 0.9)), 5e-4 * (1.0 - 0.05 * i)
+
+
+def _run(rconf, graphed, n_steps, n_rays=192):
+    from neuraludf_amd.train import Trainer, GraphedStep
+    dev = torch.device("cuda:0")
+    tr = Trainer(dev, rconf, seed=0, fused_adam=True)
+    tr.renderer.diagnostics = False
+    scene = synth.make_scene("tiny")
+    stepper = GraphedStep(tr, eager_steps=2) if graphed else tr.step
+    torch.manual_seed(1234)                      # the jitter draws of `render` come from the default CUDA generator
+    hist = []
+    for i in range(n_steps):
+        rays = synth.make_rays(scene, i % 3, n_rays, seed=100 + i)
+        batch = {k: v.to(dev) for k, v in rays.items()}
+        kw, lr = _schedule(i)
+        for gi, g in enumerate(tr.optimizer.param_groups):
+            g["lr"] = lr * (0.2 if gi == 0 else 1.0)
+        loss, out = stepper(batch, **kw)
+        hist.append((loss.clone(), out["color"].detach().clone(), out["weight_sum"].detach().clone(),
+                     [p.detach().clone() for g in tr.param_groups for p in g]))
+    torch.cuda.synchronize()
+    return tr, stepper, hist
+
+
+@pytest.mark.parametrize("rconf", [RCONF, RCONF_BG], ids=["no_background", "background_nerf"])
+def test_graph_replay_equals_eager_to_the_bit(rconf):
+    n = 7                                            # 2 eager steps, capture + replay on the 3rd call, 4 more replays
+    _, _, eager = _run(rconf, False, n)
+    tr, gs, graph = _run(rconf, True, n)
+    assert gs.enabled and gs.replays == n - 2 and len(gs.graphs) == 1
+    for i, (a, b) in enumerate(zip(eager, graph)):
+        assert torch.equal(a[0], b[0]), ("loss", i, float(a[0]), float(b[0]))
+        assert torch.equal(a[1], b[1]), ("colour", i)
+        assert torch.equal(a[2], b[2]), ("weight_sum", i)
+        for j, (p, q) in enumerate(zip(a[3], b[3])):
+            assert torch.equal(p, q), ("parameter", i, j)
+    # the optimizer's host state followed the replays (checkpoints stay interchangeable)
+    steps = {float(st["step"]) for st in tr.optimizer.state.values()}
+    assert steps == {float(n)}, steps
+
+
+def test_new_loss_weights_are_a_new_capture_and_dp_stays_eager():
+    from neuraludf_amd.train import Trainer, GraphedStep
+    dev = torch.device("cuda:0")
+    tr = Trainer(dev, RCONF, seed=0, fused_adam=True)
+    gs = GraphedStep(tr, eager_steps=1)
+    scene = synth.make_scene("tiny")
+    batch = {k: v.to(dev) for k, v in synth.make_rays(scene, 0, 128, seed=5).items()}
+    for _ in range(3):
+        gs(batch)
+    assert gs.replays == 2 and len(gs.graphs) == 1
+    tr.tc["igr_weight"] = 0.2                         # a by-value kernel / python scalar of the step: part of the key
+    l0, _ = gs(batch)                                 # eager again under the new key
+    assert len(gs.graphs) == 2 and gs.replays == 2
+    l1, _ = gs(batch)
+    assert gs.replays == 3 and torch.isfinite(l1)
+    other = {k: v.to(dev) for k, v in synth.make_rays(scene, 1, 64, seed=6).items()}      # another batch shape
+    gs(other)
+    assert len(gs.graphs) == 3
+    tr2 = Trainer(dev, RCONF, seed=0, fused_adam=False)           # torch.optim.Adam: no dynamic-scalar path -> eager
+    assert not GraphedStep(tr2).enabled
