@@ -625,7 +625,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
 
 int nudf_chain_rows_class(const NudfChain& p, bool allow_blocked = false);  // mlp_chain_rows.hip
 int nudf_mlp_chain_rows_launch(const NudfChain& p, int cls, hipStream_t st);
-int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st);
+int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st, int force_pair = 0);
+int nudf_chain_pair_mode();
 
 // NUDF_CHAIN_ROWS=1 lets large launches choose the wave-private kernel on their own (measured in round 2: equal to
 // the workgroup-shared tiles on the forward sweeps, 10-20 % slower on the sweeps that stream stored state, see
@@ -688,16 +689,26 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   for (int i = 0; i < p.n_steps; ++i) blocked = blocked || (p.step[i].layout & 31) != 0;
   if (blocked) {   // only the transposed-product shared tile addresses the blocked layout
     const int cls = nudf_chain_rows_class(p, true);
-    if (cls < 0 || (p.tile_rows != 66 && p.tile_rows != 0)) {
+    if (cls < 0 || (p.tile_rows != 66 && p.tile_rows != 130 && p.tile_rows != 0)) {
       nudf_set_error("nudf_mlp_chain: blocked-layout buffers need the transposed-product kernel (tile_rows 0 / 66, fp32 "
                      "steps, 16-byte aligned rows)", hipErrorInvalidValue);
       return (int)hipErrorInvalidValue;
     }
-    return nudf_mlp_chain_tq_launch(p, cls, st);
+    return nudf_mlp_chain_tq_launch(p, cls, st, p.tile_rows == 130);
+  }
+  if (p.tile_rows == 130) {     // paired tiles requested explicitly (tests, A/B): any size
+    const int cls = nudf_chain_rows_class(p);
+    if (cls >= 0) return nudf_mlp_chain_tq_launch(p, cls, st, 1);
   }
   if (p.tile_rows == 66 || (p.tile_rows == 0 && p.P > 256 * 64 && nudf_chain_quad_mode() > 0)) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0 && (p.tile_rows == 66 || cls <= 1 || nudf_chain_quad_mode() >= 2)) return nudf_mlp_chain_tq_launch(p, cls, st);
+  }
+  // NUDF_CHAIN_PAIR=2: paired tiles (mlp_chain_pair_kernel, reached through the transposed-product launcher) for every
+  // fp32 launch of at least 32 768 points that meets that kernel's contract -- a measured counter-example, off by default
+  if (p.tile_rows == 0 && p.P >= 32768 && !any16 && nudf_chain_pair_mode() >= 2) {
+    const int cls = nudf_chain_rows_class(p);
+    if (cls >= 0) return nudf_mlp_chain_tq_launch(p, cls, st);
   }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {

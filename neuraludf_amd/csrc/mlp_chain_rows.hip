@@ -572,6 +572,62 @@ __device__ __forceinline__ void tq_mma(const float* __restrict__ arow, const f32
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// tq_mma with a ring of D register sets (D - 1 k groups of LDS / L2 reads in flight instead of one; see ch_mma_ring in
+// mlp_chain.hip).  Same MFMA order: bit-identical results.
+template <int NRT, int NCT, int D, class Tail>
+__device__ __forceinline__ void tq_mma_ring(const float* __restrict__ arow, const f32x4* __restrict__ bptr, size_t bstride,
+                                            int G, f32x16 (&acc)[2][2], Tail&& tail) {
+  f32x4 a[D][NRT], b[D][NCT];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int glast = G - 1;
+  auto load = [&](f32x4 (&as)[NRT], f32x4 (&bs)[NCT], int g) {
+    g = (g < glast) ? g : glast;
+    const f32x4* bq = bptr + (size_t)g * bstride;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) bs[j] = bq[j * 64];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) as[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 8);
+  };
+  auto mma = [&](const f32x4 (&as)[NRT], const f32x4 (&bs)[NCT]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(bs[j][jj], as[i][jj], acc[i][j]);
+  };
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) load(a[d], b[d], d);
+  int g = 0;
+#pragma unroll 1
+  for (; g + D <= G; g += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      load(a[(d + D - 1) % D], b[(d + D - 1) % D], g + d + D - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a[d], b[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int rem = G - g;
+  // tail: up to D - 1 groups whose operands are already requested; the epilogue's stored-state operands go out behind
+  // them, before the last group's MFMAs
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) {
+    if (d == rem - 1 || (rem == 0 && d == 0)) {
+      tail();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (d < rem) mma(a[d], b[d]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // the wave's tiles as straight-line code; X2 of tile t + 1 is requested before tile t is computed and stored
 template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
@@ -609,7 +665,7 @@ __device__ __forceinline__ void tq_epilogue_any(const NudfChainStep& st, float* 
   else tq_epilogue<EPI, 1, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
 }
 
-template <int XCLS>
+template <int XCLS, int RING = 0>
 __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
   __shared__ __attribute__((aligned(16))) ChainTqSmem sm;
   const int tid = threadIdx.x;
@@ -741,7 +797,14 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
               for (int e = 0; e < 4; ++e) px1[i][j][4 * q + e] = v[e];
             }
       };
-      if (nrt == 2 && nct == 2) tq_mma<2, 2>(arow, bptr, bstride, G, acc, tail);
+      if (RING > 1) {
+        constexpr int D = RING > 1 ? RING : 2;
+        if (nrt == 2 && nct == 2) tq_mma_ring<2, 2, D>(arow, bptr, bstride, G, acc, tail);
+        else if (nrt == 2) tq_mma_ring<2, 1, D>(arow, bptr, bstride, G, acc, tail);
+        else if (nct == 2) tq_mma_ring<1, 2, D>(arow, bptr, bstride, G, acc, tail);
+        else tq_mma_ring<1, 1, D>(arow, bptr, bstride, G, acc, tail);
+      }
+      else if (nrt == 2 && nct == 2) tq_mma<2, 2>(arow, bptr, bstride, G, acc, tail);
       else if (nrt == 2) tq_mma<2, 1>(arow, bptr, bstride, G, acc, tail);
       else if (nct == 2) tq_mma<1, 2>(arow, bptr, bstride, G, acc, tail);
       else tq_mma<1, 1>(arow, bptr, bstride, G, acc, tail);
@@ -780,9 +843,250 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
   if (dbg && lane == 0) dbg[63] = wall_clock64();
 }
 
-int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st) {
+// =====================================================================================================
+// PAIRED 64-point tiles ("pair"): ONE workgroup of 8 waves owns two 64-point tiles (two LDS activation tiles, 150 KB,
+// one workgroup per CU) and runs them in ANTI-PHASE by construction: in every phase one half (4 waves, one per SIMD)
+// runs the K loop of a step -- alone on the matrix pipe -- while the other half runs the epilogue of its previous K loop;
+// one __syncthreads() per phase swaps the roles.
+//
+// Why (scripts/chain_timeline.py, round 3): two independent 64-point workgroups per CU drift INTO phase -- while both
+// are in their K loops they share the matrix pipe and slow down together, so they also reach their epilogues together
+// and the pipe idles: K-loop efficiency 45-48 % (50 % = two waves sharing a saturated pipe) with only 55 % of the
+// pipe's time used on the 128-wide colour-net sweeps, 76 % on the UDF forward.  In-phase is the stable state of that
+// design (the wave that falls behind gets the whole pipe and catches up); the one-off start-up delay cannot hold the
+// workgroups apart.  Here the phase relation is enforced: per step and pair the pipe is busy 2 M of max(M, E) + max(M, E).
+//
+// Same tiles, step tables, K loop, epilogues and summation order as mlp_chain_tq_kernel (the halves' code IS that
+// kernel's): results are bit-identical to it.  A step whose epilogue is followed by a positional-encoding tail (the skip
+// layer) needs one barrier between the two inside its half; both halves execute it (the other one after its K loop).
+// =====================================================================================================
+struct ChainPairSmem {
+  float act[2][64 * CH_LD];   // 149 504 B
+  float bias[2][2][256];      //   4 096 B
+  float xs[2][64 * 3];
+  float vs[2][64 * 3];
+};
+
+template <int XCLS>
+__global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(NudfChain p) {
+  __shared__ __attribute__((aligned(16))) ChainPairSmem sm;
+  const int tid8 = threadIdx.x;
+  const int half = __builtin_amdgcn_readfirstlane(tid8 >> 8);
+  const int tid = tid8 & 255;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ln = lane & 31;
+  const int m0 = (blockIdx.x * 2 + half) * 64;
+  const bool live = m0 < p.P;          // the odd tile of the last pair: that half only keeps the barriers company
+  float* act = sm.act[half];
+  float* xs = sm.xs[half];
+  float* vs = sm.vs[half];
+
+  // ---- tile initialisation (as mlp_chain_tq_kernel, each half its own tile) ------------------------
+  if (p.x && live) {
+    for (int e = tid; e < 64 * 3; e += 256) {
+      int r = m0 + e / 3;
+      if (r > p.P - 1) r = p.P - 1;
+      xs[e] = p.x[(size_t)(r / p.x_div) * 3 + (e % 3)];
+      vs[e] = p.v ? p.v[(size_t)r * 3 + (e % 3)] : 0.0f;
+    }
+  }
+  {
+    const NudfChainStep& s0 = p.step[0];
+    sm.bias[half][0][tid] = (s0.bias && tid < s0.N) ? s0.bias[tid] : 0.0f;
+  }
+  __syncthreads();
+  if (live) {
+    if (p.init == NUDF_CH_INIT_LOAD) {
+      const int k4 = p.k0 >> 2;
+      for (int e = tid; e < 64 * k4; e += 256) {
+        const int r = e / k4, c4 = e - r * k4;
+        int gr = m0 + r;
+        if (gr > p.P - 1) gr = p.P - 1;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.A0 + (size_t)gr * p.lda0 + c4 * 4);
+        *reinterpret_cast<f32x4*>(act + r * CH_LD + c4 * 4) = val;
+      }
+    } else if (p.init == NUDF_CH_INIT_POSENC) {
+      ch_write_pe_rows<256>(act, xs, vs, 64, tid, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0);
+    } else if (p.init == NUDF_CH_INIT_SEED) {
+      const int C = p.k0;
+      for (int e = tid; e < 64 * C; e += 256) {
+        const int r = e / C, c = e - r * C;
+        int gr = m0 + r;
+        const bool lv = gr < p.P;
+        if (!lv) gr = p.P - 1;
+        float sg, om;
+        const float hst = (p.init_state16 & 4) ? p.A0[ch_blk_off(gr, c, p.lda0)] : p.A0[(size_t)gr * p.lda0 + c];
+        ch_sp_derivs(hst, p.seed_xscale, sg, om);
+        const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * sg;
+        act[r * CH_LD + c] = val;
+        if (p.G0 && lv) {
+          if (p.init_state16 & 8) p.G0[ch_blk_off(gr, c, p.ldg0)] = val;
+          else p.G0[(size_t)gr * p.ldg0 + c] = val;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 8 + half * 4 + wave) * 64 : nullptr;
+  if (dbg && lane == 0) {
+    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    dbg[1] = __builtin_amdgcn_s_memtime();
+    dbg[62] = wall_clock64();
+  }
+
+  const int L = p.n_steps;
+  // Phase ph = 0 .. 2 L, one __syncthreads() each: half 0 runs K(0) E(0) K(1) E(1) ... and idles in the last phase, half 1
+  // idles in the first and runs the same sequence one phase later -- so that K loops and epilogues of the two halves
+  // alternate.  Written per step (K loop, barrier, epilogue, barrier: the straight-line body of mlp_chain_tq_kernel, whose
+  // register allocation it keeps) with the idle phases as one extra barrier in front (half 1) / behind (half 0).
+  if (half == 1) __syncthreads();
+
+  for (int si = 0; si < L; ++si) {
+    const NudfChainStep& st = p.step[si];
+    const int G = st.K >> 3;
+    const int NT = (st.N + 31) >> 5;
+    int rt0, ct0, nrt, nct;
+    if (NT <= 2) { rt0 = wave >> 1; ct0 = wave & 1; nrt = 1; nct = (ct0 < NT) ? 1 : 0; }
+    else if (NT <= 4) { rt0 = wave >> 1; ct0 = 2 * (wave & 1); nrt = 1; nct = min(2, max(0, NT - ct0)); }
+    else { rt0 = 0; ct0 = 2 * wave; nrt = 2; nct = min(2, max(0, NT - ct0)); }
+    if (!live) nct = 0;
+
+    ChrStep cs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ChrStep& c = cs[i];
+      c.row = (unsigned)(m0 + (rt0 + i) * 32 + ln);
+      const int lay = chr_pin(st.layout);
+      auto base = [&](int ld, bool blk) {
+        return blk ? (c.row - (unsigned)ln) * (unsigned)ld + 4u * (unsigned)ln : c.row * (unsigned)ld;
+      };
+      c.x1 = base(st.ldx1, lay & NUDF_CH_BLK_X1); c.m1 = (lay & NUDF_CH_BLK_X1) ? 32u : 1u;
+      c.x2 = base(st.ldx2, lay & NUDF_CH_BLK_X2); c.m2 = (lay & NUDF_CH_BLK_X2) ? 32u : 1u;
+      c.c1 = base(st.ldc1, lay & NUDF_CH_BLK_C1); c.mc1 = (lay & NUDF_CH_BLK_C1) ? 32u : 1u;
+      c.c2 = base(st.ldc2, lay & NUDF_CH_BLK_C2); c.mc2 = (lay & NUDF_CH_BLK_C2) ? 32u : 1u;
+      c.X1 = (chr_gcp)chr_pin(st.X1);
+      c.X2 = (chr_gcp)chr_pin(st.X2);
+      c.C1 = (chr_gp)chr_pin(st.C1);
+      c.C2 = (chr_gp)chr_pin(st.C2);
+      c.N = chr_pin(st.N);
+      c.nq = chr_pin(((st.N + 3) & ~3) - 4);
+      c.iparam = chr_pin(st.iparam);
+      c.act_col0 = chr_pin(st.act_col0);
+      c.act_write = chr_pin(st.act_write);
+      const int flim = (st.epi == NUDF_CH_MULSP && st.iparam > 0) ? min(st.N, st.iparam) : st.N;
+      c.lim1 = chr_pin(min((flim + 3) & ~3, st.ldc1));
+      c.lim2 = chr_pin(min((st.N + 3) & ~3, st.ldc2));
+      c.scale = chr_pin(st.scale);
+      c.xscale = chr_pin(st.xscale);
+    }
+
+    f32x16 acc[2][2];
+    float px1[2][2][16];
+    float nbias = 0.0f;
+    if (si + 1 < L) {
+      const NudfChainStep& sn = p.step[si + 1];
+      if (sn.bias && tid < sn.N) nbias = sn.bias[tid];
+    }
+    // ---------------- K loop of step si: this half alone on the matrix pipe ----------------
+    if (nct > 0) {
+      const float* arow = act + (rt0 * 32 + ln) * CH_LD + 4 * h;
+      const f32x4* bptr = reinterpret_cast<const f32x4*>(st.Bp) + (size_t)ct0 * 64 + lane;
+      const size_t bstride = (size_t)NT * 64;
+      const bool u1 = XCLS >= 1 && CH_USES_X1(st.epi);
+      auto tail = [&]() {
+        if (XCLS == 0) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+              if (u1 && i < nrt && j < nct) v = chr_load_quad(cs[i].X1, cs[i].x1, 32 * (ct0 + j) + 4 * h + 8 * qd, cs[i].nq, cs[i].m1);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) px1[i][j][4 * qd + e] = v[e];
+            }
+      };
+      if (nrt == 2 && nct == 2) tq_mma<2, 2>(arow, bptr, bstride, G, acc, tail);
+      else if (nrt == 2) tq_mma<2, 1>(arow, bptr, bstride, G, acc, tail);
+      else if (nct == 2) tq_mma<1, 2>(arow, bptr, bstride, G, acc, tail);
+      else tq_mma<1, 1>(arow, bptr, bstride, G, acc, tail);
+    }
+    sm.bias[half][(si + 1) & 1][tid] = nbias;
+    if (dbg && lane == 0) dbg[2 + 4 * si] = __builtin_amdgcn_s_memtime();
+    // the epilogue the OTHER half runs in this phase (half 0 sees E(si - 1) of half 1, half 1 sees E(si) of half 0): if
+    // it ends with a positional-encoding tail, it has one barrier inside -- keep it company
+    {
+      const int so = (half == 0) ? si - 1 : si;
+      if (so >= 0 && p.step[so].pe_tail_col >= 0) __syncthreads();
+    }
+    __syncthreads();  // phase boundary: the other half's epilogue is done, its K loop may start; ours starts its epilogue
+    if (dbg && lane == 0) dbg[3 + 4 * si] = __builtin_amdgcn_s_memtime();
+
+    // ---------------- epilogue of step si: beside the other half's K loop ----------------
+    if (nct > 0) {
+      const float* bl = sm.bias[half][si & 1];
+      switch (st.epi) {
+        case NUDF_CH_SOFTPLUS: tq_epilogue_any<NUDF_CH_SOFTPLUS>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_NONE: tq_epilogue_any<NUDF_CH_NONE>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_RELU: tq_epilogue_any<NUDF_CH_RELU>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_SIGMOIDN: tq_epilogue_any<NUDF_CH_SIGMOIDN>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_UDFHEAD: tq_epilogue_any<NUDF_CH_UDFHEAD>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_MULSP: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULSP>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_MULMASK: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULMASK>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_TANGENT: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_TANGENT>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_BWD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_BWD>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_ADDMASK: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_ADDMASK>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        case NUDF_CH_RELUADD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_RELUADD>(st, act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, bl); break;
+        default: break;
+      }
+    }
+    if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
+    if (st.pe_tail_col >= 0) {
+      __syncthreads();
+      if (live) {
+        const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
+        ch_write_pe_rows<256>(act, xs, vs, 64, tid, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe,
+                              st.pe_tail_col, min((pe_end + 15) & ~15, 288), false, (st.layout & NUDF_CH_BLK_PE) != 0);
+      }
+    }
+    __syncthreads();  // phase boundary
+    if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
+  }
+  if (half == 0) {    // last phase: half 1 runs E(L - 1)
+    if (p.step[L - 1].pe_tail_col >= 0) __syncthreads();
+    __syncthreads();
+  }
+  if (dbg && lane == 0) dbg[63] = wall_clock64();
+}
+
+// NUDF_CHAIN_PAIR: 0 (default) = independent 64-point workgroups; 1 = launches of at least 32 768 points that already go
+// to the transposed-product kernel (blocked state: the UDF sweeps) run as paired tiles; 2 = every fp32 launch of at least
+// 32 768 points that meets that kernel's contract does (colour / NeRF chains, coarse forward).  MEASURED (round 3,
+// profiles/r03_chain_pair.txt): not faster -- a K loop alone on the pipe next to the partner's epilogue reaches only 77 %
+// of the pipe rate (two in-phase K loops together 95 %), and the epilogue beside a K loop takes 1.8x as long; the
+// kernel stays as the measured counter-example to "enforce anti-phase".
+int nudf_chain_pair_mode() {
+  static const int mode = [] {
+    const char* e = getenv("NUDF_CHAIN_PAIR");
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
+}
+
+int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st, int force_pair) {
   const dim3 grid((p.P + 63) / 64), block(256);
-  if (cls == 0) hipLaunchKernelGGL((mlp_chain_tq_kernel<0>), grid, block, 0, st, p);
+  // forward sweeps (no stored-state operand): three register sets in the K loop, two k groups of operand reads in flight
+  // (tq_mma_ring; measured 629 -> 605 us at 65 536 points).  The input-gradient instantiation spills 28 registers with a
+  // third set and gains nothing, the tangent / adjoint one has no room at all (254 of 256 VGPRs).  NUDF_TQ_RING=0: two sets.
+  static const int ring = [] {
+    const char* e = getenv("NUDF_TQ_RING");
+    return e ? atoi(e) : 3;
+  }();
+  if (cls == 0 && ring == 3) hipLaunchKernelGGL((mlp_chain_tq_kernel<0, 3>), grid, block, 0, st, p);
+  else if (cls == 0) hipLaunchKernelGGL((mlp_chain_tq_kernel<0>), grid, block, 0, st, p);
   else if (cls == 1) hipLaunchKernelGGL((mlp_chain_tq_kernel<1>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((mlp_chain_tq_kernel<2>), grid, block, 0, st, p);
   NUDF_CHECK_LAUNCH("nudf_mlp_chain(tq)");

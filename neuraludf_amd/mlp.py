@@ -171,6 +171,7 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
 USE_CHAIN = os.environ.get("NUDF_CHAIN", "1") != "0"     # 0: per-layer GEMM launches (A/B measurements, cross-checks)
 CHAIN_DEBUG = None     # int64 tensor [blocks * 4, 32]: per-wave timeline written by the kernel (scripts/chain_timeline.py)
 CHAIN_TILE = int(os.environ.get("NUDF_CHAIN_TILE", "0"))  # 0 = auto, 32 / 64 force the points-per-workgroup tile
+COLOR_TILE = int(os.environ.get("NUDF_COLOR_TILE", "0"))  # the colour network's three chain launches only (A/B)
 
 
 def k8(n: int) -> int:
@@ -287,7 +288,12 @@ class ChainBuilder:
         P, e = self.c.P, set(self.epis)
         x1 = bool(e & {"MULSP", "TANGENT", "BWD", "MULMASK", "ADDMASK"})
         x2 = bool(e & {"TANGENT", "BWD", "ADDMASK", "RELUADD"})
-        if self.blocked or self.c.tile_rows == 66:
+        pair = int(os.environ.get("NUDF_CHAIN_PAIR", "0"))
+        if self.c.tile_rows == 130 or ((self.blocked or self.c.tile_rows == 66) and pair >= 1 and P >= 32768):
+            kern = "mlp_chain_pair_kernel<%d>" % (2 if x2 else (1 if x1 else 0))
+        elif self.c.tile_rows == 0 and pair >= 2 and P >= 32768 and PRECISION == "fp32":
+            kern = "mlp_chain_pair_kernel<%d>" % (2 if x2 else (1 if x1 else 0))
+        elif self.blocked or self.c.tile_rows == 66:
             kern = "mlp_chain_tq_kernel<%d>" % (2 if x2 else (1 if x1 else 0))
         elif self.c.tile_rows == 128:
             kern = "mlp_chain_rows_kernel"
@@ -477,7 +483,7 @@ BLOCKED_STATE = os.environ.get("NUDF_BLOCKED_STATE", "1") != "0"
 
 
 def _state_blocked(P):
-    return BLOCKED_STATE and PRECISION == "fp32" and USE_CHAIN and CHAIN_TILE in (0, 66) and P > 256 * 64
+    return BLOCKED_STATE and PRECISION == "fp32" and USE_CHAIN and CHAIN_TILE in (0, 66, 130) and P > 256 * 64
 
 
 def _state_dtype():
@@ -1131,7 +1137,7 @@ class ColorEngine:
         VIN = torch.empty(Pp, pad32(H + npe + dout), device=dev) if keep_state else None
         HB = [CIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
         HV = [VIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
-        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp))
+        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp), tile_rows=COLOR_TILE)
         cb.init_load(CIN, CIN.shape[1])
         cb.posenc(rays_d, self.net.multires_view, 1.0, x_div=S)
         for l in range(n - 1):
@@ -1170,7 +1176,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(Dv[n - 1]), Dv[n - 1].shape[1])
         dVIN = _buf(P, self.view[0].inp, dev, zero=False)
-        cb = ChainBuilder(P, "LOAD", k8(plv.out))
+        cb = ChainBuilder(P, "LOAD", k8(plv.out), tile_rows=COLOR_TILE)
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
@@ -1184,7 +1190,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (H + npe), dVIN.shape[1],
              dout, None, 0, 0, P, ptr(Db[n - 1]), Db[n - 1].shape[1])
         dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)
-        cb = ChainBuilder(P, "LOAD", k8(plb.out))
+        cb = ChainBuilder(P, "LOAD", k8(plb.out), tile_rows=COLOR_TILE)
         cb.init_load(Db[n - 1], Db[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.base[i]

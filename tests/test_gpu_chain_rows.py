@@ -101,3 +101,38 @@ def test_blocked_state_layout_matches_row_major_path(dev):
         assert torch.equal(a[k], b[k]), k
     st = mlp_state_probe(dev, P)
     assert mlp._isblk(st["X"][4]) and not mlp._isblk(st["X"][0])      # the blocked path really ran
+
+
+# ---- two 64-point tiles per workgroup in anti-phase (tile_rows = 130, mlp_chain_pair_kernel) -----------------------------
+@pytest.mark.parametrize("P", [1, 63, 65, 129, 191, 1000, 4133])
+def test_pair_kernel_equals_tq_kernel_to_the_bit_ragged_sizes(dev, P):
+    """the paired-tile kernel runs the transposed-product kernel's own K loops and epilogues, only interleaved in time:
+    every sweep output, stored array and parameter gradient of all three networks is bit-identical -- including sizes whose
+    last workgroup holds one live tile and one dead one (P = 1, 63, 65: 1-2 tiles; 129, 191: 3 tiles)."""
+    a = sweeps(dev, P, 66, seed=P)
+    b = sweeps(dev, P, 130, seed=P)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+
+
+def test_pair_kernel_full_size_default_dispatch_and_determinism(dev):
+    """at >= 32 768 points the automatic choice IS the paired kernel (blocked state for the UDF sweeps, row-major for the
+    colour / NeRF chains and forward-only launches): bit-identical to the explicit pair request, to the transposed-product
+    kernel and -- on the UDF sweeps -- to the default shared-tile kernel; re-runs are identical."""
+    from neuraludf_amd import mlp
+    P = 64 * 701 + 13                       # 702 tiles = 351 pairs, ragged last tile
+    assert mlp._state_blocked(P)
+    ref = sweeps(dev, P, 64, seed=11)       # row-major state, mlp_chain_kernel<64>
+    tq = sweeps(dev, P, 66, seed=11)
+    auto = sweeps(dev, P, 0, seed=11)
+    pair = sweeps(dev, P, 130, seed=11)
+    again = sweeps(dev, P, 0, seed=11)
+    for k in auto:
+        assert torch.equal(auto[k], pair[k]), k
+        assert torch.equal(auto[k], again[k]), k
+        assert torch.equal(auto[k], tq[k]), k
+    for k in ("udf", "sign", "feat", "X4", "X8", "g", "DA0", "DA3", "DA7", "uo"):
+        assert torch.equal(ref[k], auto[k]), k
+    bad, _, worst, worst_l2 = compare(ref, auto, f"P={P} shared vs paired", verbose=True)
+    assert not bad, bad
