@@ -1334,8 +1334,8 @@ class NerfEngine:
 
     def __init__(self, net):
         self.net = net
-        if not net.use_viewdirs:
-            raise NotImplementedError("NeRF without view directions")
+        # (use_viewdirs=False never gets here: the reference's forward asserts False for it, and so does models.fields.NeRF)
+        assert net.use_viewdirs, "NeRF(use_viewdirs=False) has no forward in the reference (fields.py:629-630)"
         self.D, self.W = net.D, net.W
         self.e = net.input_ch
         self.ev = net.input_ch_view

@@ -400,8 +400,13 @@ class NeRF(nn.Module):
         return _NerfFn.apply(eng, pts4, rays_d, S, *eng.params())
 
     def forward(self, input_pts, input_views):
+        """fields.py:599-630.  `use_viewdirs=False` ends in `assert False` in the reference's own forward (:629-630): the
+        same here (the constructor still registers `output_linear`, so state dicts interchange).  `input_views=None`
+        returns the density only (:614-617): the colour branch is evaluated on zero directions and dropped."""
+        assert self.use_viewdirs, "NeRF(use_viewdirs=False): the reference's forward asserts False here (fields.py:629-630)"
         if input_views is None:
-            raise NotImplementedError("NeRF.forward without view directions is unused on the hot path")
+            zeros = torch.zeros(input_pts.shape[0], self.d_in_view, device=input_pts.device)
+            return self.evaluate(input_pts, zeros, 1)[0]
         return self.evaluate(input_pts, input_views.contiguous(), 1)
 
 

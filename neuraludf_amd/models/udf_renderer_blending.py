@@ -413,7 +413,11 @@ class UDFRendererBlending:
         if color_maps is not None:
             from . import blend
             if img_index is not None:
-                raise NotImplementedError("img_index is None on every call site of the reference")
+                # fields.py:507-508 does torch.index_select(blending_weights [N, S, 10], 1, img_index): it selects along
+                # the SAMPLE axis, so the result [N, len(img_index), 10] no longer matches pts_pixel_mask [N, S, V] two
+                # lines later (:511) -- the branch cannot run in the reference either; no call site passes img_index
+                raise NotImplementedError("img_index: the reference's own branch (fields.py:507-511) is shape-inconsistent "
+                                          "and unused; every call site passes None")
             color_pixel, patch_colors, patch_mask = blend.blend_and_composite(
                 self.h_patch_size, pts.reshape(N, S, 3), logits.reshape(N, S, -1), weights, grad.reshape(N, S, 3).detach(),
                 rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv, bg_in=bg_color_in, bg_tail=bg_color)

@@ -456,6 +456,23 @@ def test_nerf(dev, nets):
     ((s2 * w1.to(dev)).sum() + (rgb2 * w2.to(dev)).sum()).backward()
     for n, p in net.named_parameters():
         assert rel(p.grad, on.nerf[n].grad) < GTOL, n
+    # density-only call (fields.py:614-617: input_views=None returns alpha) and its gradients into the pts / alpha layers
+    net.zero_grad()
+    s3 = net(pts4.to(dev), None)
+    assert torch.equal(s3, s2.detach())
+    (s3 * w1.to(dev)).sum().backward()
+    for o in on.nerf.values():
+        o.grad = None
+    (O.nerf_forward(on.nerf, pts4, dirs)[0] * w1).sum().backward()
+    for n, p in net.named_parameters():
+        if n.startswith("pts_linears") or n.startswith("alpha_linear"):
+            assert rel(p.grad, on.nerf[n].grad) < GTOL, n
+    # use_viewdirs=False: constructible (output_linear in the state dict), forward asserts like the reference (:629-630)
+    from neuraludf_amd.models import fields
+    nv = fields.NeRF(D=2, W=64, d_in=4, d_in_view=3, multires=2, multires_view=2, use_viewdirs=False).to(dev)
+    assert "output_linear.weight" in nv.state_dict()
+    with pytest.raises(AssertionError):
+        nv(pts4.to(dev), dirs.to(dev))
 
 
 # ---------------------------------------------------------------------------------------------
