@@ -556,6 +556,22 @@ int nudf_color_loss_sums(const float* cb, const float* c, const float* gt, int n
 int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px, float* out, float* den_out,
                            void* stream);
 
+/* The whole loss assembly of a train step when only the two L1 colour terms and the three regularisers are active
+ * (exp_runner_blending.py:330-371; loss/loss.py:105-133; udf_renderer_blending.py:531-536, 553): nudf_color_loss_fwd +
+ * nudf_sums_errors_fwd + total = ((cl + gens w_igr_ns) + sparse w_sparse) + ge w_igr in one launch, each product / sum
+ * of the last line rounded on its own like the runner's scalar torch ops.  out[8] = {total, cl, Lb, Lc, ge, gens,
+ * sparse, 0}; den_out[1].  bwd: upstream d_total (device scalar, NULL = 1) and optionally d_extra[8] for the other
+ * outputs (indexed like out[], NULL = none) -> d_cb / d_c [n] and d_sums[5]. */
+int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
+                       const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns,
+                       float w_sparse, float* out, float* den_out, void* stream);
+int nudf_step_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, const float* sums,
+                       float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns, float w_sparse,
+                       const float* d_total, const float* d_extra, float* d_cb, float* d_c, float* d_sums, void* stream);
+/* out4 [P_pad, 4] (16-byte aligned): column 0 = sign[r] * d[r] * scale (d NULL: sign[r] * scale) for r < P, everything
+ * else zero: the 4-wide column-0 operand of the UDF head's adjoint and second-order weight gradient (fields.py:184-231) */
+int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * GPU-resident ray / patch batch generation: Dataset.gen_random_rays_patches_at (dataset/dataset.py:228-294) and
  * Dataset.near_far_from_sphere (:329-335) in one call.  The pixel coordinates are drawn by the caller

@@ -191,6 +191,7 @@ SYMBOLS = [
     "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
     "nudf_sums_errors_fwd", "nudf_sums_errors_bwd", "nudf_color_loss_fwd", "nudf_color_loss_bwd",
     "nudf_gen_ray_batch", "nudf_color_loss_sums", "nudf_color_loss_finish",
+    "nudf_step_loss_fwd", "nudf_step_loss_bwd", "nudf_col0_seed4",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -245,6 +246,9 @@ _ARGTYPES = {
     "nudf_gen_ray_batch": [C.POINTER(RayBatch), _P],
     "nudf_color_loss_sums": [_P, _P, _P, _I, _P, _I, _P, _P],
     "nudf_color_loss_finish": [_P, _I, _F, _F, _F, _P, _P, _P],
+    "nudf_step_loss_fwd": [_P, _P, _P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P],
+    "nudf_step_loss_bwd": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "nudf_col0_seed4": [_P, _P, _F, _I, _I, _P, _P],
 }
 
 _lib = None

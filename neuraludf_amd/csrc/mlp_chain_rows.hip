@@ -22,6 +22,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// A/B build switches of the transposed-product shared-tile kernel (scripts/build_variants.sh): alternating wave priority
+// per layer (1, shipping) / none (0) / fixed by wave slot (2); the one-off start-up delay of odd wave slots (1 / 0)
+#ifndef NUDF_TQ_PRIO
+#define NUDF_TQ_PRIO 1
+#endif
+#ifndef NUDF_TQ_SLEEP
+#define NUDF_TQ_SLEEP 1
+#endif
 #define CHR_WAVES 4
 #ifndef CHR_STEP_SYNC
 #define CHR_STEP_SYNC 0      // 1: barrier at the top of every step (L1 sharing of the weight stream): measured -3 %
@@ -721,8 +729,10 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
 
   // de-phase the two workgroups of a CU once (see mlp_chain_kernel)
   const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
+#if NUDF_TQ_SLEEP
   if (gridDim.x > 256)
     for (unsigned d = 0; d < (slot & 1u) * 2u; ++d) __builtin_amdgcn_s_sleep(127);
+#endif
 
   unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 64 : nullptr;
   if (dbg && lane == 0) {
@@ -733,7 +743,11 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
 
   for (int si = 0; si < p.n_steps; ++si) {
     const NudfChainStep& st = p.step[si];
+#if NUDF_TQ_PRIO == 1
     if ((si + slot) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif NUDF_TQ_PRIO == 2
+    if (si == 0) __builtin_amdgcn_s_setprio(slot & 1u);
+#endif
     const int G = st.K >> 3;
     const int NT = (st.N + 31) >> 5;
     int rt0, ct0, nrt, nct;

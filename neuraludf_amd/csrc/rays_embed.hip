@@ -722,3 +722,117 @@ extern "C" int nudf_color_loss_bwd(const float* cb, const float* c, const float*
   NUDF_CHECK_LAUNCH("nudf_color_loss_bwd");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The loss assembly of a train step in ONE launch each way (exp_runner_blending.py:330-371 with only the two L1 colour
+// terms and the three regularisers active -- every shipped conf outside the *_ft blending ones):
+//     ColorLoss (loss/loss.py:105-133)            cl = (Lb w_b + Lc w_c) / (w_b + w_c + w_px)
+//     regularisers from the composite sums (:531-536, 553)   ge, gens, sparse
+//     total (:367-371)                             ((cl + gens * w_igr_ns) + sparse * w_sparse) + ge * w_igr
+// Same arithmetic as nudf_color_loss_fwd + nudf_sums_errors_fwd followed by the runner's chain of scalar torch ops (each
+// product and sum rounded on its own); it replaces ~20 one-element launches of that chain and its autograd backward,
+// ~4.5 us each on the critical path of a 5.5 ms step.  out[8] = {total, cl, Lb, Lc, ge, gens, sparse, 0}.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
+                                                             const float* __restrict__ gt, int n,
+                                                             const float* __restrict__ mask, int n_mask,
+                                                             const float* __restrict__ sums, float n_rays, float w_b,
+                                                             float w_c, float w_px, float w_igr, float w_igr_ns,
+                                                             float w_sparse, float* out, float* den_out) {
+  __shared__ float red[3][16];
+  float sb = 0.f, sc = 0.f, sm = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float g = gt[i];
+    sb += fabsf(cb[i] - g);
+    sc += fabsf(c[i] - g);
+  }
+  if (mask)
+    for (int i = threadIdx.x; i < n_mask; i += 1024) sm += mask[i];
+  sb = wave_sum(sb); sc = wave_sum(sc); sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sc; red[2][threadIdx.x >> 6] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tb = 0.f, tc = 0.f, tm = 0.f;
+    for (int w = 0; w < 16; ++w) { tb += red[0][w]; tc += red[1][w]; tm += red[2][w]; }
+    const float den = mask ? (tm + 1e-4f) : (float)n;
+    const float Lb = tb / den, Lc = tc / den;
+    const float cl = (Lb * w_b + Lc * w_c) / (w_b + w_c + w_px);
+    const float ge = sums[0] / (sums[1] + 1e-5f);
+    const float gens = sums[2] / (sums[3] + 1e-5f);
+    const float sp = sums[4] / n_rays;
+    float total = __fadd_rn(cl, __fmul_rn(gens, w_igr_ns));
+    total = __fadd_rn(total, __fmul_rn(sp, w_sparse));
+    total = __fadd_rn(total, __fmul_rn(ge, w_igr));
+    out[0] = total; out[1] = cl; out[2] = Lb; out[3] = Lc; out[4] = ge; out[5] = gens; out[6] = sp; out[7] = 0.f;
+    den_out[0] = den;
+  }
+}
+extern "C" int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
+                                  const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr,
+                                  float w_igr_ns, float w_sparse, float* out, float* den_out, void* stream) {
+  hipLaunchKernelGGL(step_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, sums,
+                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, out, den_out);
+  NUDF_CHECK_LAUNCH("nudf_step_loss_fwd");
+  return 0;
+}
+// upstream: d_total (device scalar; NULL = 1) and, optionally, d_extra[8] for the other outputs (index as out[]; NULL = 0)
+// -> d cb, d c [n], d sums[5]
+__global__ void step_loss_bwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
+                                     const float* __restrict__ gt, int n, const float* __restrict__ den,
+                                     const float* __restrict__ sums, float n_rays, float w_b, float w_c, float w_px,
+                                     float w_igr, float w_igr_ns, float w_sparse, const float* __restrict__ d_total,
+                                     const float* __restrict__ d_extra, float* __restrict__ d_cb, float* __restrict__ d_c,
+                                     float* __restrict__ d_sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float g = d_total ? d_total[0] : 1.0f;
+  const float g_cl = g + (d_extra ? d_extra[1] : 0.0f);
+  if (i == 0) {
+    const float d_ge = __fmul_rn(g, w_igr) + (d_extra ? d_extra[4] : 0.0f);
+    const float d_gens = __fmul_rn(g, w_igr_ns) + (d_extra ? d_extra[5] : 0.0f);
+    const float d_sp = __fmul_rn(g, w_sparse) + (d_extra ? d_extra[6] : 0.0f);
+    const float a = sums[1] + 1e-5f, b = sums[3] + 1e-5f;
+    d_sums[0] = d_ge / a;
+    d_sums[1] = -d_ge * sums[0] / (a * a);
+    d_sums[2] = d_gens / b;
+    d_sums[3] = -d_gens * sums[2] / (b * b);
+    d_sums[4] = d_sp / n_rays;
+  }
+  if (i >= n) return;
+  const float W = w_b + w_c + w_px;
+  const float kb = (g_cl * w_b / W + (d_extra ? d_extra[2] : 0.0f)) / den[0];
+  const float kc = (g_cl * w_c / W + (d_extra ? d_extra[3] : 0.0f)) / den[0];
+  const float t = gt[i];
+  const float a = cb[i] - t, b = c[i] - t;
+  d_cb[i] = kb * ((a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f));
+  d_c[i] = kc * ((b > 0.f) ? 1.f : ((b < 0.f) ? -1.f : 0.f));
+}
+extern "C" int nudf_step_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den,
+                                  const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr,
+                                  float w_igr_ns, float w_sparse, const float* d_total, const float* d_extra, float* d_cb,
+                                  float* d_c, float* d_sums, void* stream) {
+  hipLaunchKernelGGL(step_loss_bwd_kernel, dim3(nblocks(max(n, 1), 256)), dim3(256), 0, (hipStream_t)stream, cb, c, gt, n,
+                     den, sums, n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, d_total, d_extra, d_cb, d_c, d_sums);
+  NUDF_CHECK_LAUNCH("nudf_step_loss_bwd");
+  return 0;
+}
+
+// out4 [P_pad, 4]: column 0 = sign * d * scale (d = NULL: sign * scale), the rest (and rows >= P) zero -- the 4-wide
+// column-0 operand of the UDF head's adjoint / second-order weight gradient (mlp.UDFEngine.backward), in one launch
+// instead of a zero fill, two products and a strided copy.  (sign * d) * scale, each product rounded, as torch does.
+__global__ void col0_seed4_kernel(const float* __restrict__ sign, const float* __restrict__ d, float scale, int P, int P_pad,
+                                  float* __restrict__ out4) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P_pad) return;
+  float v = 0.0f;
+  if (r < P) v = d ? __fmul_rn(__fmul_rn(sign[r], d[r]), scale) : __fmul_rn(sign[r], scale);
+  reinterpret_cast<float4*>(out4)[r] = make_float4(v, 0.0f, 0.0f, 0.0f);
+}
+extern "C" int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4, void* stream) {
+  if (P_pad <= 0) return 0;
+  hipLaunchKernelGGL(col0_seed4_kernel, dim3(nblocks(P_pad, 256)), dim3(256), 0, (hipStream_t)stream, sign, d, scale, P,
+                     P_pad, out4);
+  NUDF_CHECK_LAUNCH("nudf_col0_seed4");
+  return 0;
+}

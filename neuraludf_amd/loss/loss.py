@@ -75,6 +75,48 @@ class _ColorLossFn(torch.autograd.Function):
         return d_cb, d_c, None, None, None, None, None, None
 
 
+class _StepLossFn(torch.autograd.Function):
+    """(color_base, color, gt[, mask], composite sums[5]) -> (total, colour total, Lb, Lc, gradient_error,
+    gradient_error_near_surface, sparse_error): ColorLoss's two L1 terms, the three regularisers and the runner's weighted
+    total (exp_runner_blending.py:330-371) in ONE launch each way (nudf_step_loss_fwd / _bwd) instead of ~20 one-element
+    launches.  Same values as the unfused chain (same reductions, every product / sum of the total rounded on its own)."""
+
+    @staticmethod
+    def forward(ctx, cb, c, gt, mask, sums, n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse):
+        from .._lib import call, ptr
+        ctx.set_materialize_grads(False)
+        cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
+        m_ = mask.detach().float().contiguous() if mask is not None else None
+        sums_ = sums.detach().contiguous()
+        out = torch.empty(8, device=cb_.device)
+        den = torch.empty(1, device=cb_.device)
+        w = tuple(float(x) for x in (w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse))
+        call("nudf_step_loss_fwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_), m_.numel() if m_ is not None else 0,
+             ptr(sums_), float(n_rays), *w, ptr(out), ptr(den))
+        ctx.save_for_backward(cb_, c_, gt_, den, sums_)
+        ctx.w, ctx.n_rays = w, float(n_rays)
+        return tuple(out[i] for i in range(7))
+
+    @staticmethod
+    def backward(ctx, *d):
+        from .._lib import call, ptr
+        if all(x is None for x in d):
+            return (None,) * 12
+        cb_, c_, gt_, den, sums_ = ctx.saved_tensors
+        d_total = d[0].contiguous() if d[0] is not None else None      # autograd's own tensor: no extra launch
+        d_extra = None
+        if any(x is not None for x in d[1:]) or d_total is None:      # gradients into the logged terms: rare
+            z = den.new_zeros(())
+            d_extra = torch.stack([z] + [x if x is not None else z for x in d[1:]] + [z])
+            if d_total is None:
+                d_total = z
+        d_cb, d_c = torch.empty_like(cb_), torch.empty_like(c_)
+        d_sums = torch.empty(5, device=cb_.device)
+        call("nudf_step_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), ptr(sums_), ctx.n_rays, *ctx.w,
+             ptr(d_total), ptr(d_extra), ptr(d_cb), ptr(d_c), ptr(d_sums))
+        return (d_cb, d_c, None, None, d_sums) + (None,) * 7
+
+
 class _ColorLossFromSumsFn(torch.autograd.Function):
     """second half of the ray-sharded fused ColorLoss: the GLOBAL sums [sum|cb-gt|, sum|c-gt|, D] (already all-reduced,
     packed with the renderer's sums by the caller, dist.py (1)) -> (total, color_base_loss, color_loss); the backward

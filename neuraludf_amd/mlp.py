@@ -867,9 +867,12 @@ class UDFEngine:
         if head4_path:
             # the head's adjoint is [sign * d udf / scale | d feat]: d feat is used where it lies (tile load, GEMM operand)
             # and column 0 travels as a 4-wide operand -- no [P, 257] copy (52 us), no separate column-sum kernel (36 us)
-            head4 = torch.zeros(pad_rows(P), 4, device=dev)
-            if d_udf is not None:
-                head4[:P, 0] = sign * d_udf.reshape(-1) * inv_scale
+            head4 = torch.empty(pad_rows(P), 4, device=dev)
+            if d_udf is not None:      # column 0 = sign * d udf / scale, the rest zero: one launch
+                call("nudf_col0_seed4", ptr(sign), ptr(d_udf.reshape(-1).contiguous()), float(inv_scale), P, pad_rows(P),
+                     ptr(head4))
+            else:
+                head4.zero_()
             r1, ldr1 = head4, 4
         else:
             ABAR[L] = _buf(P, plL.out, dev, zero=False)
@@ -915,8 +918,9 @@ class UDFEngine:
             if second:
                 jobs = [(DA[l], layers[l].out, R[l], layers[l].in_pad, grads[l][0], None) for l in range(L)]
                 if head4_path:
-                    sg4 = torch.zeros(pad_rows(P), 4, device=dev)
-                    sg4[:P, 0] = sign * inv_scale  # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
+                    sg4 = torch.empty(pad_rows(P), 4, device=dev)
+                    # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
+                    call("nudf_col0_seed4", ptr(sign), None, float(inv_scale), P, pad_rows(P), ptr(sg4))
                     jobs.append((sg4, 1, R[L], plL.in_pad, dWL[:1], None))
                 gemm_tn_grouped(jobs, P)
             return unpack_group(layers, grads, claim_grad_slot(self, layers))

@@ -258,7 +258,9 @@ class UDFRendererBlending:
         self.diagnostics = True            # fill the debug keys of the result dict
         self.compute_sparse_random = False
         self.data_parallel = False         # all-reduce the batch-global loss sums over the process group
-        self.defer_loss_sums = False       # data parallel only: hand the LOCAL sums to the caller (key '_loss_sums')
+        self.defer_loss_sums = False       # hand the (local) sums to the caller (key '_loss_sums') instead of the three error
+                                           # terms: the ray-sharded step packs them into its one all-reduce, the
+                                           # single-process step finishes them inside its fused loss launch (train.Trainer)
         from .patch_projector import PatchProjector
         self.patch_projector = PatchProjector(self.h_patch_size)
         self._u_cache = {}
@@ -399,7 +401,7 @@ class UDFRendererBlending:
         color, color_base, weights, depth, normals, wsum, wsum_all, sums = outs[:8]
         diag = dict(zip(_DIAG, outs[8:])) if self.diagnostics else {}
         local_sums = None
-        if self.data_parallel and self.defer_loss_sums and nudf_dist.world_size() > 1:
+        if self.defer_loss_sums and (not self.data_parallel or nudf_dist.world_size() > 1):
             # ray-sharded step: the caller packs these five LOCAL sums with its other batch-global partial sums into ONE
             # all-reduce and finishes with `errors_from_sums` (train.Trainer.loss; dist.py (1))
             local_sums = sums

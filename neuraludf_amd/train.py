@@ -107,19 +107,32 @@ class GraphedStep:
             if ent["calls"] <= self.eager_steps:
                 return tr.step(batch, **kw)
             self._capture(ent, batch, blend, cos_anneal_ratio is not None, flip_saturation, perturb_overwrite)
+        # inputs: copied into the captured step's static tensors -- unless the caller already writes them there
+        # (`static_inputs`: a resident batch, or a batch generator given these tensors as its outputs): every copy is a
+        # ~5 us launch on the critical path
         for k, v in ent["batch"].items():
-            if v is not batch[k]:
-                v.copy_(batch[k])
+            src = batch[k]
+            if torch.is_tensor(v) and src is not v and src.data_ptr() != v.data_ptr():
+                v.copy_(src)
         if blend is not None:
             for k, v in ent["blend"].items():
-                if v is not blend[k]:
-                    v.copy_(blend[k])
+                src = blend[k]
+                if torch.is_tensor(v) and src is not v and src.data_ptr() != v.data_ptr():
+                    v.copy_(src)
         self.scalars.upload([0.0 if cos_anneal_ratio is None else float(cos_anneal_ratio), float(flip_saturation)],
                             tr.optimizer.dyn_values())
         ent["graph"].replay()
         tr.optimizer.advance()
         self.replays += 1
         return ent["loss"], ent["out"]
+
+    def static_inputs(self, batch, blend=None, cos_anneal_ratio=1.0, perturb_overwrite=-1):
+        """the captured step's own input tensors for this kind of batch (None before its capture): fill them in place
+        (or pass them back as the batch) and the replay needs no input copies."""
+        ent = self.graphs.get(self._key(batch, blend, cos_anneal_ratio is not None, perturb_overwrite))
+        if ent is None or ent["graph"] is None:
+            return None
+        return ent["batch"], ent["blend"]
 
     def _capture(self, ent, batch, blend, has_anneal, flip_saturation, perturb_overwrite):
         tr = self.tr
@@ -188,6 +201,8 @@ class Trainer:
             self.color_loss = loss_cls(**lc)
         self.data_parallel = data_parallel
         self._beta_flag = True
+        if not data_parallel:
+            self.renderer.defer_loss_sums = True        # the step's loss assembly is fused (see `loss`)
         if data_parallel:
             self.renderer.data_parallel = True
             self.renderer.defer_loss_sums = True
@@ -233,7 +248,26 @@ class Trainer:
         if tc["mask_weight"] > 0:
             bce_sum = torch.nn.functional.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3), batch["mask"],
                                                                reduction="sum")
-        if "_loss_sums" in out:
+        if "_loss_sums" in out and not self.data_parallel:
+            # single-process step: the renderer handed over the composite kernel's five sums; when only the two L1 colour
+            # terms are active (every shipped conf outside the *_ft blending ones) the whole loss assembly -- ColorLoss,
+            # the three regularisers, the weighted total -- is ONE launch each way (loss._StepLossFn)
+            sums = out.pop("_loss_sums")
+            if bce_sum is None and self.color_loss.fusable(out["color_base"], out["color"], batch["true_rgb"],
+                                                           out["color_pixel"], out["patch_colors"]):
+                from .loss.loss import _StepLossFn
+                cw = self.color_loss
+                loss, _, _, _, ge, gens, se = _StepLossFn.apply(
+                    out["color_base"], out["color"], batch["true_rgb"], pixel_mask, sums, float(weight_sum.shape[0]),
+                    cw.color_base_weight, cw.color_weight, cw.color_pixel_weight, tc["igr_weight"], tc["igr_ns_weight"],
+                    tc["sparse_weight"])
+                out["gradient_error"], out["gradient_error_near_surface"], out["sparse_error"] = ge, gens, se
+                return loss, out
+            ge, gens, se = self.renderer.errors_from_sums(sums, weight_sum.shape[0])
+            out["gradient_error"], out["gradient_error_near_surface"], out["sparse_error"] = ge, gens, se
+            cl = self.color_loss(*cargs)
+            mask_loss = bce_sum / float(weight_sum.numel()) if bce_sum is not None else None
+        elif "_loss_sums" in out:
             # ray-sharded step: ONE all-reduce of every batch-global partial sum -- the renderer's five, the fused colour
             # loss's three and the mask term's two (dist.py (1)); everything after it is the same arithmetic on every rank
             parts = [out.pop("_loss_sums")]
