@@ -310,12 +310,16 @@ def main():
     if use_graph:                      # set-up, not warm-up: two eager steps, then the capture (+ its first replay)
         for _ in range(3):
             run_step()
-        assert gstep.replays == 1
-        # the batch is resident (as in the eager loop): hand the replays the captured step's own input tensors, so that no
-        # per-step input copy is enqueued
-        batch, blend_static = gstep.static_inputs(batch, step_kw.get("blend"))
-        if blend_static is not None:
-            step_kw["blend"] = blend_static
+        st_in = gstep.static_inputs()
+        if gstep.replays != 1 or st_in is None:      # this configuration could not be captured: eager launches
+            use_graph = False
+            run_step = lambda: tr.step(batch, **step_kw)
+        else:
+            # the batch is resident (as in the eager loop): hand the replays the captured step's own input tensors, so
+            # that no per-step input copy is enqueued
+            batch, blend_static = st_in
+            if blend_static is not None:
+                step_kw["blend"] = blend_static
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()

@@ -148,8 +148,10 @@ def patch_cameras(ref_intrinsic, src_intrinsics, ref_c2w, src_c2ws):
 
 
 def blend_and_composite(hps, pts, logits, weights, grad, rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv,
-                        bg_in=None, bg_tail=None):
-    """-> (color_pixel [N,3], patch_colors [N,Npx,3] | None, patch_mask [N] | None)."""
+                        bg_in=None, bg_tail=None, patch_cams=None):
+    """-> (color_pixel [N,3], patch_colors [N,Npx,3] | None, patch_mask [N] | None).
+    `patch_cams` = patch_cameras(...) computed by the caller (a graph-captured step: the four small matrix inverses of the
+    camera constants run through a solver library that cannot be captured, so train.GraphedStep computes them outside)."""
     N, S = pts.shape[0], pts.shape[1]
     V, _, H, W = color_maps.shape
     proj = torch.matmul(intrinsics[:, :3, :3], w2cs[:, :3, :]).reshape(V, 12)      # projector_utils.py:69-70
@@ -160,7 +162,8 @@ def blend_and_composite(hps, pts, logits, weights, grad, rays_d, color_maps, w2c
         # the reference rescales the caller's uv tensor in place from (-1,1) to pixels (patch_projector.py:75-76)
         rays_uv[:, 0] = (rays_uv[:, 0] + 1) / 2. * (W - 1)
         rays_uv[:, 1] = (rays_uv[:, 1] + 1) / 2. * (H - 1)
-        ref_cam, src_cam = patch_cameras(intrinsics[0], intrinsics, query_c2w, torch.inverse(w2cs))
+        ref_cam, src_cam = patch_cams if patch_cams is not None else patch_cameras(intrinsics[0], intrinsics, query_c2w,
+                                                                                   torch.inverse(w2cs))
         patch_colors, patch_mask = _PatchBlendFn.apply(pts, grad, rays_d, rays_uv, logits, weights, ref_cam, src_cam,
                                                        color_maps, hps)
     return color_pixel, patch_colors, patch_mask

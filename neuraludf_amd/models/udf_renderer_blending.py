@@ -377,7 +377,8 @@ class UDFRendererBlending:
 
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, cos_anneal_ratio=None, background_rgb=None,
                     bg_z=None, bg_sigma=None, bg_color=None, flip_saturation=0.0, color_maps=None, w2cs=None,
-                    intrinsics=None, query_c2w=None, img_index=None, rays_uv=None, s_nominal=None, bg_color_in=None):
+                    intrinsics=None, query_c2w=None, img_index=None, rays_uv=None, s_nominal=None, bg_color_in=None,
+                    patch_cams=None):
         """(:327-584) given sorted samples."""
         N, S = z_vals.shape
         dev = z_vals.device
@@ -422,7 +423,8 @@ class UDFRendererBlending:
                                           "and unused; every call site passes None")
             color_pixel, patch_colors, patch_mask = blend.blend_and_composite(
                 self.h_patch_size, pts.reshape(N, S, 3), logits.reshape(N, S, -1), weights, grad.reshape(N, S, 3).detach(),
-                rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv, bg_in=bg_color_in, bg_tail=bg_color)
+                rays_d, color_maps, w2cs, intrinsics, query_c2w, rays_uv, bg_in=bg_color_in, bg_tail=bg_color,
+                patch_cams=patch_cams)
 
         g3 = grad.reshape(N, S, 3)
         ret = {
@@ -450,7 +452,7 @@ class UDFRendererBlending:
     # ------------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, near, far, cos_anneal_ratio=None, perturb_overwrite=-1, background_rgb=None,
                flip_saturation=0, color_maps=None, w2cs=None, intrinsics=None, query_c2w=None, img_index=None,
-               rays_uv=None, z_vals_override=None):
+               rays_uv=None, z_vals_override=None, patch_cams=None):
         dev = rays_o.device
         N = len(rays_o)
         if N == 0:
@@ -512,7 +514,7 @@ class UDFRendererBlending:
             bgrgb = torch.as_tensor(background_rgb, dtype=torch.float32, device=dev).reshape(-1)[:3].contiguous()
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, cos_anneal_ratio, bgrgb, z_out, bg_sigma,
                                bg_color, flip_saturation, color_maps, w2cs, intrinsics, query_c2w, img_index, rays_uv,
-                               s_nominal=n_samples, bg_color_in=bg_color_in)
+                               s_nominal=n_samples, bg_color_in=bg_color_in, patch_cams=patch_cams)
 
         sparse_random_error = 0.0
         if True:

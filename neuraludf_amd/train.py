@@ -82,6 +82,7 @@ class GraphedStep:
         self.enabled = isinstance(trainer.optimizer, FusedAdam) and not trainer.data_parallel
         self.scalars = None
         self.replays = 0
+        self._last = None
 
     def _key(self, batch, blend, has_anneal, perturb_overwrite):
         tr = self.tr
@@ -94,7 +95,9 @@ class GraphedStep:
         tr = self.tr
         kw = dict(cos_anneal_ratio=cos_anneal_ratio, flip_saturation=flip_saturation, blend=blend,
                   perturb_overwrite=perturb_overwrite)
-        if not self.enabled:
+        if not self.enabled or (blend is not None and tr.lc["color_patch_weight"] > 0):
+            # (the trimmed patch loss reads its trim count on the host -- loss/loss.py:79-84 -- so a step with it on cannot be
+            # captured; it is 15 ms of kernels, far from launch-bound)
             return tr.step(batch, **kw)
         key = self._key(batch, blend, cos_anneal_ratio is not None, perturb_overwrite)
         ent = self.graphs.get(key)
@@ -103,10 +106,20 @@ class GraphedStep:
                 self.graphs.pop(next(iter(self.graphs)))
             ent = self.graphs[key] = dict(calls=0, graph=None)
         ent["calls"] += 1
+        self._last = ent
         if ent["graph"] is None:
-            if ent["calls"] <= self.eager_steps:
+            if ent["calls"] <= self.eager_steps or ent.get("failed"):
                 return tr.step(batch, **kw)
-            self._capture(ent, batch, blend, cos_anneal_ratio is not None, flip_saturation, perturb_overwrite)
+            prev_stream = torch.cuda.current_stream()
+            try:
+                self._capture(ent, batch, blend, cos_anneal_ratio is not None, flip_saturation, perturb_overwrite)
+            except Exception as e:      # an op of this configuration cannot be captured: this key stays eager
+                import warnings
+                ent["failed"], ent["graph"] = True, None
+                torch.cuda.set_stream(prev_stream)      # torch.cuda.graph.__exit__ skips this when capture_end raises
+                torch.cuda.synchronize()
+                warnings.warn("GraphedStep: capture failed (%s); this configuration keeps running eagerly" % (e,))
+                return tr.step(batch, **kw)
         # inputs: copied into the captured step's static tensors -- unless the caller already writes them there
         # (`static_inputs`: a resident batch, or a batch generator given these tensors as its outputs): every copy is a
         # ~5 us launch on the critical path
@@ -126,11 +139,11 @@ class GraphedStep:
         self.replays += 1
         return ent["loss"], ent["out"]
 
-    def static_inputs(self, batch, blend=None, cos_anneal_ratio=1.0, perturb_overwrite=-1):
-        """the captured step's own input tensors for this kind of batch (None before its capture): fill them in place
-        (or pass them back as the batch) and the replay needs no input copies."""
-        ent = self.graphs.get(self._key(batch, blend, cos_anneal_ratio is not None, perturb_overwrite))
-        if ent is None or ent["graph"] is None:
+    def static_inputs(self):
+        """(batch, blend) input tensors of the step captured / replayed by the last call (None before a capture): fill
+        them in place -- or pass them back as the batch -- and the replay needs no input copies."""
+        ent = self._last
+        if ent is None or ent.get("graph") is None:
             return None
         return ent["batch"], ent["blend"]
 
@@ -234,6 +247,8 @@ class Trainer:
             kw = dict(color_maps=blend["color_maps"], w2cs=blend["w2cs"], intrinsics=blend["intrinsics"],
                       query_c2w=blend["query_c2w"],
                       rays_uv=batch["rays_uv"].clone() if lc["color_patch_weight"] > 0 else None)
+            if "ref_cam" in blend:        # patch-camera constants computed by the caller (GraphedStep: outside the capture)
+                kw["patch_cams"] = (blend["ref_cam"], blend["src_cam"])
         out = self.renderer.render(batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
                                    flip_saturation=flip_saturation, cos_anneal_ratio=cos_anneal_ratio,
                                    perturb_overwrite=perturb_overwrite, **kw)

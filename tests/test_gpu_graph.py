@@ -75,3 +75,36 @@ def test_new_loss_weights_are_a_new_capture_and_dp_stays_eager():
     assert len(gs.graphs) == 3
     tr2 = Trainer(dev, RCONF, seed=0, fused_adam=False)           # torch.optim.Adam: no dynamic-scalar path -> eager
     assert not GraphedStep(tr2).enabled
+
+
+def test_pixel_blending_step_replays_and_patch_loss_stays_eager():
+    """pixel blending over source views (colour_pixel term on) is captured -- its camera products are graph-safe -- and
+    replays bit-identically; with the trimmed patch loss on (a host-side trim count) the step stays eager."""
+    from neuraludf_amd.train import Trainer, GraphedStep
+    dev = torch.device("cuda:0")
+    rconf = dict(n_samples=24, n_importance=12, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
+                 use_norm_grad_for_cosine=True, h_patch_size=3)
+    scene = synth.make_scene("tiny")
+    src = {k: v.to(dev) for k, v in synth.make_source_views(scene, 0, 8).items()}
+    batch = {k: v.to(dev) for k, v in synth.make_rays(scene, 0, 96, seed=9, margin=6).items()}
+
+    def run(graphed, lconf, n=5):
+        tr = Trainer(dev, rconf, color_loss_conf=lconf, seed=0, fused_adam=True)
+        st = GraphedStep(tr, eager_steps=1) if graphed else tr.step
+        torch.manual_seed(7)
+        hist = []
+        for i in range(n):
+            loss, out = st(batch, cos_anneal_ratio=0.5 + 0.1 * i, flip_saturation=0.9, blend=src)
+            hist.append((loss.clone(), out["color_pixel"].detach().clone()))
+        torch.cuda.synchronize()
+        return st, hist
+
+    lconf = dict(color_pixel_weight=0.5, color_patch_weight=0.0)
+    _, eager = run(False, lconf)
+    gs, graph = run(True, lconf)
+    assert gs.replays == 4
+    for i, (a, b) in enumerate(zip(eager, graph)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), i
+    batch["gt_patch_colors"] = torch.rand(96, 49, 3, device=dev)
+    gs2, _ = run(True, dict(color_pixel_weight=0.5, color_patch_weight=0.1), n=3)
+    assert gs2.replays == 0 and len(gs2.graphs) == 0
