@@ -78,6 +78,28 @@ def _cpu_info():
     return model, firsts
 
 
+def _vs_reference_fixture(workload, n_rays, rays, got):
+    """the same comparison against outputs the REFERENCE ITSELF produced on these exact inputs (build container, CPU):
+    tests/golden/ref_bench_cfg2_full.npz, written by tests/golden/make_golden_full.py bench_cfg2 -- bench.py's own rays
+    (dtu scene, camera 0, seed 1234), seed-0 weights, cos_anneal_ratio = flip_saturation = 1.  None for other workloads."""
+    import math
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "ref_bench_cfg2_full.npz")
+    if workload != "dtu_scan24_512x128" or n_rays != 512 or not os.path.exists(path):
+        return None
+    fx = np.load(path)
+    if not np.array_equal(fx["ray_rays_d"], rays["rays_d"].numpy()) or not np.array_equal(fx["ray_rays_o"], rays["rays_o"].numpy()):
+        return {"error": "fixture rays differ from the timed rays"}
+    col, zv, w = (torch.from_numpy(fx[k]) for k in ("out_color", "out_z_vals", "out_weights"))
+    same = (got["z_vals"] - zv).abs().max(dim=1)[0] < 1e-4
+    mse = float(((got["color"] - col) ** 2).mean())
+    return {"value_db": 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-30)), "max_abs_diff": float((got["color"] - col).abs().max()),
+            "rays_with_identical_samples": int(same.sum()),
+            "max_abs_diff_on_rays_with_identical_samples": float((got["color"] - col)[same].abs().max()) if bool(same.any()) else None,
+            "weights_max_abs_diff_on_rays_with_identical_samples": float((got["weights"] - w)[same].abs().max()) if bool(same.any()) else None,
+            "fixture": "tests/golden/ref_bench_cfg2_full.npz (the reference's own CPU run on these rays and weights)"}
+
+
 def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_rays=None):
     """The CPU leg of BASELINE's metric: one full train step (render + loss + backward + Adam) on the host cores, on a
     bounded sample of the timed workload.  kind "reference": the reference's OWN UDFRendererBlending / ColorLoss classes
@@ -133,6 +155,7 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
                 "weights_max_abs_diff": float(dw.max()),
                 "weight_mass_on_moved_samples": (float(ref["weights"][:, :moved.shape[1]][moved].sum()) / wsum) if wsum > 0 else None,
                 "rays": n_rays, "rays_with_identical_samples": int(same.sum()), "samples_per_ray": s_core, "precision": precision,
+                "vs_reference_fixture": _vs_reference_fixture(workload, n_rays, rays, got),
                 "what": "HIP colours / weights vs the oracle's END TO END on identical rays / network weights: the hierarchical "
                         "sampling runs on both sides, so rays whose quantile bins flip (tests/test_gpu_fullsize_parity.py) enter "
                         "with different sample positions; weight_mass_on_moved_samples = share of the reference's total "

@@ -41,8 +41,12 @@ CASES = {
     # source images are not stored: common.smooth_images(8, 1024, 1024) regenerates them from the seed.
     "cfg3_garment": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=3, perturb=1.0, upsampling_type="mix",
                          use_norm_grad_for_cosine=True, h_patch_size=3),
+    # the EXACT inputs bench.py times and scores (`psnr_vs_ref`): dtu scene (1600 x 1200, f = 2892), camera 0, 512 rays
+    # drawn with seed 1234 and no margin, seed-0 weights WITHOUT the perturbation, cos_anneal_ratio = flip_saturation = 1:
+    # file ref_bench_cfg2_full.npz (per-ray outputs, sample positions, weights)
+    "bench_cfg2": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0),
 }
-SCENE = {"cfg3_garment": "garment"}
+SCENE = {"cfg3_garment": "garment", "bench_cfg2": "dtu"}
 RAYS = {"cfg5_shape": 1024, "cfg3_garment": 1024}
 # garment scene: fov 60 deg from radius 2.2 -- the central 424 x 424 pixels see the object (elsewhere weight_sum ~ 0 and
 # the blending terms would be compared on empty rays)
@@ -66,11 +70,16 @@ def main():
     kw = CASES[case]
     rf, rr, rl = load_reference()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    mods = perturb_(build_modules(rf, seed=0))
+    mods = build_modules(rf, seed=0)
+    if case != "bench_cfg2":
+        mods = perturb_(mods)
     sums = {k: checksum(v) for k, v in state_dicts(mods).items()}
     scene = synth.make_scene(SCENE.get(case, "tiny"))
     n_rays = RAYS.get(case, N_RAYS)
-    rays = synth.make_rays(scene, 0, n_rays, seed=11, margin=MARGIN.get(case, 6))
+    if case == "bench_cfg2":
+        rays = synth.make_rays(scene, 0, n_rays, seed=1234)            # bench.py's own call
+    else:
+        rays = synth.make_rays(scene, 0, n_rays, seed=11, margin=MARGIN.get(case, 6))
     r = rr.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
     t0 = time.time()
     bkw, keys = {}, list(KEYS)
@@ -81,8 +90,9 @@ def main():
         bkw = dict(color_maps=src["color_maps"], w2cs=src["w2cs"], intrinsics=src["intrinsics"],
                    query_c2w=src["query_c2w"], rays_uv=rays["rays_uv"].clone())
         keys += ["color_pixel", "patch_colors", "patch_mask"]
-    out = r.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7, perturb_overwrite=0,
-                   flip_saturation=0.9, **bkw)
+    sched = dict(cos_anneal_ratio=1.0, flip_saturation=1.0) if case == "bench_cfg2" else dict(cos_anneal_ratio=0.7,
+                                                                                              flip_saturation=0.9)
+    out = r.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], perturb_overwrite=0, **sched, **bkw)
     loss = loss_of(out, rays)
     extra = {}
     if blend:
@@ -102,6 +112,8 @@ def main():
     if case == "cfg5_shape":      # keep the file small: per-ray outputs, sample positions and weights only
         keys = ["z_vals", "color", "color_base", "weights", "depth", "weight_sum", "gradient_error",
                 "gradient_error_near_surface", "sparse_error"]
+    if case == "bench_cfg2":
+        keys = ["z_vals", "color", "color_base", "weights", "depth", "weight_sum"]
     if case == "cfg3_garment":    # per-ray outputs, sample positions, weights and udf (no [N,S,3] arrays)
         keys = ["z_vals", "color", "color_base", "weights", "depth", "udf", "normals", "weight_sum", "gradient_error",
                 "gradient_error_near_surface", "sparse_error", "color_pixel", "patch_colors", "patch_mask"]

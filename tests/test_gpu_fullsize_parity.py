@@ -457,3 +457,57 @@ def test_mixed16_at_cfg5_shape_vs_reference(dev):
     assert p_base >= 60.0, p_base
     assert cos_min > 0.99, (cos_key, cos_min)
     assert abs(float(loss) - float(fx["loss"])) < 2e-3
+
+
+def test_bench_inputs_vs_reference_fixture(dev):
+    """the EXACT inputs bench.py times and scores -- dtu scene (1600 x 1200, f = 2892), camera 0, 512 rays drawn with seed
+    1234, seed-0 weights without perturbation, cos_anneal_ratio = flip_saturation = 1 -- against the reference's own CPU
+    run on them (fixture ref_bench_cfg2_full.npz, make_golden_full.py bench_cfg2): render_core on the reference's samples
+    (values 1e-4, all parameter gradients 1e-3) and the end-to-end render (rays with identical samples, colours on them)."""
+    from neuraludf_amd import synth
+    from neuraludf_amd.models import fields
+    from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
+    fx = dict(np.load(os.path.join(HERE, "golden", "ref_bench_cfg2_full.npz")))
+    mods = build_modules(fields, seed=0)
+    for k, v in state_dicts(mods).items():
+        assert abs(checksum(v) - float(fx["wsum_" + k])) < 1e-6 * max(1.0, abs(float(fx["wsum_" + k]))), k
+    for m in mods.values():
+        m.to(dev)
+    rays_cpu = synth.make_rays(synth.make_scene("dtu"), 0, 512, seed=1234)               # bench.py's own call
+    assert np.array_equal(fx["ray_rays_d"], rays_cpu["rays_d"].numpy())
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    rend = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **KW)
+    z_ref = torch.from_numpy(fx["out_z_vals"]).to(dev)
+    out = rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0, perturb_overwrite=0,
+                      flip_saturation=1.0, z_vals_override=z_ref)
+    loss = _loss(out, rays["true_rgb"])
+    loss.backward()
+    torch.cuda.synchronize()
+    wd = (out["weights"].detach().cpu() - torch.from_numpy(fx["out_weights"])).abs().max(dim=1)[0]
+    ok = wd < 1e-4
+    assert int((~ok).sum()) <= 3, int((~ok).sum())          # rays with a flipped hard alpha selection (see the cfg5 test)
+    for k in ["color", "color_base", "weight_sum"]:
+        assert rel(out[k], fx["out_" + k]) < VTOL, k
+    for k in ["weights", "depth"]:
+        assert rel(out[k].detach().cpu()[ok], torch.from_numpy(fx["out_" + k])[ok]) < VTOL, k
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
+    worst, n = ("", 0.0), 0
+    for net in ("udf", "color", "var", "beta"):
+        for pn, p in mods[net].named_parameters():
+            key = f"grad_{net}_{pn}"
+            if key not in fx or p.grad is None:
+                continue
+            r = rel(p.grad, fx[key])
+            n += 1
+            if r > worst[1]:
+                worst = (key, r)
+            assert r < GTOL, (key, r)
+    assert n >= 50
+    with torch.no_grad():
+        e2e = rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0, perturb_overwrite=0,
+                          flip_saturation=1.0)
+    good = (e2e["z_vals"].cpu() - torch.from_numpy(fx["out_z_vals"])).abs().max(dim=1)[0] < 1e-4
+    assert float(good.float().mean()) > 0.75, int(good.sum())
+    assert rel(e2e["color"][good.to(dev)], torch.from_numpy(fx["out_color"])[good]) < VTOL
+    print(f"bench inputs vs the reference: {n} parameter gradients, worst {worst[0]} {worst[1]:.2e}; rays with a flipped alpha "
+          f"selection {int((~ok).sum())}; end to end {int(good.sum())} / 512 rays with the reference's samples")
