@@ -171,7 +171,6 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
 USE_CHAIN = os.environ.get("NUDF_CHAIN", "1") != "0"     # 0: per-layer GEMM launches (A/B measurements, cross-checks)
 CHAIN_DEBUG = None     # int64 tensor [blocks * 4, 32]: per-wave timeline written by the kernel (scripts/chain_timeline.py)
 CHAIN_TILE = int(os.environ.get("NUDF_CHAIN_TILE", "0"))  # 0 = auto, 32 / 64 force the points-per-workgroup tile
-COLOR_TILE = int(os.environ.get("NUDF_COLOR_TILE", "0"))  # the colour network's three chain launches only (A/B)
 
 
 def k8(n: int) -> int:
@@ -1141,7 +1140,7 @@ class ColorEngine:
         VIN = torch.empty(Pp, pad32(H + npe + dout), device=dev) if keep_state else None
         HB = [CIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
         HV = [VIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
-        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp), tile_rows=COLOR_TILE)
+        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp))
         cb.init_load(CIN, CIN.shape[1])
         cb.posenc(rays_d, self.net.multires_view, 1.0, x_div=S)
         for l in range(n - 1):
@@ -1180,7 +1179,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(Dv[n - 1]), Dv[n - 1].shape[1])
         dVIN = _buf(P, self.view[0].inp, dev, zero=False)
-        cb = ChainBuilder(P, "LOAD", k8(plv.out), tile_rows=COLOR_TILE)
+        cb = ChainBuilder(P, "LOAD", k8(plv.out))
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
@@ -1194,7 +1193,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (H + npe), dVIN.shape[1],
              dout, None, 0, 0, P, ptr(Db[n - 1]), Db[n - 1].shape[1])
         dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)
-        cb = ChainBuilder(P, "LOAD", k8(plb.out), tile_rows=COLOR_TILE)
+        cb = ChainBuilder(P, "LOAD", k8(plb.out))
         cb.init_load(Db[n - 1], Db[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.base[i]

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: records an experiment of round 3 whose code was removed again (NUDF_CHAIN_RING / NUDF_CHAIN_W8 / NUDF_COLOR_TILE / NUDF_SEQ16
+# switches no longer exist); kept as the provenance of profiles/r03_chain_experiments.txt.
 # round 3, call D: K-loop pipeline depth (NUDF_CHAIN_RING 0 / 3 / 4), ring for the tq sweeps (NUDF_TQ_RING=3), colour-net
 # tile size; per-kernel lines of the bench for each; bit-identity of the ring kernels vs the two-set loop
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: records an experiment of round 3 whose code was removed again (NUDF_CHAIN_RING / NUDF_CHAIN_W8 / NUDF_COLOR_TILE / NUDF_SEQ16
+# switches no longer exist); kept as the provenance of profiles/r03_chain_experiments.txt.
 # round 3, call G: 8 waves per workgroup for 32-point tiles / narrow chains (NUDF_CHAIN_W8 = 0 / 1 / 2 / 3), tq ring default,
 # chain-kernel parity suites incl. the paired kernel's bit-identity
 cd $GRAFT_REPO_ROOT
