@@ -78,25 +78,36 @@ def _cpu_info():
     return model, firsts
 
 
-def _vs_reference_fixture(workload, n_rays, rays, got):
-    """the same comparison against outputs the REFERENCE ITSELF produced on these exact inputs (build container, CPU):
-    tests/golden/ref_bench_cfg2_full.npz, written by tests/golden/make_golden_full.py bench_cfg2 -- bench.py's own rays
-    (dtu scene, camera 0, seed 1234), seed-0 weights, cos_anneal_ratio = flip_saturation = 1.  None for other workloads."""
+def _vs_reference_fixture(workload, n_rays, rays, rend, dev):
+    """the same comparison against outputs the REFERENCE ITSELF produced (build container, CPU) on the timed inputs:
+    tests/golden/ref_bench_cfg2_full.npz, written by tests/golden/make_golden_full.py bench_cfg2 -- bench.py's own ray
+    construction (dtu scene, camera 0, seed 1234), seed-0 weights, cos_anneal_ratio = flip_saturation = 1.  The fixture's
+    stored rays are rendered (this host's CPU builds the same rays to within an ulp of the ray directions; `ray_ulp_diff`
+    says by how much).  None for other workloads."""
     import math
     import numpy as np
     path = os.path.join(ROOT, "tests", "golden", "ref_bench_cfg2_full.npz")
     if workload != "dtu_scan24_512x128" or n_rays != 512 or not os.path.exists(path):
         return None
     fx = np.load(path)
-    if not np.array_equal(fx["ray_rays_d"], rays["rays_d"].numpy()) or not np.array_equal(fx["ray_rays_o"], rays["rays_o"].numpy()):
-        return {"error": "fixture rays differ from the timed rays"}
+    fr = {k: torch.from_numpy(fx["ray_" + k]) for k in ("rays_o", "rays_d", "near", "far")}
+    ray_diff = float((fr["rays_d"] - rays["rays_d"]).abs().max())
+    if ray_diff > 1e-6:
+        return {"error": "fixture rays differ from the timed rays by %g" % ray_diff}
+    with torch.no_grad():
+        got = rend.render(fr["rays_o"].to(dev), fr["rays_d"].to(dev), fr["near"].to(dev), fr["far"].to(dev),
+                          cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
+    got = {k: got[k].cpu() for k in ("color", "z_vals", "weights")}
     col, zv, w = (torch.from_numpy(fx[k]) for k in ("out_color", "out_z_vals", "out_weights"))
-    same = (got["z_vals"] - zv).abs().max(dim=1)[0] < 1e-4
+    zerr = (got["z_vals"] - zv).abs().max(dim=1)[0]
+    same, exact = zerr < 1e-4, zerr < 1e-5
     mse = float(((got["color"] - col) ** 2).mean())
     return {"value_db": 20.0 * math.log10(1.0 / math.sqrt(mse + 1e-30)), "max_abs_diff": float((got["color"] - col).abs().max()),
-            "rays_with_identical_samples": int(same.sum()),
+            "rays_with_identical_samples": int(same.sum()), "rays_with_samples_within_1e-5": int(exact.sum()),
+            "max_abs_diff_on_rays_with_samples_within_1e-5": float((got["color"] - col)[exact].abs().max()) if bool(exact.any()) else None,
             "max_abs_diff_on_rays_with_identical_samples": float((got["color"] - col)[same].abs().max()) if bool(same.any()) else None,
             "weights_max_abs_diff_on_rays_with_identical_samples": float((got["weights"] - w)[same].abs().max()) if bool(same.any()) else None,
+            "ray_ulp_diff": ray_diff,
             "fixture": "tests/golden/ref_bench_cfg2_full.npz (the reference's own CPU run on these rays and weights)"}
 
 
@@ -155,7 +166,7 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
                 "weights_max_abs_diff": float(dw.max()),
                 "weight_mass_on_moved_samples": (float(ref["weights"][:, :moved.shape[1]][moved].sum()) / wsum) if wsum > 0 else None,
                 "rays": n_rays, "rays_with_identical_samples": int(same.sum()), "samples_per_ray": s_core, "precision": precision,
-                "vs_reference_fixture": _vs_reference_fixture(workload, n_rays, rays, got),
+                "vs_reference_fixture": _vs_reference_fixture(workload, n_rays, rays, rend, dev),
                 "what": "HIP colours / weights vs the oracle's END TO END on identical rays / network weights: the hierarchical "
                         "sampling runs on both sides, so rays whose quantile bins flip (tests/test_gpu_fullsize_parity.py) enter "
                         "with different sample positions; weight_mass_on_moved_samples = share of the reference's total "
