@@ -108,3 +108,22 @@ def test_pixel_blending_step_replays_and_patch_loss_stays_eager():
     batch["gt_patch_colors"] = torch.rand(96, 49, 3, device=dev)
     gs2, _ = run(True, dict(color_pixel_weight=0.5, color_patch_weight=0.1), n=3)
     assert gs2.replays == 0 and len(gs2.graphs) == 0
+
+
+def test_graph_replay_equals_eager_in_the_16_bit_mode():
+    """the same bit-identity in BASELINE config 5's operand mode (16-bit MFMA operands, bf16 saved state): the mode that was
+    launch-bound at the headline shape (3.66 ms eager, 2.67 ms replayed)."""
+    from neuraludf_amd import mlp
+    assert mlp.PRECISION == "fp32"
+    try:
+        mlp.set_precision("mixed16")
+        n = 5
+        _, _, eager = _run(RCONF, False, n)
+        _, gs, graph = _run(RCONF, True, n)
+    finally:
+        mlp.set_precision("fp32")
+    assert gs.replays == n - 2
+    for i, (a, b) in enumerate(zip(eager, graph)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), i
+        for j, (p, q) in enumerate(zip(a[3], b[3])):
+            assert torch.equal(p, q), (i, j)
