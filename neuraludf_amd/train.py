@@ -132,6 +132,8 @@ class GraphedStep:
                 src = blend[k]
                 if torch.is_tensor(v) and src is not v and src.data_ptr() != v.data_ptr():
                     v.copy_(src)
+        tr.optimizer._order = ent["order"]       # the tensors of THIS capture's Adam launch (an eager step of another
+                                                 # configuration in between may have left another list)
         self.scalars.upload([0.0 if cos_anneal_ratio is None else float(cos_anneal_ratio), float(flip_saturation)],
                             tr.optimizer.dyn_values())
         ent["graph"].replay()
@@ -172,7 +174,7 @@ class GraphedStep:
         finally:
             tr.renderer.sched_scalars = None
             tr.optimizer.dyn_base = None
-        ent["graph"], ent["loss"], ent["out"] = g, loss, out
+        ent["graph"], ent["loss"], ent["out"], ent["order"] = g, loss, out, list(tr.optimizer._order)
 
 
 class Trainer:
