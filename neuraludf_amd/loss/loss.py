@@ -198,9 +198,18 @@ class ColorPatchLoss(nn.Module):
             # order statistics over the whole ray batch: gather errors + masks, trim identically everywhere
             return _global_trimmed_mean(error, m, penalize_ratio)
         err_s, idx = torch.sort(error, descending=True)
-        ms = m[idx].clone()
-        ms[:int(penalize_ratio * ms.sum())] = False
-        return err_s[ms].mean()
+        return _trimmed_mean(err_s, m[idx], penalize_ratio)
+
+
+def _trimmed_mean(err_sorted, mask_sorted, ratio):
+    """loss/loss.py:79-84 on the descending-sorted errors: clear the mask of the first int(ratio * mask.sum()) entries, mean
+    of the errors still masked.  The reference reads that count on the host (`int(...)`, then boolean indexing): here it
+    stays on the device -- floor(ratio * count) in the same float32 arithmetic, a position test and a masked sum -- so the
+    step never waits for the GPU and can be captured in a HIP graph.  Same value up to the rounding of the final sum."""
+    k = torch.floor(ratio * mask_sorted.sum())                        # python float x int64 tensor -> float32, as there
+    pos = torch.arange(err_sorted.shape[0], device=err_sorted.device, dtype=torch.float32)
+    keep = (mask_sorted & (pos >= k)).to(err_sorted.dtype)
+    return (err_sorted * keep).sum() / keep.sum()
 
 
 def _global_trimmed_mean(error, m, ratio):
@@ -212,9 +221,7 @@ def _global_trimmed_mean(error, m, ratio):
     e = torch.cat([e[:r * n], error, e[(r + 1) * n:]])                    # keep the local autograd edge
     mm = both[:, 1] > 0.5
     es, idx = torch.sort(e, descending=True)
-    mk = mm[idx].clone()
-    mk[:int(ratio * mk.sum())] = False
-    return es[mk].mean()
+    return _trimmed_mean(es, mm[idx], ratio)
 
 
 class ColorLoss(nn.Module):

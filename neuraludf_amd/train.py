@@ -95,10 +95,17 @@ class GraphedStep:
         tr = self.tr
         kw = dict(cos_anneal_ratio=cos_anneal_ratio, flip_saturation=flip_saturation, blend=blend,
                   perturb_overwrite=perturb_overwrite)
-        if not self.enabled or (blend is not None and tr.lc["color_patch_weight"] > 0):
-            # (the trimmed patch loss reads its trim count on the host -- loss/loss.py:79-84 -- so a step with it on cannot be
-            # captured; it is 15 ms of kernels, far from launch-bound)
+        if not self.enabled:
             return tr.step(batch, **kw)
+        if (blend is not None and "ref_cam" not in blend and tr.lc["color_pixel_weight"] > 0
+                and tr.lc["color_patch_weight"] > 0):
+            # the camera constants of the patch warp hold four small matrix inverses (a solver library: not capturable):
+            # computed here, per step, outside the graph; the captured step reads them as inputs
+            from .models import blend as _blend
+            blend = dict(blend)
+            blend["ref_cam"], blend["src_cam"] = _blend.patch_cameras(blend["intrinsics"][0], blend["intrinsics"],
+                                                                      blend["query_c2w"], torch.inverse(blend["w2cs"]))
+            kw["blend"] = blend
         key = self._key(batch, blend, cos_anneal_ratio is not None, perturb_overwrite)
         ent = self.graphs.get(key)
         if ent is None:
