@@ -385,6 +385,57 @@ __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* 
   }
 }
 
+// The same for the 16-bit stored state (config-5 mode: X1, X2 hold bf16): BOTH stored operands of tile t + 1 are requested
+// before tile t is computed and stored.  The per-tile loop below loads them at the top of each tile -- after the previous
+// tile's 16-32 two-byte stores, with nothing else in flight -- i.e. one exposed HBM round trip per tile and operand set:
+// at config 5's shape the tangent sweep (two operands in, two arrays out) took 1.95 ms against 1.13 ms for the adjoint.
+// Raw 16-bit values wait in registers and are widened at use.  The registers come from the X1 prefetch of the fp32 K
+// loop, which the 16-bit instantiation does not use at all (see mlp_chain_kernel).
+#ifndef NUDF_SEQ16
+#define NUDF_SEQ16 1     // A/B build switch (scripts/build_variants.sh): 0 = per-tile loop for the 16-bit stored state
+#endif
+template <int EPI, int NRT, int NCT>
+__device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
+                                                  int ln, f32x16 (&acc)[2][2]) {
+  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
+  unsigned r1[2][16], r2[2][16];      // 32-bit homes: 16-bit private arrays are not promoted to registers (they went to scratch)
+  const unsigned short* X1h = reinterpret_cast<const unsigned short*>(st.X1);
+  const unsigned short* X2h = reinterpret_cast<const unsigned short*>(st.X2);
+  auto issue = [&](unsigned (&a1)[16], unsigned (&a2)[16], int i, int j) {
+    const int col = (ct0 + j) * 32 + ln;
+    const unsigned colc = (unsigned)((col < st.N) ? col : 0);
+    const unsigned row = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h);
+    if (U1) {
+      const unsigned vo = row * (unsigned)st.ldx1 + colc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = (X1h + (size_t)CH_KOFF(r) * st.ldx1)[vo];
+    }
+    if (U2) {
+      if (st.X2) {
+        const unsigned vo = row * (unsigned)st.ldx2 + colc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = (X2h + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0;
+      }
+    }
+  };
+  constexpr int NTL = NRT * NCT;
+  issue(r1[0], r2[0], 0, 0);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (t + 1 < NTL) issue(r1[(t + 1) & 1], r2[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
+    float x1[16], x2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      x1[r] = U1 ? __builtin_bit_cast(float, r1[t & 1][r] << 16) : 0.0f;
+      x2[r] = U2 ? __builtin_bit_cast(float, r2[t & 1][r] << 16) : 0.0f;
+    }
+    ch_epilogue_tile<EPI, true, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1, false, x2);
+  }
+}
+
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
 template <int EPI, bool ANY16>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
@@ -396,6 +447,13 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
       float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
       if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1);
       else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1);
+      return;
+    }
+  }
+  if constexpr (ANY16 && (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
+    if (NUDF_SEQ16 && (st.layout & NUDF_CH_STATE16) && nrt == 2) {
+      if (nct == 2) ch_epilogue_seq16<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc);
+      else ch_epilogue_seq16<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc);
       return;
     }
   }
@@ -443,14 +501,19 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
         continue;
       }
     }
-    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 && st.prec != 0);
+    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16);
   }
 }
 
 // ANY16: some step of the chain uses 16-bit MFMA operands (config-5 mode).  The fp32 chains get a kernel without any of
 // the 16-bit code: its register pressure (conversions, raw-bf16 operand prefetch) would otherwise spill into them.
 template <int TM, bool ANY16>
-__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_arg) {
+  // The descriptor is read where it lies, in the kernarg segment: the by-value parameter is otherwise a private copy that
+  // the optimiser has to prove away, and once it fails (it did when the 16-bit epilogues grew) all 2 KB go to scratch and
+  // every K loop pays vmcnt(0) for it.
+  (void)p_arg;
+  const NudfChain& p = *(const NudfChain*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int WMT = TM / 32;  // row tiles per wave in the wide layout
   __shared__ __attribute__((aligned(16))) ChainSmem<TM> sm;
   const int tid = threadIdx.x;
@@ -557,7 +620,9 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p) {
       const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
       const f32x4* bptr = Bp + (size_t)ct0 * 64 + lane;
       const size_t bstride = (size_t)NT * 64;  // float4 per k group
-      const bool pfx = CH_USES_X1(st.epi);
+      // the 16-bit instantiation never prefetches X1 under the K loop (its conversions need the registers; the fp32 steps
+      // of a 16-bit chain -- the abs-head column -- have no stored operand): px1 stays dead there, the epilogues load X1
+      const bool pfx = !ANY16 && CH_USES_X1(st.epi);
       ChPrefetch pf;
       pf.X1 = st.X1;
       pf.ldx1 = st.ldx1;

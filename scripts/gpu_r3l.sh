@@ -1,6 +1,5 @@
 #!/bin/bash
-# NOTE: records an experiment of round 3 whose code was removed again (NUDF_CHAIN_RING / NUDF_CHAIN_W8 / NUDF_COLOR_TILE / NUDF_SEQ16
-# switches no longer exist); kept as the provenance of profiles/r03_chain_experiments.txt.
+# A/B at the config-5 shape: sequential 16-bit epilogues (NUDF_SEQ16=1, default) against the per-tile epilogues (=0)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3l
