@@ -445,7 +445,7 @@ def main():
             b[4] += nbytes
         dom = max(agg, key=lambda k: agg[k][2])
         n, fl, sec = agg[dom]
-        peak = MFMA_F32_PEAK_TFLOPS if (args.precision == "fp32" or dom != "mlp_chain") else MFMA_F16_PEAK_TFLOPS
+        peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS
         result["roofline"] = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": fl / sec / 1e12,
                               "peak": peak, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak,
                               "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
@@ -460,7 +460,8 @@ def main():
         # larger of the two floors, i.e. the roof that launch could at best run into
         pk = []
         for detail, (name, cnt, f, t, by) in sorted(per.items(), key=lambda kv: -kv[1][3]):
-            pkp = MFMA_F32_PEAK_TFLOPS if (args.precision == "fp32" or name != "mlp_chain") else MFMA_F16_PEAK_TFLOPS
+            # mixed16: chains AND weight-gradient GEMMs take bf16 / f16 MFMA operands -> the 16-bit dense peak for both
+            pkp = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS
             t_mfma, t_hbm = f / (pkp * 1e12), by / (HBM_PEAK_GBS * 1e9)
             pk.append({"kernel": detail, "class": name, "launches": cnt, "gflop": f / 1e9, "us": t * 1e6,
                        "tflops": f / t / 1e12, "frac_mfma": f / t / 1e12 / pkp,

@@ -93,6 +93,10 @@ typedef struct NudfGemmTNProblem {
 #define NUDF_TN_B16 2
 #define NUDF_TN_A_BLK 4                         /* fp32 operand in the BLOCKED layout of NudfChainStep (rows padded to 32) */
 #define NUDF_TN_B_BLK 8
+#define NUDF_TN_A_P4 16                         /* with NUDF_TN_A16: the bf16 operand is 4-point packed like the chains'
+                                                   16-bit stored state (NUDF_CH_STATE16): element (row, col) at
+                                                   ((row / 4) ld + col) 4 + row % 4, rows padded to a multiple of 4    */
+#define NUDF_TN_B_P4 32
 typedef struct NudfGemmTNGroup {
   int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
   int32_t prec;                                 /* as NudfGemmTN.prec                     */
@@ -436,7 +440,11 @@ typedef struct NudfChainStep {
 #define NUDF_CH_BLK_PE 16           /* pe_dst */
 /* config-5 mode: this step's stored-state arrays -- X1, X2, C1, the TANGENT mirror C2 and pe_dst -- hold bf16 (ld in
  * elements); SOFTPLUS / MULSP / TANGENT / BWD steps of the workgroup-shared kernels only.  Values are rounded to
- * nearest even when stored; everything on chip stays fp32. */
+ * nearest even when stored; everything on chip stays fp32.  The arrays are 4-POINT PACKED: element (row, col) of a
+ * [R, ld] buffer (R a multiple of 64) sits at ((row / 4) ld + col) 4 + row % 4 -- the four consecutive points a lane of a
+ * 32 x 32 accumulator tile holds for its column are one 8-byte access, and a dword is the row pair the 16-bit
+ * weight-gradient GEMM contracts (NUDF_TN_A_P4 / NUDF_TN_B_P4).  The same holds for a bf16 A0 / G0 of the SEED
+ * initialisation (init_state16 bits 1 / 2). */
 #define NUDF_CH_STATE16 32
 typedef struct NudfChain {
   int32_t P, n_steps;

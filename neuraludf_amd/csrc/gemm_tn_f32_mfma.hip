@@ -629,6 +629,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnPlan g) {
 // out of it, bf16 operands are copied bit for bit, the MFMAs run over the same rows in the same order: bit-identical C.
 // Thread (r = tid / 16, c = 8 (tid % 16)) stages k-pairs r and r + 16, 8 columns each: 2 x 2 rows of 16 B (bf16 operand)
 // or 32 B (fp32 operand).
+// A 4-POINT PACKED bf16 operand (NUDF_TN_A_P4 / _B_P4: the chains' 16-bit stored state) already holds the image's dwords:
+// the 8 bytes of (point quad, column) are the k-pairs (2 quad, 2 quad + 1) of that column.  Thread (quad = tid / 32 + 8 ps,
+// t = tid % 32) loads columns 2 t, 2 t + 1 and 64 + 2 t, 65 + 2 t (16 B each: a wave instruction reads 2 x 512 contiguous
+// bytes) and stores the even dwords to one image row, the odd ones to the next -- no bit shuffling at all (the row-major
+// bf16 operand needs 16 and/shift/or per 8 values).
 // =======================================================================================================
 #define BK16 64
 #define LD16 132
@@ -637,7 +642,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-template <bool H> struct Tn16Stage { f32x4 v[2][2][H ? 1 : 2]; };   // [pass][row of the pair][16-byte piece]
+template <int KIND> struct Tn16Stage { f32x4 v[2][2][KIND ? 1 : 2]; };   // [pass][row of the pair (P4: column pair)][16-byte piece]
 
 __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
   __shared__ __attribute__((aligned(16))) unsigned smem[4 * T16];
@@ -669,22 +674,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
 
+  // operand kinds: 0 = fp32 row-major, 1 = bf16 row-major, 2 = bf16 4-point packed
   auto run_kind = [&](auto KA, auto KB) {
-    constexpr bool kA = decltype(KA)::value, kB = decltype(KB)::value;
+    constexpr int kA = decltype(KA)::value, kB = decltype(KB)::value;
     // this thread's 8 columns of an operand, clamped into the buffer (columns past NA / NB only feed outputs that are
     // never stored); rows are clamped per load
     // (a bf16 operand's leading dimension is a multiple of 8, an fp32 one's of 4: the two 4-column pieces of an fp32
     // row are clamped separately)
     const int ca = i0 + pc, cb = j0 + pc;
-    const char* pa = reinterpret_cast<const char*>(q.A1) + (size_t)min(ca, q.lda1 - (kA ? 8 : 4)) * (kA ? 2 : 4);
-    const char* pb = reinterpret_cast<const char*>(q.B1) + (size_t)min(cb, q.ldb1 - (kB ? 8 : 4)) * (kB ? 2 : 4);
+    // (P4: this thread's column pairs p4c and 64 + p4c, 8 bytes per column and point quad; a packed operand's leading
+    // dimension is a multiple of 8, so clamping a pair to ld - 2 keeps it inside the row)
+    const int p4c = (tid & 31) * 2, p4q = tid >> 5;
+    const char* pa = (kA == 2) ? reinterpret_cast<const char*>(q.A1) + (size_t)min(i0 + p4c, q.lda1 - 2) * 8
+                               : reinterpret_cast<const char*>(q.A1) + (size_t)min(ca, q.lda1 - (kA ? 8 : 4)) * (kA ? 2 : 4);
+    const char* pb = (kB == 2) ? reinterpret_cast<const char*>(q.B1) + (size_t)min(j0 + p4c, q.ldb1 - 2) * 8
+                               : reinterpret_cast<const char*>(q.B1) + (size_t)min(cb, q.ldb1 - (kB ? 8 : 4)) * (kB ? 2 : 4);
+    const int pa2x = (kA == 2) ? (min(i0 + p4c + 64, q.lda1 - 2) - min(i0 + p4c, q.lda1 - 2)) * 8 : 0;
+    const int pb2x = (kB == 2) ? (min(j0 + p4c + 64, q.ldb1 - 2) - min(j0 + p4c, q.ldb1 - 2)) * 8 : 0;
     const int pa2 = (min(ca + 4, q.lda1 - 4) - min(ca, q.lda1 - 4)) * 4;   // byte offset of an fp32 row's second piece
     const int pb2 = (min(cb + 4, q.ldb1 - 4) - min(cb, q.ldb1 - 4)) * 4;
-    const size_t rowa = (size_t)q.lda1 * (kA ? 2 : 4), rowb = (size_t)q.ldb1 * (kB ? 2 : 4);
+    // bytes per row (P4: per point quad)
+    const size_t rowa = (size_t)q.lda1 * (kA == 2 ? 8 : kA ? 2 : 4), rowb = (size_t)q.ldb1 * (kB == 2 ? 8 : kB ? 2 : 4);
     Tn16Stage<kA> sa;
     Tn16Stage<kB> sb;
     auto load = [&](auto Hc, const char* p, int p2, size_t rowbytes, auto& st, int kt) {
-      constexpr bool h = decltype(Hc)::value;
+      constexpr int h = decltype(Hc)::value;
+      if constexpr (h == 2) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int quad = min(((mbeg + kt * BK16) >> 2) + p4q + 8 * ps, (g.M - 1) >> 2);
+          const char* src = p + (size_t)quad * rowbytes;
+          st.v[ps][0][0] = *reinterpret_cast<const f32x4*>(src);
+          st.v[ps][1][0] = *reinterpret_cast<const f32x4*>(src + p2);
+        }
+        return;
+      }
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
@@ -692,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
           const int row = min(mbeg + kt * BK16 + 2 * (pr + 16 * ps) + rr, g.M - 1);
           const char* src = p + (size_t)row * rowbytes;
           st.v[ps][rr][0] = *reinterpret_cast<const f32x4*>(src);
-          if constexpr (!h) st.v[ps][rr][1] = *reinterpret_cast<const f32x4*>(src + p2);
+          if constexpr (h == 0) st.v[ps][rr][1] = *reinterpret_cast<const f32x4*>(src + p2);
         }
     };
     auto widen = [](const f32x4& raw, f32x4& lo, f32x4& hi) {
@@ -706,14 +730,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
       return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
     };
     auto store = [&](auto Hc, const auto& st, int kt, unsigned* tile, bool bias) {
-      constexpr bool h = decltype(Hc)::value;
+      constexpr int h = decltype(Hc)::value;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (h == 2) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int qd = p4q + 8 * ps;                                // point quad of the k-step = image rows 2 qd, 2 qd + 1
+          const int nv = mend - (mbeg + kt * BK16 + 4 * qd);          // live points of the quad (rows >= mend are zeros)
+          const unsigned m01 = nv >= 2 ? 0xffffffffu : (nv == 1 ? 0x0000ffffu : 0u);
+          const unsigned m23 = nv >= 4 ? 0xffffffffu : (nv == 3 ? 0x0000ffffu : 0u);
+          const uint4 a = __builtin_bit_cast(uint4, st.v[ps][0][0]), b = __builtin_bit_cast(uint4, st.v[ps][1][0]);
+          // columns p4c, p4c + 1 | 64 + p4c, 65 + p4c
+          const u32x4 even = {a.x & m01, a.z & m01, b.x & m01, b.z & m01};
+          const u32x4 odd = {a.y & m23, a.w & m23, b.y & m23, b.w & m23};
+          if (bias) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              bias_lo[c] += (__builtin_bit_cast(float, even[c] << 16) + __builtin_bit_cast(float, even[c] & 0xffff0000u)) +
+                            (__builtin_bit_cast(float, odd[c] << 16) + __builtin_bit_cast(float, odd[c] & 0xffff0000u));
+          }
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          unsigned* dst = tile + (2 * qd) * LD16 + p4c;
+          *reinterpret_cast<u32x2*>(dst) = u32x2{even[0], even[1]};
+          *reinterpret_cast<u32x2*>(dst + 64) = u32x2{even[2], even[3]};
+          *reinterpret_cast<u32x2*>(dst + LD16) = u32x2{odd[0], odd[1]};
+          *reinterpret_cast<u32x2*>(dst + LD16 + 64) = u32x2{odd[2], odd[3]};
+        }
+        return;
+      }
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const int k0 = mbeg + kt * BK16 + 2 * (pr + 16 * ps);
         const bool v0 = k0 < mend, v1 = k0 + 1 < mend;
         u32x4 olo, ohi;
-        if constexpr (h) {
+        if constexpr (h == 1) {
           const f32x4 r0 = v0 ? st.v[ps][0][0] : z, r1 = v1 ? st.v[ps][1][0] : z;
           const uint4 a = __builtin_bit_cast(uint4, r0), b = __builtin_bit_cast(uint4, r1);
           olo = u32x4{(a.x & 0xffffu) | (b.x << 16), (a.x >> 16) | (b.x & 0xffff0000u),
@@ -769,8 +819,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
       }
     };
     if (nk > 0) {
-      load(KA, pa, pa2, rowa, sa, 0);
-      load(KB, pb, pb2, rowb, sb, 0);
+      load(KA, pa, kA == 2 ? pa2x : pa2, rowa, sa, 0);
+      load(KB, pb, kB == 2 ? pb2x : pb2, rowb, sb, 0);
       store(KA, sa, 0, As, do_bias);
       store(KB, sb, 0, Bs, false);
     }
@@ -778,8 +828,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (kt + 1 < nk) {
-        load(KA, pa, pa2, rowa, sa, kt + 1);
-        load(KB, pb, pb2, rowb, sb, kt + 1);
+        load(KA, pa, kA == 2 ? pa2x : pa2, rowa, sa, kt + 1);
+        load(KB, pb, kB == 2 ? pb2x : pb2, rowb, sb, kt + 1);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
       mma(cur);
@@ -791,11 +841,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
       __syncthreads();
     }
   };
-  const bool a16 = (q.flags & NUDF_TN_A16) != 0, b16 = (q.flags & NUDF_TN_B16) != 0;
-  if (a16 && b16) run_kind(std::true_type{}, std::true_type{});
-  else if (!a16 && !b16) run_kind(std::false_type{}, std::false_type{});
-  else if (a16) run_kind(std::true_type{}, std::false_type{});
-  else run_kind(std::false_type{}, std::true_type{});
+  const int ka = (q.flags & NUDF_TN_A16) ? ((q.flags & NUDF_TN_A_P4) ? 2 : 1) : 0;
+  const int kb = (q.flags & NUDF_TN_B16) ? ((q.flags & NUDF_TN_B_P4) ? 2 : 1) : 0;
+  typedef std::integral_constant<int, 0> K0;
+  typedef std::integral_constant<int, 1> K1;
+  typedef std::integral_constant<int, 2> K2;
+  // (row-major and packed bf16 meet only across problems of a group; tn_plan rejects the pair inside one problem)
+  if (ka == 2 && kb == 2) run_kind(K2{}, K2{});
+  else if (ka == 2) run_kind(K2{}, K0{});
+  else if (kb == 2) run_kind(K0{}, K2{});
+  else if (ka == 1 && kb == 1) run_kind(K1{}, K1{});
+  else if (ka == 0 && kb == 0) run_kind(K0{}, K0{});
+  else if (ka == 1) run_kind(K1{}, K0{});
+  else run_kind(K0{}, K1{});
+  const bool a_p4 = ka == 2;
 
   if (g.dbg && tid == 0) {
     long long* d = g.dbg + 4 * (size_t)blockIdx.x;
@@ -806,8 +865,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
   float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
   if (do_bias) {   // the loop's last barrier has passed: the operand image is free
     float* red = reinterpret_cast<float*>(smem);
-    *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
-    *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
+    if (a_p4) {   // 8 thread rows x (2 + 2) columns each: partial sums in rows 0..7, zeros in rows 8..15 of the 16-row table
+      float* r0 = red + (tid >> 5) * BM + (tid & 31) * 2;
+      r0[0] = bias_lo[0]; r0[1] = bias_lo[1]; r0[64] = bias_lo[2]; r0[65] = bias_lo[3];
+      r0[8 * BM] = 0.0f; r0[8 * BM + 1] = 0.0f; r0[8 * BM + 64] = 0.0f; r0[8 * BM + 65] = 0.0f;
+    } else {
+      *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
+      *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
+    }
     __syncthreads();
     if (tid < BM) {
       float sum = 0.0f;
@@ -882,6 +947,17 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   for (int i = 0; i < g.n_problems; ++i) {
     const NudfGemmTNProblem& q = g.prob[i];
     const int ma = (q.flags & NUDF_TN_A16) ? 8 : 4, mb = (q.flags & NUDF_TN_B16) ? 8 : 4;
+    {
+      const bool ap4 = (q.flags & NUDF_TN_A_P4) != 0, bp4 = (q.flags & NUDF_TN_B_P4) != 0;
+      const bool a16 = (q.flags & NUDF_TN_A16) != 0, b16 = (q.flags & NUDF_TN_B16) != 0;
+      if ((ap4 && !a16) || (bp4 && !b16) || ((ap4 || bp4) && g.prec == 0) || (ap4 && b16 && !bp4) || (bp4 && a16 && !ap4) ||
+          ((ap4 || bp4) && (flags & TNF_NO_PACK16)) || ((ap4 || bp4) && g.rows_per_block % 4)) {
+        nudf_set_error("nudf_gemm_tn_grouped: a 4-point packed operand is a bf16 operand of the 16-bit MFMA mode "
+                       "(NUDF_TN_x16 set, prec != 0, rows_per_block a multiple of 4); a problem's other operand is packed "
+                       "as well or fp32", hipErrorInvalidValue);
+        return -1;
+      }
+    }
     if (((q.flags & NUDF_TN_A_BLK) && (q.flags & NUDF_TN_A16)) || ((q.flags & NUDF_TN_B_BLK) && (q.flags & NUDF_TN_B16))) {
       nudf_set_error("nudf_gemm_tn_grouped: the blocked layout is defined for fp32 operands", hipErrorInvalidValue);
       return -1;
@@ -1041,6 +1117,16 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
     n16 += ((f & NUDF_TN_A16) ? 1 : 0) + ((f & NUDF_TN_B16) ? 1 : 0);
   }
   if (n16 < args->n_problems) packed16 = false;
+  bool any_p4 = false;
+  for (int i = 0; i < args->n_problems; ++i) any_p4 = any_p4 || (args->prob[i].flags & (NUDF_TN_A_P4 | NUDF_TN_B_P4));
+  if (any_p4) {   // only the packed-image kernel reads 4-point packed operands
+    for (int i = 0; i < args->n_problems; ++i)
+      if (args->prob[i].flags & (NUDF_TN_A_BLK | NUDF_TN_B_BLK)) {
+        nudf_set_error("nudf_gemm_tn_grouped: 4-point packed and blocked operands cannot share a group", hipErrorInvalidValue);
+        return (int)hipErrorInvalidValue;
+      }
+    packed16 = true;
+  }
   if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");

@@ -183,6 +183,32 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
   if (g < G16) mma(a0, b0);   // odd number of 16-wide k steps
 }
 
+// 16-bit stored state, 4-point packed (ch_p4_off): the 16 accumulator rows of a lane are 4 groups of 4 consecutive
+// points = 4 accesses of 8 bytes.  q0 = the lane's first point quad (tile row 0 + 4 h) / 4, groups are 2 quads apart.
+typedef __bf16 ch_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ch_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ch_p4_widen(const uint2& w, float* x) {
+  x[0] = __builtin_bit_cast(float, w.x << 16);
+  x[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
+  x[2] = __builtin_bit_cast(float, w.y << 16);
+  x[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+}
+__device__ __forceinline__ void ch_p4_load(const float* X, int ld, unsigned q0, unsigned col, uint2 (&w)[4]) {
+  const uint2* Xq = reinterpret_cast<const uint2*>(X) + (size_t)q0 * ld + col;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) w[g] = Xq[(size_t)(2 * g) * ld];
+}
+__device__ __forceinline__ void ch_p4_store(float* C, int ld, unsigned q0, unsigned col, const float (&v)[16]) {
+  uint2* Cq = reinterpret_cast<uint2*>(C) + (size_t)q0 * ld + col;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    uint2 w;
+    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(ch_f32x2{v[4 * g], v[4 * g + 1]}, ch_bf16x2));
+    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(ch_f32x2{v[4 * g + 2], v[4 * g + 3]}, ch_bf16x2));
+    Cq[(size_t)(2 * g) * ld] = w;
+  }
+}
+
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
 // One 32x32 accumulator tile of a step's epilogue.  Branch-free per element: uniform options are tested once
 // around whole 16-element loops, the column predicate (N may end inside the tile) is one exec region, rows
@@ -214,9 +240,10 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
   if (CH_USES_X1(EPI) && load_x1) {
     const unsigned vo = grow0 * (unsigned)st.ldx1 + colc;
     if (S16) {
-      const unsigned short* X1h = reinterpret_cast<const unsigned short*>(st.X1);
+      uint2 w[4];
+      ch_p4_load(st.X1, st.ldx1, (grow0 >> 2), colc, w);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x1[r] = ch_bf2f((X1h + (size_t)CH_KOFF(r) * st.ldx1)[vo]);
+      for (int g = 0; g < 4; ++g) ch_p4_widen(w[g], x1 + 4 * g);
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) x1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
@@ -229,9 +256,10 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     } else if (st.X2) {
       const unsigned vo = grow0 * (unsigned)st.ldx2 + colc;
       if (S16) {
-        const unsigned short* X2h = reinterpret_cast<const unsigned short*>(st.X2);
+        uint2 w[4];
+        ch_p4_load(st.X2, st.ldx2, (grow0 >> 2), colc, w);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x2[r] = ch_bf2f((X2h + (size_t)CH_KOFF(r) * st.ldx2)[vo]);
+        for (int g = 0; g < 4; ++g) ch_p4_widen(w[g], x2 + 4 * g);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
@@ -327,9 +355,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     } else if (st.C1) {
       const unsigned vo = grow0 * (unsigned)st.ldc1 + col;
       if (S16) {
-        unsigned short* C1h = reinterpret_cast<unsigned short*>(st.C1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) (C1h + (size_t)CH_KOFF(r) * st.ldc1)[vo] = ch_f2bf(out[r]);
+        ch_p4_store(st.C1, st.ldc1, (grow0 >> 2), (unsigned)col, out);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
@@ -338,9 +364,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     if (EPI == NUDF_CH_TANGENT || (EPI == NUDF_CH_RELU && st.C2)) {
       const unsigned vo = grow0 * (unsigned)st.ldc2 + col;
       if (S16 && EPI == NUDF_CH_TANGENT) {
-        unsigned short* C2h = reinterpret_cast<unsigned short*>(st.C2);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) (C2h + (size_t)CH_KOFF(r) * st.ldc2)[vo] = ch_f2bf(out2[r]);
+        ch_p4_store(st.C2, st.ldc2, (grow0 >> 2), (unsigned)col, out2);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
@@ -398,26 +422,18 @@ template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
                                                   int ln, f32x16 (&acc)[2][2]) {
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
-  unsigned r1[2][16], r2[2][16];      // 32-bit homes: 16-bit private arrays are not promoted to registers (they went to scratch)
-  const unsigned short* X1h = reinterpret_cast<const unsigned short*>(st.X1);
-  const unsigned short* X2h = reinterpret_cast<const unsigned short*>(st.X2);
-  auto issue = [&](unsigned (&a1)[16], unsigned (&a2)[16], int i, int j) {
+  uint2 r1[2][4], r2[2][4];      // raw 4-point packs of tile t and t + 1
+  auto issue = [&](uint2 (&a1)[4], uint2 (&a2)[4], int i, int j) {
     const int col = (ct0 + j) * 32 + ln;
     const unsigned colc = (unsigned)((col < st.N) ? col : 0);
-    const unsigned row = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h);
-    if (U1) {
-      const unsigned vo = row * (unsigned)st.ldx1 + colc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[r] = (X1h + (size_t)CH_KOFF(r) * st.ldx1)[vo];
-    }
+    const unsigned q0 = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) >> 2;
+    if (U1) ch_p4_load(st.X1, st.ldx1, q0, colc, a1);
     if (U2) {
       if (st.X2) {
-        const unsigned vo = row * (unsigned)st.ldx2 + colc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a2[r] = (X2h + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+        ch_p4_load(st.X2, st.ldx2, q0, colc, a2);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a2[r] = 0;
+        for (int g = 0; g < 4; ++g) a2[g] = uint2{0u, 0u};
       }
     }
   };
@@ -428,9 +444,17 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
     if (t + 1 < NTL) issue(r1[(t + 1) & 1], r2[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
     float x1[16], x2[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      x1[r] = U1 ? __builtin_bit_cast(float, r1[t & 1][r] << 16) : 0.0f;
-      x2[r] = U2 ? __builtin_bit_cast(float, r2[t & 1][r] << 16) : 0.0f;
+    for (int g = 0; g < 4; ++g) {
+      if (U1) ch_p4_widen(r1[t & 1][g], x1 + 4 * g);
+      if (U2) ch_p4_widen(r2[t & 1][g], x2 + 4 * g);
+    }
+    if (!U1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x1[r] = 0.0f;
+    }
+    if (!U2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
     }
     ch_epilogue_tile<EPI, true, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1, false, x2);
   }
@@ -552,13 +576,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
       const bool live = gr < p.P;
       if (!live) gr = p.P - 1;
       float s, om;
-      const float hst = (p.init_state16 & 1) ? ch_bf2f(reinterpret_cast<const unsigned short*>(p.A0)[(size_t)gr * p.lda0 + c])
+      const float hst = (p.init_state16 & 1) ? ch_bf2f(reinterpret_cast<const unsigned short*>(p.A0)[ch_p4_off(gr, c, p.lda0)])
                                              : p.A0[(size_t)gr * p.lda0 + c];
       ch_sp_derivs(hst, p.seed_xscale, s, om);
       const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
       sm.act[r * CH_LD + c] = val;
       if (p.G0 && live) {
-        if (p.init_state16 & 2) reinterpret_cast<unsigned short*>(p.G0)[(size_t)gr * p.ldg0 + c] = ch_f2bf(val);
+        if (p.init_state16 & 2) reinterpret_cast<unsigned short*>(p.G0)[ch_p4_off(gr, c, p.ldg0)] = ch_f2bf(val);
         else p.G0[(size_t)gr * p.ldg0 + c] = val;
       }
     }

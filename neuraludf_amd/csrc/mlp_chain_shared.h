@@ -17,6 +17,14 @@ __device__ __forceinline__ size_t ch_blk_off(int r, int c, int ld) {
   return (size_t)(r >> 5) * 32 * ld + (size_t)(c >> 2) * 128 + (size_t)(r & 31) * 4 + (c & 3);
 }
 
+// 16-bit stored state (NUDF_CH_STATE16, nudf.h): bf16, FOUR CONSECUTIVE POINTS of one feature packed into 8 bytes --
+// element (row, col) of a [R, ld] buffer sits at ((row / 4) ld + col) 4 + row % 4.  A lane of a 32x32 accumulator tile
+// holds rows 8 g + 4 h + {0..3} of its column: one 8-byte store / load per group g instead of four 2-byte ones, 32
+// lanes = 256 contiguous bytes; and a dword is the (k, k + 1) row pair of one column that the 16-bit weight-gradient
+// GEMM's MFMA operand image is made of.
+__device__ __forceinline__ size_t ch_p4_off(unsigned row, unsigned col, unsigned ld) {
+  return ((size_t)(row >> 2) * ld + col) * 4 + (row & 3);
+}
 // bf16 <-> fp32 of the 16-bit stored state (round to nearest even on the way out)
 __device__ __forceinline__ float ch_bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ unsigned short ch_f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -74,7 +82,7 @@ __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, co
       val *= scale;
       arow[c] = val;
       if (mirror) {
-        if (dst16) reinterpret_cast<unsigned short*>(gdst)[goff + c] = ch_f2bf(val);
+        if (dst16) reinterpret_cast<unsigned short*>(gdst)[ch_p4_off(m0 + r, gcol0 + c, ldg)] = ch_f2bf(val);
         else if (dstblk) gdst[ch_blk_off(m0 + r, gcol0 + c, ldg)] = val;
         else gdst[goff + c] = val;
       }

@@ -38,7 +38,9 @@ def pad_rows(P: int) -> int:
 
 def _buf(P, width, dev, zero=None, dtype=torch.float32, blocked=False):
     """[pad_rows(P), pad32(width)] fp32 (rows >= P are scratch for the tile kernels); pad columns zeroed (default),
-    everything zeroed (zero=True) or nothing (zero=False).  dtype = bfloat16: stored state of the 16-bit mode.
+    everything zeroed (zero=True) or nothing (zero=False).  dtype = bfloat16: stored state of the 16-bit mode, which is
+    4-POINT PACKED (include/nudf.h, NUDF_CH_STATE16: element (r, c) at ((r // 4) ld + c) 4 + r % 4; `unpack16` gives the
+    plain view) -- only the chain kernels and the grouped weight-gradient GEMM address it.
     blocked = True marks the buffer as holding the BLOCKED layout of include/nudf.h (same size; only the
     transposed-product chain kernel and the grouped weight-gradient GEMM address it; `unblock` gives the plain view)."""
     if blocked:
@@ -47,6 +49,13 @@ def _buf(P, width, dev, zero=None, dtype=torch.float32, blocked=False):
         t._nudf_blk = True
         return t
     ld = pad32(width)
+    if dtype == torch.bfloat16:
+        # pad columns: zero bits are zero in the packed layout as well -- the whole buffer is cleared only when asked for
+        t = (torch.zeros if zero else torch.empty)((pad_rows(P), ld), device=dev, dtype=dtype)
+        if zero is None and ld != width:
+            t.view(pad_rows(P) // 4, ld, 4)[:, width:, :].zero_()
+        t._nudf_p4 = True
+        return t
     if zero is None:          # only the pad COLUMNS must be finite zeros (they meet zero weight rows / unread dW columns);
         t = torch.empty((pad_rows(P), ld), device=dev, dtype=dtype)            # a full fill of a [65536, 224] buffer
         if ld != width:                                                        # costs 15 us, the 7 pad columns 3 us
@@ -61,6 +70,26 @@ def _is16(t):
 
 def _isblk(t):
     return t is not None and getattr(t, "_nudf_blk", False)
+
+
+def _isp4(t):
+    return t is not None and getattr(t, "_nudf_p4", False)
+
+
+def pack16(t):
+    """4-point packed bf16 copy of a row-major [R, ld] buffer (R % 4 == 0): the 16-bit stored-state layout."""
+    R, ld = t.shape
+    assert R % 4 == 0
+    b = t.to(torch.bfloat16).reshape(R // 4, 4, ld).permute(0, 2, 1).reshape(R, ld).contiguous()
+    b._nudf_p4 = True
+    return b
+
+
+def unpack16(t):
+    """row-major fp32 copy of a 4-point packed bf16 buffer; inverse of `pack16`."""
+    R, ld = t.shape
+    assert _isp4(t) and R % 4 == 0
+    return t.reshape(R // 4, ld, 4).permute(0, 2, 1).reshape(R, ld).float()
 
 
 def block(t):
@@ -215,6 +244,8 @@ class ChainBuilder:
     def init_store(self, G0):
         if G0 is not None:
             self.c.G0, self.c.ldg0 = self._p(G0), G0.shape[1]
+            if _is16(G0) and not _isp4(G0):
+                raise _lib.NudfError("a bf16 copy of the initial tile is 4-point packed (mlp.pack16 / _buf)")
             if _is16(G0) or _isblk(G0):
                 if self.c.init != CH_INIT["SEED"]:
                     raise _lib.NudfError("a bf16 / blocked copy of the initial tile exists for the SEED initialisation only")
@@ -226,6 +257,8 @@ class ChainBuilder:
     def init_seed(self, A0, lda0, sign, wrow, scale, xscale):
         self.c.A0, self.c.lda0 = self._p(A0), lda0
         if _is16(A0):
+            if not _isp4(A0):
+                raise _lib.NudfError("a bf16 seed operand is 4-point packed (mlp.pack16 / _buf)")
             self.c.init_state16 |= 1
         if _isblk(A0):
             self.c.init_state16 |= 4
@@ -251,9 +284,9 @@ class ChainBuilder:
         # 16-bit stored state (config-5 mode): X1, X2, C1, the TANGENT mirror C2 and pe_dst of a step are bf16 TOGETHER
         state = [t for t in (X1, X2, C1, C2 if epi == "TANGENT" else None, pe_dst) if t is not None]
         if any(_is16(t) for t in state):
-            if not all(_is16(t) for t in state) or epi not in ("SOFTPLUS", "MULSP", "TANGENT", "BWD") or s.prec == 0:
-                raise _lib.NudfError("bf16 stored state: every state array of a SOFTPLUS / MULSP / TANGENT / BWD step of "
-                                     "the 16-bit mode, or none")
+            if not all(_is16(t) and _isp4(t) for t in state) or epi not in ("SOFTPLUS", "MULSP", "TANGENT", "BWD") or s.prec == 0:
+                raise _lib.NudfError("bf16 stored state (4-point packed, mlp.pack16): every state array of a SOFTPLUS / "
+                                     "MULSP / TANGENT / BWD step of the 16-bit mode, or none")
             s.layout = _lib.CH_STATE16
         else:
             s.layout = ((1 if _isblk(X1) else 0) | (2 if _isblk(X2) else 0) | (4 if _isblk(C1) else 0) |
@@ -334,7 +367,8 @@ def gemm_tn_grouped(jobs, M):
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
             q.A1, q.B1, q.C, q.dbias = ptr(A1), ptr(B1), ptr(Cm), ptr(db)
-            q.flags = (1 if _is16(A1) else 0) | (2 if _is16(B1) else 0) | (4 if _isblk(A1) else 0) | (8 if _isblk(B1) else 0)
+            q.flags = ((1 if _is16(A1) else 0) | (2 if _is16(B1) else 0) | (4 if _isblk(A1) else 0) | (8 if _isblk(B1) else 0) |
+                       (16 if _isp4(A1) else 0) | (32 if _isp4(B1) else 0))
             q.lda1, q.ldb1, q.ldc, q.NA, q.NB = A1.shape[1], B1.shape[1], Cm.shape[1], NA, NB
             flops += 2.0 * M * NA * NB
             nbytes += float(M) * (NA * A1.element_size() + NB * B1.element_size())

@@ -196,6 +196,57 @@ def test_gemm_tn_grouped_16bit_mfma_mode(dev, M):
         assert rel(pb[:NA], j[5][:NA]) < 2e-5
 
 
+@pytest.mark.parametrize("M", [77, 1000, 5001])
+def test_gemm_tn_grouped_16bit_packed_operands(dev, M):
+    """the chains' 16-bit stored state is 4-POINT PACKED (include/nudf.h, NUDF_TN_A_P4 / _B_P4: element (r, c) at
+    ((r // 4) ld + c) 4 + r % 4): the packed-image kernel copies its dwords straight into the MFMA operand image.  Same
+    values, same MFMA order as the row-major bf16 operand: C is BIT-IDENTICAL, the bias sums agree to fp32 rounding (other
+    summation order); ragged widths, a ragged last quad (M % 4 != 0), pad rows holding garbage, packed with fp32 partners;
+    a packed operand outside the 16-bit mode / next to a row-major bf16 partner is refused."""
+    from neuraludf_amd import mlp, _lib
+    g = torch.Generator().manual_seed(15)
+    shapes = [(256, 256, True, True), (217, 256, False, True), (256, 40, True, True), (3, 128, True, False), (129, 72, True, True),
+              (1, 256, False, True)]
+    Mp = mlp.pad_rows(M)
+    jobs_rm, jobs_p4 = [], []
+    for NA, NB, a16, b16 in shapes:
+        lda, ldb = (NA + 7) // 8 * 8, (NB + 7) // 8 * 8
+        if not a16:
+            lda = (NA + 3) // 4 * 4
+        A = torch.randn(Mp, lda, generator=g)       # rows >= M: garbage the kernel must mask
+        B = torch.randn(Mp, ldb, generator=g)
+        A[M:] = float("nan")
+        B[M:] = float("nan")
+        Ad, Bd = A.to(dev), B.to(dev)
+        mk = lambda: (torch.zeros(mlp.pad32(NA), ldb, device=dev), torch.zeros(mlp.pad32(NA), device=dev))
+        jobs_rm.append((Ad.to(torch.bfloat16) if a16 else Ad, NA, Bd.to(torch.bfloat16) if b16 else Bd, NB) + mk())
+        Ap, Bp = (mlp.pack16(Ad) if a16 else Ad), (mlp.pack16(Bd) if b16 else Bd)
+        if a16:
+            assert torch.equal(mlp.unpack16(Ap)[:M], Ad.to(torch.bfloat16).float()[:M])
+        jobs_p4.append((Ap, NA, Bp, NB) + mk())
+    old = mlp.PRECISION
+    mlp.PRECISION = "mixed16"
+    try:
+        mlp.gemm_tn_grouped(jobs_rm, M)
+        mlp.gemm_tn_grouped(jobs_p4, M)
+        again = [(j[0], j[1], j[2], j[3], torch.zeros_like(j[4]), torch.zeros_like(j[5])) for j in jobs_p4]
+        mlp.gemm_tn_grouped(again, M)
+        # refused combinations
+        bad = jobs_p4[0]
+        with pytest.raises(_lib.NudfError):     # packed next to a row-major bf16 partner
+            mlp.gemm_tn_grouped([(bad[0], 256, jobs_rm[0][2], 256, torch.zeros_like(bad[4]), None)], M)
+        mlp.PRECISION = "fp32"
+        with pytest.raises(_lib.NudfError):     # packed operand, fp32 MFMA mode
+            mlp.gemm_tn_grouped([(bad[0], 256, bad[2], 256, torch.zeros_like(bad[4]), None)], M)
+    finally:
+        mlp.PRECISION = old
+    for (NA, NB, a16, b16), r, p, q in zip(shapes, jobs_rm, jobs_p4, again):
+        assert torch.isfinite(p[4]).all() and torch.isfinite(p[5]).all(), (NA, NB)
+        assert torch.equal(r[4], p[4]), (NA, NB, a16, b16)
+        assert rel(p[5][:NA], r[5][:NA]) < 2e-5, (NA, NB, a16, b16)
+        assert torch.equal(p[4], q[4]) and torch.equal(p[5], q[5])
+
+
 @pytest.mark.parametrize("M", [77, 5000])
 def test_gemm_tn_grouped_blocked_operands(dev, M):
     """fp32 operands in the BLOCKED layout of nudf.h (what the transposed-product chain kernel stores), alone and mixed

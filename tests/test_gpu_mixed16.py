@@ -55,3 +55,58 @@ def test_mixed16_render_and_gradients_track_fp32():
     worst = min(_cos(g16[k], g32[k]) for k in g32 if float(g32[k].abs().max()) > 0)
     assert worst > 0.98, worst
     print(f"mixed16 vs fp32: colour PSNR {psnr:.1f} dB, min gradient cosine {worst:.5f}")
+
+
+@pytest.mark.parametrize("P", [1000, 64 * 37 + 1])
+def test_mixed16_stored_state_is_4_point_packed(P):
+    """the 16-bit mode's saved arrays (X, DA; R / EX / ABAR through the parameter gradients) are bf16 in the 4-point
+    packed layout of include/nudf.h (NUDF_CH_STATE16): unpacked (mlp.unpack16) they are the fp32 path's arrays to 16-bit
+    operand accuracy at every row -- a layout slip would move whole rows by O(1) -- ragged P (pad rows, a partial last
+    quad for the weight-gradient GEMM) included; the parameter gradients of the three-sweep backward keep their direction."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from chain_sweeps import engines
+    from neuraludf_amd import mlp
+    dev = torch.device("cuda:0")
+    st_ = engines(dev)
+    eng, ceng = st_["eng"], st_["ceng"]
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    d_udf = torch.randn(P, generator=g).to(dev)
+    d_g = torch.randn(P, 3, generator=g).to(dev)
+    d_feat = (torch.randn(P, ceng.cin_ld, generator=g) * 0.1).to(dev)
+
+    def run():
+        st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
+        gr, DA = eng.gradient(x, st)
+        grads = eng.backward(x, st, DA, d_udf, d_feat, ceng.cin_ld, d_g)
+        return st, gr, DA, [t.clone() for t in grads]
+
+    assert mlp.PRECISION == "fp32"
+    st32, g32, DA32, p32 = run()
+    try:
+        mlp.set_precision("mixed16")
+        st16, g16, DA16, p16 = run()
+    finally:
+        mlp.set_precision("fp32")
+    L = len(DA32)
+    for l in range(1, L + 1):
+        a = st16["X"][l]
+        assert a.dtype == torch.bfloat16 and mlp._isp4(a)
+        w = eng.layers[l].inp
+        ref = mlp.unblock(st32["X"][l])[:P, :w] if mlp._isblk(st32["X"][l]) else st32["X"][l][:P, :w]
+        d = (mlp.unpack16(a)[:P, :w] - ref).abs()
+        assert float(d.max()) < 2e-2 * (float(ref.abs().max()) + 1e-6), (l, float(d.max()), float(ref.abs().max()))
+    for l in range(L):
+        w = eng.layers[l].out
+        ref = DA32[l][:P, :w]
+        got = mlp.unpack16(DA16[l])[:P, :w]
+        rel_l2 = float((got - ref).norm() / (ref.norm() + 1e-30))
+        assert rel_l2 < 3e-2, (l, rel_l2)
+        # per row: no row moved by O(1)
+        row = (got - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-3 * float(ref.norm(dim=1).max()))
+        assert float(row.max()) < 0.25, (l, float(row.max()))
+    assert float((g16 - g32).abs().max()) < 5e-2 * float(g32.abs().max())
+    for a, b in zip(p16, p32):
+        if float(b.abs().max()) > 0:
+            assert _cos(a, b) > 0.98, _cos(a, b)
