@@ -446,6 +446,10 @@ typedef struct NudfChainStep {
  * weight-gradient GEMM contracts (NUDF_TN_A_P4 / NUDF_TN_B_P4).  The same holds for a bf16 A0 / G0 of the SEED
  * initialisation (init_state16 bits 1 / 2). */
 #define NUDF_CH_STATE16 32
+/* the ReLU family of the 16-bit mode (colour net): per array, because its steps also touch fp32 interface buffers (the
+ * view-branch input, d VIN).  RELU: C1; MULMASK / ADDMASK: X1 and / or C1 -- bf16, 4-point packed as above. */
+#define NUDF_CH_P4_X1 64
+#define NUDF_CH_P4_C1 128
 typedef struct NudfChain {
   int32_t P, n_steps;
   int32_t init;                    /* NUDF_CH_INIT_*                                                 */

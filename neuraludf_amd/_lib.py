@@ -128,6 +128,7 @@ class Adam(C.Structure):
 
 CH_MAX_STEPS = 14
 CH_STATE16 = 32     # NudfChainStep.layout: the step's stored-state arrays hold bf16
+CH_P4_X1, CH_P4_C1 = 64, 128   # ReLU-family steps of the 16-bit mode: that array is bf16, 4-point packed
 CH = dict(NONE=0, SOFTPLUS=1, MULSP=2, TANGENT=3, BWD=4, UDFHEAD=5, RELU=6, SIGMOIDN=7, MULMASK=8, ADDMASK=9, RELUADD=10)
 CH_INIT = dict(LOAD=0, POSENC=1, SEED=2)
 

@@ -215,7 +215,8 @@ __device__ __forceinline__ void ch_p4_store(float* C, int ld, unsigned q0, unsig
 // need no predicate because every output / operand buffer is row-padded to the tile size (see nudf.h).
 // Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
 // S16: the step's stored-state arrays (X1, X2, C1, and the TANGENT mirror C2) hold bf16 (config-5 mode, NUDF_CH_STATE16)
-template <int EPI, bool X2IN = false, bool S16 = false>
+// RT16: ReLU-family step in the 16-bit instantiation -- X1 / C1 are bf16 (packed) where the step's layout bits say so
+template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
                                                  const float* x2in = nullptr) {
@@ -239,7 +240,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
   float x2[16];   // x1 (the stored activation) was prefetched under the fp32 K loop; the short 16-bit loops load it here
   if (CH_USES_X1(EPI) && load_x1) {
     const unsigned vo = grow0 * (unsigned)st.ldx1 + colc;
-    if (S16) {
+    if (S16 || (RT16 && (st.layout & NUDF_CH_P4_X1))) {
       uint2 w[4];
       ch_p4_load(st.X1, st.ldx1, (grow0 >> 2), colc, w);
 #pragma unroll
@@ -354,7 +355,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       }
     } else if (st.C1) {
       const unsigned vo = grow0 * (unsigned)st.ldc1 + col;
-      if (S16) {
+      if (S16 || (RT16 && (st.layout & NUDF_CH_P4_C1))) {
         ch_p4_store(st.C1, st.ldc1, (grow0 >> 2), (unsigned)col, out);
       } else {
 #pragma unroll
@@ -525,7 +526,8 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
         continue;
       }
     }
-    ch_epilogue_tile<EPI>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16);
+    constexpr bool RT16 = ANY16 && (EPI == NUDF_CH_RELU || EPI == NUDF_CH_MULMASK || EPI == NUDF_CH_ADDMASK);
+    ch_epilogue_tile<EPI, false, false, RT16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16);
   }
 }
 
@@ -752,7 +754,10 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     bad = (s.K & 15) || s.K <= 0 || s.K > 288 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
           (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 2 ||
           ((s.layout & NUDF_CH_STATE16) && s.epi != NUDF_CH_SOFTPLUS && s.epi != NUDF_CH_MULSP &&
-           s.epi != NUDF_CH_TANGENT && s.epi != NUDF_CH_BWD);
+           s.epi != NUDF_CH_TANGENT && s.epi != NUDF_CH_BWD) ||
+          ((s.layout & NUDF_CH_P4_X1) && s.epi != NUDF_CH_MULMASK && s.epi != NUDF_CH_ADDMASK) ||
+          ((s.layout & NUDF_CH_P4_C1) && s.epi != NUDF_CH_RELU && s.epi != NUDF_CH_MULMASK && s.epi != NUDF_CH_ADDMASK) ||
+          ((s.layout & (NUDF_CH_P4_X1 | NUDF_CH_P4_C1)) && s.prec == 0);
   }
   if (bad) {
     nudf_set_error("nudf_mlp_chain: K%16, K<=288, N<=256, x_div>=1, 16-byte aligned packed weights required", hipErrorInvalidValue);
@@ -760,7 +765,8 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   bool any16 = false;
-  for (int i = 0; i < p.n_steps; ++i) any16 = any16 || p.step[i].prec != 0 || (p.step[i].layout & NUDF_CH_STATE16);
+  for (int i = 0; i < p.n_steps; ++i)
+    any16 = any16 || p.step[i].prec != 0 || (p.step[i].layout & (NUDF_CH_STATE16 | NUDF_CH_P4_X1 | NUDF_CH_P4_C1));
   // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of
   // that kernel is 1024 waves = 32 768 points, so it is chosen when the last round is at least ~80 % full; the
   // up-sampling rounds (5-8 k points) and awkward sizes keep the workgroup-shared tiles below.

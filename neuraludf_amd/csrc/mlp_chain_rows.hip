@@ -1114,7 +1114,7 @@ int nudf_chain_rows_class(const NudfChain& p, bool allow_blocked) {
   auto vec_ok = [](const void* q, int ld) { return ((((uintptr_t)q) | ((unsigned)ld << 2)) & 15) == 0; };
   for (int i = 0; i < p.n_steps; ++i) {
     const NudfChainStep& s = p.step[i];
-    if (s.prec != 0 || (s.layout & NUDF_CH_STATE16)) return -1;
+    if (s.prec != 0 || (s.layout & (NUDF_CH_STATE16 | NUDF_CH_P4_X1 | NUDF_CH_P4_C1))) return -1;
     if ((s.layout & 31) && !allow_blocked) return -1;
     const int e = s.epi;
     if (CH_USES_X1(e)) {

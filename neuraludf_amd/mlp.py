@@ -283,7 +283,14 @@ class ChainBuilder:
         s.prec = getattr(Bp, "prec", 0)
         # 16-bit stored state (config-5 mode): X1, X2, C1, the TANGENT mirror C2 and pe_dst of a step are bf16 TOGETHER
         state = [t for t in (X1, X2, C1, C2 if epi == "TANGENT" else None, pe_dst) if t is not None]
-        if any(_is16(t) for t in state):
+        if epi in ("RELU", "MULMASK", "ADDMASK") and (_is16(X1) or _is16(C1)):
+            # the ReLU family (colour net): bf16 per array -- X2 (d VIN), the C2 mirror and pe_dst (VIN) stay fp32
+            if any(_is16(t) for t in (X2, C2, pe_dst)) or not all(_isp4(t) for t in (X1, C1) if _is16(t)) or s.prec == 0 \
+                    or (epi == "RELU" and _is16(X1)):
+                raise _lib.NudfError("bf16 stored state of a RELU / MULMASK / ADDMASK step: X1 and / or C1 (4-point packed, "
+                                     "mlp.pack16), 16-bit mode only")
+            s.layout = (_lib.CH_P4_X1 if _is16(X1) else 0) | (_lib.CH_P4_C1 if _is16(C1) else 0)
+        elif any(_is16(t) for t in state):
             if not all(_is16(t) and _isp4(t) for t in state) or epi not in ("SOFTPLUS", "MULSP", "TANGENT", "BWD") or s.prec == 0:
                 raise _lib.NudfError("bf16 stored state (4-point packed, mlp.pack16): every state array of a SOFTPLUS / "
                                      "MULSP / TANGENT / BWD step of the 16-bit mode, or none")
@@ -1172,8 +1179,9 @@ class ColorEngine:
         pack_group(self.base + self.view, self._kinds())
         Pp = pad_rows(P)
         VIN = torch.empty(Pp, pad32(H + npe + dout), device=dev) if keep_state else None
-        HB = [CIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
-        HV = [VIN] + [_buf(P, H, dev, zero=False) for _ in range(n - 1)] if keep_state else None
+        sd = _state_dtype()     # hidden activations: bf16 (4-point packed) in the 16-bit mode; CIN / VIN stay fp32
+        HB = [CIN] + [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] if keep_state else None
+        HV = [VIN] + [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] if keep_state else None
         cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp))
         cb.init_load(CIN, CIN.shape[1])
         cb.posenc(rays_d, self.net.multires_view, 1.0, x_div=S)
@@ -1209,7 +1217,8 @@ class ColorEngine:
         grads = alloc_grads(self.view + self.base)
         plv = self.view[n - 1]
         nb = plv.out - dout
-        Dv = [_buf(P, H, dev, zero=False) for _ in range(n - 1)] + [_buf(P, plv.out, dev, zero=False)]
+        sd = HV[1].dtype        # adjoints of the hidden layers follow the saved activations (bf16 in the 16-bit mode)
+        Dv = [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] + [_buf(P, plv.out, dev, zero=False)]
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(Dv[n - 1]), Dv[n - 1].shape[1])
         dVIN = _buf(P, self.view[0].inp, dev, zero=False)
@@ -1223,7 +1232,7 @@ class ColorEngine:
         cb.launch()
         # base head: d color_base = direct + through the view branch's input columns
         plb = self.base[n - 1]
-        Db = [_buf(P, H, dev, zero=False) for _ in range(n - 1)] + [_buf(P, plb.out, dev, zero=False)]
+        Db = [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] + [_buf(P, plb.out, dev, zero=False)]
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (H + npe), dVIN.shape[1],
              dout, None, 0, 0, P, ptr(Db[n - 1]), Db[n - 1].shape[1])
         dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3s
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_mixed16.py tests/test_gpu_kernels.py -k "mixed16 or gemm_tn" "tests/test_gpu_fullsize_parity.py::test_mixed16_at_cfg5_shape_vs_reference" "tests/test_gpu_fullsize_parity.py::test_mixed16_vs_oracle_psnr_hierarchical" -q -x > $O/pytest.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_mixed16.py tests/test_gpu_kernels.py tests/test_abi.py -k "mixed16 or gemm_tn or color or abi" "tests/test_gpu_fullsize_parity.py::test_mixed16_at_cfg5_shape_vs_reference" "tests/test_gpu_fullsize_parity.py::test_mixed16_vs_oracle_psnr_hierarchical" -q -x > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
 tail -n 30 $O/pytest.log
 for i in a b; do

@@ -110,3 +110,52 @@ def test_mixed16_stored_state_is_4_point_packed(P):
     for a, b in zip(p16, p32):
         if float(b.abs().max()) > 0:
             assert _cos(a, b) > 0.98, _cos(a, b)
+
+
+@pytest.mark.parametrize("P", [960, 64 * 41])
+def test_mixed16_colour_net_state_is_packed_bf16(P):
+    """the colour net's saved hidden activations and hidden adjoints are bf16 (4-point packed) in the 16-bit mode while
+    its interface buffers (CIN, VIN, d VIN, d CIN, the head adjoints) stay fp32: unpacked hidden state = the fp32 path's to
+    16-bit accuracy at every row, outputs within the mode's bar, parameter gradients and d CIN keep their direction."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from chain_sweeps import engines
+    from neuraludf_amd import mlp
+    dev = torch.device("cuda:0")
+    st_ = engines(dev)
+    eng, ceng = st_["eng"], st_["ceng"]
+    S = 64
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    rays_d = torch.nn.functional.normalize(torch.randn(P // S, 3, generator=g), dim=-1).to(dev)
+    d_cb = torch.randn(P, 3, generator=g).to(dev)
+    d_cc = torch.randn(P, 3, generator=g).to(dev)
+    feat = eng.forward(x, need_grad_state=False, feat_ld=ceng.cin_ld)["feat"]      # fp32 features for both runs
+
+    def run():
+        cb, cc, logits, cst = ceng.forward(feat, rays_d, S, P)
+        d_lg = torch.randn(P, logits.shape[1], generator=torch.Generator().manual_seed(7)).to(dev) if logits is not None else None
+        grads, dCIN = ceng.backward(cst, cb, cc, d_cb, d_cc, d_lg)
+        return cb.clone(), cc.clone(), cst, [t.clone() for t in grads], dCIN.clone()
+
+    assert mlp.PRECISION == "fp32"
+    cb32, cc32, st32, g32, d32 = run()
+    try:
+        mlp.set_precision("mixed16")
+        cb16, cc16, st16, g16, d16 = run()
+    finally:
+        mlp.set_precision("fp32")
+    assert _psnr(cc16, cc32) > 55.0 and _psnr(cb16, cb32) > 55.0
+    for name in ("HB", "HV"):
+        assert st16[name][0].dtype == torch.float32          # CIN / VIN
+        for l in range(1, len(st32[name])):
+            a, ref = st16[name][l], st32[name][l][:P]
+            assert a.dtype == torch.bfloat16 and mlp._isp4(a)
+            got = mlp.unpack16(a)[:P]
+            row = (got - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-3 * float(ref.norm(dim=1).max()))
+            assert float(row.max()) < 0.1, (name, l, float(row.max()))
+            assert bool(((got > 0) == (ref > 0)).float().mean() > 0.995)      # the ReLU masks of the reverse sweep
+    assert _cos(d16[:, :256], d32[:, :256]) > 0.99
+    for a, b in zip(g16, g32):
+        if float(b.abs().max()) > 0:
+            assert _cos(a, b) > 0.98, _cos(a, b)
