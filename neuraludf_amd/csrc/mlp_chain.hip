@@ -129,13 +129,18 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
 // activation tile converted on the fly (v_cvt_pk_*_f32, round-to-nearest-even) and one 16-byte read of the
 // pre-converted weight fragments per 32-column tile.  16x the fp32 MFMA rate and a separate matrix pipe: the
 // sweep becomes epilogue / LDS bound.
+#ifndef NUDF_MMA16_RING
+#define NUDF_MMA16_RING 1    // A/B build switch (scripts/build_variants.sh): 0 = one k step of weight fragments in flight
+#endif
 template <int NRT, int NCT, bool BF>
 __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride,
                                          int G16, f32x16 (&acc)[2][2]) {
   // (requesting the epilogue's stored-state operands under this loop, as the fp32 loop does, was measured in round 2:
   // 64 more live registers next to the conversions -> 185-511 spilled registers, chains 7.2 -> 17.8 ms at config 5)
   f32x4 a0[NRT][2], a1[NRT][2];
+#if !NUDF_MMA16_RING
   uint4 b0[NCT], b1[NCT];
+#endif
   auto lda = [&](f32x4 (&a)[NRT][2], int g) {
 #pragma unroll
     for (int i = 0; i < NRT; ++i) {
@@ -163,6 +168,54 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
       }
     }
   };
+#if NUDF_MMA16_RING
+  // Weight fragments come from L2 (~600-800 cycles) and a 16-wide k step is only 4 MFMAs = 128 matrix cycles per wave:
+  // with the fragments of ONE step in flight (the fp32 loop's depth, where a step is 1024 cycles) two waves per SIMD keep
+  // the pipe at ~50 % (scripts/chain_timeline.py, 16-bit mode).  Ring of 4 fragment sets = three k steps in flight; the
+  // prefetch index is clamped instead of guarded (branch-free body, exact vmcnt), the last G16 % 4 steps run as a tail.
+  uint4 br[4][NCT];
+  const int gl = G16 - 1;
+  lda(a0, 0);
+  ldb(br[0], 0);
+  ldb(br[1], min(1, gl));
+  ldb(br[2], min(2, gl));
+  int g = 0;
+#pragma unroll 1
+  for (; g + 4 <= G16; g += 4) {
+    ldb(br[3], min(g + 3, gl));
+    lda(a1, min(g + 1, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, br[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    ldb(br[0], min(g + 4, gl));
+    lda(a0, min(g + 2, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, br[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    ldb(br[1], min(g + 5, gl));
+    lda(a1, min(g + 3, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, br[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    ldb(br[2], min(g + 6, gl));
+    lda(a0, min(g + 4, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, br[3]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int rem = G16 - g;          // 0..3 steps left: fragments in br[0..rem-1], activations of step g in a0
+  if (rem > 0) {
+    if (rem > 1) lda(a1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, br[0]);
+    if (rem > 1) {
+      if (rem > 2) lda(a0, g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, br[1]);
+      if (rem > 2) mma(a0, br[2]);
+    }
+  }
+#else
   lda(a0, 0);
   ldb(b0, 0);
   int g = 0;
@@ -181,6 +234,7 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
     __builtin_amdgcn_sched_barrier(0);
   }
   if (g < G16) mma(a0, b0);   // odd number of 16-wide k steps
+#endif
 }
 
 // 16-bit stored state, 4-point packed (ch_p4_off): the 16 accumulator rows of a lane are 4 groups of 4 consecutive

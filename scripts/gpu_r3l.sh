@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B at the config-5 shape: sequential 16-bit epilogues (NUDF_SEQ16=1, default) against the per-tile epilogues (=0)
+# A/B at the config-5 shape: ring of 4 weight-fragment sets in the 16-bit K loop (NUDF_MMA16_RING=1, default) against depth 1 (=0)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3l
@@ -9,10 +9,10 @@ timeout 600 python -m pytest tests/test_gpu_mixed16.py "tests/test_gpu_fullsize_
 echo "pytest rc $?" >> $O/pytest.log
 grep -E "passed|failed|mixed16" $O/pytest.log | tail -n 6
 b() { name=$1; shift; env "$@" timeout 300 python bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$name.json 2>> $O/bench.err; }
-b seq16_a NUDF_X=1
-b noseq16_a NUDF_LIB=$B/libnudf_noseq16.so
-b seq16_b NUDF_X=1
-b noseq16_b NUDF_LIB=$B/libnudf_noseq16.so
+b ring_a NUDF_X=1
+b noring_a NUDF_LIB=$B/libnudf_noring.so
+b ring_b NUDF_X=1
+b noring_b NUDF_LIB=$B/libnudf_noring.so
 python - <<'PY'
 import json,glob,os
 O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r3l"
