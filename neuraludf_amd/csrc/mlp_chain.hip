@@ -129,6 +129,12 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
 // activation tile converted on the fly (v_cvt_pk_*_f32, round-to-nearest-even) and one 16-byte read of the
 // pre-converted weight fragments per 32-column tile.  16x the fp32 MFMA rate and a separate matrix pipe: the
 // sweep becomes epilogue / LDS bound.
+#ifndef NUDF_STAGGER16
+#define NUDF_STAGGER16 0u    // s_sleep(127) units the odd wave slots of the 16-bit instantiation start late (A/B switch;
+#endif                       // measured 0..4 at the config-5 shape: 7.53 / 7.68 / 7.77 / 7.87 / 7.98 ms -- pure delay there)
+#ifndef NUDF_STAGGER32
+#define NUDF_STAGGER32 2u    // the same for the fp32 instantiation's 64-point tiles (0 also switches the 32-point tiles' stagger off)
+#endif
 #ifndef NUDF_MMA16_RING
 #define NUDF_MMA16_RING 1    // A/B build switch (scripts/build_variants.sh): 0 = one k step of weight fragments in flight
 #endif
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
   // that one workgroup's epilogues run under the other's MFMA phases.  Speed only.
   const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
   if (gridDim.x > 256) {
-    const unsigned k = (TM == 64) ? (slot & 1u) * 2u : (slot % 3u);
+    const unsigned k = ANY16 ? (slot & 1u) * NUDF_STAGGER16 : ((TM == 64) ? (slot & 1u) * NUDF_STAGGER32 : (slot % 3u) * (NUDF_STAGGER32 ? 1u : 0u));
     for (unsigned d = 0; d < k; ++d) __builtin_amdgcn_s_sleep(127);
   }
 

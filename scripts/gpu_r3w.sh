@@ -1,21 +1,17 @@
 #!/bin/bash
-# A/B at the config-5 shape: packed-pair epilogue algebra in the 16-bit mode (NUDF_PK16=1, default) against per-element (=0)
+# 16-bit mode at the config-5 shape: 64-point tiles (2 workgroups / CU) against 32-point tiles (3 / CU by registers)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r3l
+O=$GRAFT_REPO_ROOT/gpurun_out/r3w
 mkdir -p $O
-B=$GRAFT_REPO_ROOT/neuraludf_amd/build
-timeout 600 python -m pytest tests/test_gpu_mixed16.py "tests/test_gpu_fullsize_parity.py::test_mixed16_at_cfg5_shape_vs_reference" "tests/test_gpu_fullsize_parity.py::test_mixed16_vs_oracle_psnr_hierarchical" -q -s > $O/pytest.log 2>&1
-echo "pytest rc $?" >> $O/pytest.log
-grep -E "passed|failed|mixed16" $O/pytest.log | tail -n 6
 b() { name=$1; shift; env "$@" timeout 300 python bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$name.json 2>> $O/bench.err; }
-b pk_a NUDF_X=1
-b nopk_a NUDF_LIB=$B/libnudf_nopk.so
-b pk_b NUDF_X=1
-b nopk_b NUDF_LIB=$B/libnudf_nopk.so
+for r in a b; do
+b t64_$r NUDF_X=1
+b t32_$r NUDF_CHAIN_TILE=32
+done
 python - <<'PY'
 import json,glob,os
-O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r3l"
+O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r3w"
 for f in sorted(glob.glob(O+"/bench_*.json")):
     try: d=json.load(open(f))
     except Exception as e: print(f, "ERR", e); continue
