@@ -507,7 +507,7 @@ def pmc_traffic(kernel, workload, precision="fp32"):
     if (workload, precision) == ("dtu_scan24_512x128", "fp32"):
         names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (3, 2, 1)]
     elif (workload, precision) == ("dtu_scan24_1024x256", "mixed16"):
-        names = ["r02_traffic_%s_cfg5_mixed16.json" % kernel]
+        names = ["r%02d_traffic_%s_cfg5_mixed16.json" % (r, kernel) for r in (3, 2)]
     else:
         return None
     path = next((q for q in (os.path.join(ROOT, "profiles", nm) for nm in names) if os.path.exists(q)), None)
