@@ -458,8 +458,8 @@ typedef struct NudfChain {
   int32_t tile_rows;               /* 0 = choose; 32 / 64 points per workgroup (shared tile); 66 = 64-point shared tile,
                                       transposed product (16-byte epilogue accesses); 128 = prefer the wave-private
                                       kernel (4 waves x 32 points); 130 = two 64-point tiles per workgroup run in
-                                      anti-phase (mlp_chain_pair_kernel: what 0 chooses for fp32 launches of >= 32 768
-                                      points); 66 / 128 / 130 need fp32 steps and 16-byte aligned rows and fall back
+                                      anti-phase (mlp_chain_pair_kernel: opt-in, a measured counter-example -- NUDF_CHAIN_PAIR);
+                                      66 / 128 / 130 need fp32 steps and 16-byte aligned rows and fall back
                                       to 64 otherwise */
   int32_t lda0, ldg0;
   int32_t pe_L, pe_jvp;            /* positional encoding: frequencies, 1 = JVP with tangent v       */

@@ -636,13 +636,16 @@ __device__ __forceinline__ void tq_mma_ring(const float* __restrict__ arow, cons
   }
 }
 
-// the wave's tiles as straight-line code; X2 of tile t + 1 is requested before tile t is computed and stored
-template <int EPI, int NRT, int NCT>
+// the wave's tiles as straight-line code; X2 of tile t + 1 is requested before tile t is computed and stored.
+// S1: so is X1 -- only tile 0's X1 (px1[0][0]) and X2 (px2_0) were requested under the K loop, 32 registers instead of the
+// 64 of a whole-step X1 prefetch; the registers pay for a third operand set in the K loop (tq_mma_ring).
+template <int EPI, int NRT, int NCT, bool S1 = false>
 __device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
-                                            int h, int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16], const float* bias_lds) {
-  constexpr bool U2 = CH_USES_X2(EPI);
+                                            int h, int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16], const float* bias_lds,
+                                            float (*px2_0)[16] = nullptr) {
+  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
   constexpr int NTL = NRT * NCT;
-  float xb[2][16];
+  float xa[2][16], xb[2][16];
   auto issue = [&](float (&x)[16], int i, int j) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -652,28 +655,45 @@ __device__ __forceinline__ void tq_epilogue(const NudfChainStep& st, float* act,
       for (int e = 0; e < 4; ++e) x[4 * q + e] = v[e];
     }
   };
-  if (U2) issue(xb[0], 0, 0);
+  auto issue1 = [&](float (&x)[16], int i, int j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = chr_load_quad(cs[i].X1, cs[i].x1, 32 * (ct0 + j) + 4 * h + 8 * q, cs[i].nq, cs[i].m1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[4 * q + e] = v[e];
+    }
+  };
+  if (U2) {
+    if (S1 && px2_0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xb[0][r] = (*px2_0)[r];
+    } else {
+      issue(xb[0], 0, 0);
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
+    if (S1 && U1 && t + 1 < NTL) issue1(xa[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
     if (U2 && t + 1 < NTL) issue(xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
     const int i = t / NCT, j = t % NCT;
-    chr_epi_tile<EPI>(st, act + (rt0 + i) * 32 * CH_LD, cs[i], ct0 + j, h, ln, acc[i][j], px1[i][j], xb[t & 1], false, 0,
-                      bias_lds);
+    chr_epi_tile<EPI>(st, act + (rt0 + i) * 32 * CH_LD, cs[i], ct0 + j, h, ln, acc[i][j],
+                      (S1 && t > 0) ? xa[t & 1] : px1[S1 ? 0 : i][S1 ? 0 : j], xb[t & 1], false, 0, bias_lds);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int EPI>
+template <int EPI, bool S1 = false>
 __device__ __forceinline__ void tq_epilogue_any(const NudfChainStep& st, float* act, const ChrStep (&cs)[2], int rt0, int ct0,
                                                 int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
-                                                float (&px1)[2][2][16], const float* bias_lds) {
-  if (nrt == 2 && nct == 2) tq_epilogue<EPI, 2, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
-  else if (nrt == 2) tq_epilogue<EPI, 2, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
-  else if (nct == 2) tq_epilogue<EPI, 1, 2>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
-  else tq_epilogue<EPI, 1, 1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds);
+                                                float (&px1)[2][2][16], const float* bias_lds, float (*px2_0)[16] = nullptr) {
+  if (nrt == 2 && nct == 2) tq_epilogue<EPI, 2, 2, S1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds, px2_0);
+  else if (nrt == 2) tq_epilogue<EPI, 2, 1, S1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds, px2_0);
+  else if (nct == 2) tq_epilogue<EPI, 1, 2, S1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds, px2_0);
+  else tq_epilogue<EPI, 1, 1, S1>(st, act, cs, rt0, ct0, h, ln, acc, px1, bias_lds, px2_0);
 }
 
-template <int XCLS, int RING = 0>
+// S1: the epilogues' X1 operand is streamed one tile ahead (tq_epilogue) instead of prefetched for the whole step
+template <int XCLS, int RING = 0, bool S1 = false>
 __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
   __shared__ __attribute__((aligned(16))) ChainTqSmem sm;
   const int tid = threadIdx.x;
@@ -786,6 +806,7 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
 
     f32x16 acc[2][2];
     float px1[2][2][16];
+    float px2[16];      // S1: X2 of the wave's first tile
     // next step's bias: requested now, staged into LDS after the K loop (thread t <-> feature t)
     float nbias = 0.0f;
     if (si + 1 < p.n_steps) {
@@ -797,12 +818,13 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
       const f32x4* bptr = reinterpret_cast<const f32x4*>(st.Bp) + (size_t)ct0 * 64 + lane;
       const size_t bstride = (size_t)NT * 64;
       const bool u1 = XCLS >= 1 && CH_USES_X1(st.epi);
+      const bool u2 = XCLS >= 2 && CH_USES_X2(st.epi) && cs[0].X2;
       auto tail = [&]() {
         if (XCLS == 0) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < (S1 ? 1 : 2); ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < (S1 ? 1 : 2); ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -810,6 +832,15 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) px1[i][j][4 * q + e] = v[e];
             }
+        if (S1 && XCLS >= 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (u2) v = chr_load_quad(cs[0].X2, cs[0].x2, 32 * ct0 + 4 * h + 8 * q, cs[0].nq, cs[0].m2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) px2[4 * q + e] = v[e];
+          }
+        }
       };
       if (RING > 1) {
         constexpr int D = RING > 1 ? RING : 2;
@@ -830,17 +861,17 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: tq_epilogue_any<NUDF_CH_SOFTPLUS>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_NONE: tq_epilogue_any<NUDF_CH_NONE>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_RELU: tq_epilogue_any<NUDF_CH_RELU>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_SIGMOIDN: tq_epilogue_any<NUDF_CH_SIGMOIDN>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_UDFHEAD: tq_epilogue_any<NUDF_CH_UDFHEAD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_MULSP: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULSP>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_MULMASK: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_TANGENT: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_TANGENT>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_BWD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_BWD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_ADDMASK: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_ADDMASK>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
-        case NUDF_CH_RELUADD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_RELUADD>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1]); break;
+        case NUDF_CH_SOFTPLUS: tq_epilogue_any<NUDF_CH_SOFTPLUS, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_NONE: tq_epilogue_any<NUDF_CH_NONE, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_RELU: tq_epilogue_any<NUDF_CH_RELU, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_SIGMOIDN: tq_epilogue_any<NUDF_CH_SIGMOIDN, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_UDFHEAD: tq_epilogue_any<NUDF_CH_UDFHEAD, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_MULSP: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULSP, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_MULMASK: if (XCLS >= 1) tq_epilogue_any<NUDF_CH_MULMASK, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_TANGENT: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_TANGENT, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_BWD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_BWD, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_ADDMASK: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_ADDMASK, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
+        case NUDF_CH_RELUADD: if (XCLS >= 2) tq_epilogue_any<NUDF_CH_RELUADD, S1>(st, sm.act, cs, rt0, ct0, nrt, nct, h, ln, acc, px1, sm.bias[si & 1], (S1 && XCLS >= 2) ? &px2 : nullptr); break;
         default: break;
       }
     }
@@ -1093,15 +1124,34 @@ int nudf_chain_pair_mode() {
 int nudf_mlp_chain_tq_launch(const NudfChain& p, int cls, hipStream_t st, int force_pair) {
   const dim3 grid((p.P + 63) / 64), block(256);
   // forward sweeps (no stored-state operand): three register sets in the K loop, two k groups of operand reads in flight
-  // (tq_mma_ring; measured 629 -> 605 us at 65 536 points).  The input-gradient instantiation spills 28 registers with a
-  // third set and gains nothing, the tangent / adjoint one has no room at all (254 of 256 VGPRs).  NUDF_TQ_RING=0: two sets.
+  // (tq_mma_ring; measured 629 -> 605 us at 65 536 points).  NUDF_TQ_RING=0: two sets.
   static const int ring = [] {
     const char* e = getenv("NUDF_TQ_RING");
     return e ? atoi(e) : 3;
   }();
+  static const int s1 = [] {
+    const char* e = getenv("NUDF_TQ_S1");
+    return e ? atoi(e) : 1;
+  }();
+  if (force_pair || (nudf_chain_pair_mode() > 0 && p.P >= 32768)) {   // paired tiles: tile_rows 130 / NUDF_CHAIN_PAIR
+    const dim3 pgrid((p.P + 127) / 128), pblock(512);
+    if (cls == 0) hipLaunchKernelGGL((mlp_chain_pair_kernel<0>), pgrid, pblock, 0, st, p);
+    else if (cls == 1) hipLaunchKernelGGL((mlp_chain_pair_kernel<1>), pgrid, pblock, 0, st, p);
+    else hipLaunchKernelGGL((mlp_chain_pair_kernel<2>), pgrid, pblock, 0, st, p);
+    NUDF_CHECK_LAUNCH("nudf_mlp_chain(pair)");
+    return 0;
+  }
   if (cls == 0 && ring == 3) hipLaunchKernelGGL((mlp_chain_tq_kernel<0, 3>), grid, block, 0, st, p);
   else if (cls == 0) hipLaunchKernelGGL((mlp_chain_tq_kernel<0>), grid, block, 0, st, p);
+  // input-gradient sweeps: X1 streamed one tile ahead (NUDF_TQ_S1, default 1) frees the registers for the third operand
+  // set (197 VGPRs, 646-652 -> 637 us at 65 536 points).  The tangent / adjoint instantiation gets SLOWER with a streamed
+  // X1, with two or three operand sets (tangent 675 -> 703 us, adjoint 692-750 -> 727-775: two more exposed operand
+  // requests per tile): it keeps the whole-step prefetch; NUDF_TQ_S1=2 / 3 select those builds for measurements.
+  else if (cls == 1 && s1 && ring == 3) hipLaunchKernelGGL((mlp_chain_tq_kernel<1, 3, true>), grid, block, 0, st, p);
+  else if (cls == 1 && s1) hipLaunchKernelGGL((mlp_chain_tq_kernel<1, 0, true>), grid, block, 0, st, p);
   else if (cls == 1) hipLaunchKernelGGL((mlp_chain_tq_kernel<1>), grid, block, 0, st, p);
+  else if (s1 == 3 && ring == 3) hipLaunchKernelGGL((mlp_chain_tq_kernel<2, 3, true>), grid, block, 0, st, p);
+  else if (s1 >= 2) hipLaunchKernelGGL((mlp_chain_tq_kernel<2, 0, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((mlp_chain_tq_kernel<2>), grid, block, 0, st, p);
   NUDF_CHECK_LAUNCH("nudf_mlp_chain(tq)");
   return 0;
