@@ -200,6 +200,8 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
 USE_CHAIN = os.environ.get("NUDF_CHAIN", "1") != "0"     # 0: per-layer GEMM launches (A/B measurements, cross-checks)
 CHAIN_DEBUG = None     # int64 tensor [blocks * 4, 32]: per-wave timeline written by the kernel (scripts/chain_timeline.py)
 CHAIN_TILE = int(os.environ.get("NUDF_CHAIN_TILE", "0"))  # 0 = auto, 32 / 64 force the points-per-workgroup tile
+# the colour net's three chains alone ("" = as CHAIN_TILE; A/B switch: its 128-wide layers behave differently from the UDF net's)
+COLOR_TILE = int(os.environ.get("NUDF_COLOR_TILE", "0"))
 
 
 def k8(n: int) -> int:
@@ -1182,7 +1184,7 @@ class ColorEngine:
         sd = _state_dtype()     # hidden activations: bf16 (4-point packed) in the 16-bit mode; CIN / VIN stay fp32
         HB = [CIN] + [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] if keep_state else None
         HV = [VIN] + [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] if keep_state else None
-        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp))
+        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp), tile_rows=COLOR_TILE)
         cb.init_load(CIN, CIN.shape[1])
         cb.posenc(rays_d, self.net.multires_view, 1.0, x_div=S)
         for l in range(n - 1):
@@ -1222,7 +1224,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(Dv[n - 1]), Dv[n - 1].shape[1])
         dVIN = _buf(P, self.view[0].inp, dev, zero=False)
-        cb = ChainBuilder(P, "LOAD", k8(plv.out))
+        cb = ChainBuilder(P, "LOAD", k8(plv.out), tile_rows=COLOR_TILE)
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
@@ -1236,7 +1238,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (H + npe), dVIN.shape[1],
              dout, None, 0, 0, P, ptr(Db[n - 1]), Db[n - 1].shape[1])
         dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)
-        cb = ChainBuilder(P, "LOAD", k8(plb.out))
+        cb = ChainBuilder(P, "LOAD", k8(plb.out), tile_rows=COLOR_TILE)
         cb.init_load(Db[n - 1], Db[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.base[i]
