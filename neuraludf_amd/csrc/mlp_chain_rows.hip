@@ -336,7 +336,9 @@ __device__ __forceinline__ f32x4 chr_bias_fetch(const NudfChainStep& st, int lan
 // sweeps), 2 X1 and X2 (tangent / adjoint sweeps); W = tiles per operand window.  Separate instantiations keep the
 // windows (16 W registers per operand) and the unused epilogues out of the sweeps that do not need them.
 template <int XCLS, int W>
-__global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfChain p) {
+__global__ __launch_bounds__(CHR_WAVES * 64, 1) void mlp_chain_rows_kernel(NudfChain p_arg) {
+  (void)p_arg;   // read where it lies (see mlp_chain_kernel): no private copy for the optimiser to prove away
+  const NudfChain& p = *(const NudfChain*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) ChainRowsSmem sm;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -694,7 +696,9 @@ __device__ __forceinline__ void tq_epilogue_any(const NudfChainStep& st, float* 
 
 // S1: the epilogues' X1 operand is streamed one tile ahead (tq_epilogue) instead of prefetched for the whole step
 template <int XCLS, int RING = 0, bool S1 = false>
-__global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p) {
+__global__ __launch_bounds__(256, 2) void mlp_chain_tq_kernel(NudfChain p_arg) {
+  (void)p_arg;   // read where it lies (see mlp_chain_kernel): no private copy for the optimiser to prove away
+  const NudfChain& p = *(const NudfChain*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) ChainTqSmem sm;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -913,7 +917,9 @@ struct ChainPairSmem {
 };
 
 template <int XCLS>
-__global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(NudfChain p) {
+__global__ __launch_bounds__(512, 2) void mlp_chain_pair_kernel(NudfChain p_arg) {
+  (void)p_arg;   // read where it lies (see mlp_chain_kernel): no private copy for the optimiser to prove away
+  const NudfChain& p = *(const NudfChain*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) ChainPairSmem sm;
   const int tid8 = threadIdx.x;
   const int half = __builtin_amdgcn_readfirstlane(tid8 >> 8);
