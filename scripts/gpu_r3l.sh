@@ -1,5 +1,8 @@
 #!/bin/bash
-# A/B at the config-5 shape: packed-pair epilogue algebra in the 16-bit mode (NUDF_PK16=1, default) against per-element (=0)
+# A/B at the config-5 shape (1024 x 256, 16-bit mode) between the shipping library and variant builds of it:
+#   scripts/build_variants.sh <tag> <source.hip> -D<SWITCH>=<value>      (e.g. noring mlp_chain.hip -DNUDF_MMA16_RING=0)
+#   VARIANTS="<tag> ..." scripts/gpurun.sh scripts/gpu_r3l.sh
+# (used for profiles/r03_chain_experiments.txt items 7-9: NUDF_SEQ16, NUDF_MMA16_RING, the removed packed-pair algebra)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3l
@@ -7,12 +10,12 @@ mkdir -p $O
 B=$GRAFT_REPO_ROOT/neuraludf_amd/build
 timeout 600 python -m pytest tests/test_gpu_mixed16.py "tests/test_gpu_fullsize_parity.py::test_mixed16_at_cfg5_shape_vs_reference" "tests/test_gpu_fullsize_parity.py::test_mixed16_vs_oracle_psnr_hierarchical" -q -s > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
-grep -E "passed|failed|mixed16" $O/pytest.log | tail -n 6
+grep -E "passed|failed" $O/pytest.log | tail -n 2
 b() { name=$1; shift; env "$@" timeout 300 python bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$name.json 2>> $O/bench.err; }
-b pk_a NUDF_X=1
-b nopk_a NUDF_LIB=$B/libnudf_nopk.so
-b pk_b NUDF_X=1
-b nopk_b NUDF_LIB=$B/libnudf_nopk.so
+for r in a b; do
+  b ship_$r NUDF_X=1
+  for v in $VARIANTS; do b ${v}_$r NUDF_LIB=$B/libnudf_$v.so; done
+done
 python - <<'PY'
 import json,glob,os
 O=os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r3l"

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B at the config-5 shape (16-bit mode): start offset of the odd wave slots, in s_sleep(127) units (default 2)
+# A/B at the config-5 shape (16-bit mode): start offset of the odd wave slots, in s_sleep(127) units (shipping: 0).
+# Build the variants first: for k in 1 2 3 4; do scripts/build_variants.sh stag$k mlp_chain.hip -DNUDF_STAGGER16=${k}u; done
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3u
@@ -7,8 +8,8 @@ mkdir -p $O
 B=$GRAFT_REPO_ROOT/neuraludf_amd/build
 b() { name=$1; shift; env "$@" timeout 300 python bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$name.json 2>> $O/bench.err; }
 for r in a b; do
-b stag2_$r NUDF_X=1
-for k in 0 1 3 4; do b stag${k}_$r NUDF_LIB=$B/libnudf_stag$k.so; done
+b stag0_$r NUDF_X=1
+for k in 1 2 3 4; do b stag${k}_$r NUDF_LIB=$B/libnudf_stag$k.so; done
 done
 python - <<'PY'
 import json,glob,os

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B, fp32 headline workload: start offset of the odd wave slots in the shared-tile kernel (default 2 sleeps) vs none
+# A/B, fp32 headline workload: start offset of the odd wave slots in the shared-tile kernel (shipping: 2 sleeps) vs none.
+# Build the variant first: scripts/build_variants.sh stag32_0 mlp_chain.hip -DNUDF_STAGGER32=0u
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3v
