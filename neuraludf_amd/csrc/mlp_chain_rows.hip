@@ -24,6 +24,9 @@
 
 // A/B build switches of the transposed-product shared-tile kernel (scripts/build_variants.sh): alternating wave priority
 // per layer (1, shipping) / none (0) / fixed by wave slot (2); the one-off start-up delay of odd wave slots (1 / 0)
+#ifndef NUDF_TQ_SPREAD
+#define NUDF_TQ_SPREAD 1     // K loop: next group's operand requests spread over the current group's MFMA quarters (A/B: 0)
+#endif
 #ifndef NUDF_TQ_PRIO
 #define NUDF_TQ_PRIO 1
 #endif
@@ -523,6 +526,32 @@ __device__ __forceinline__ void tq_mma(const float* __restrict__ arow, const f32
   for (int i = 0; i < NRT; ++i) a0[i] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD);
 #pragma unroll
   for (int j = 0; j < NCT; ++j) b0[j] = bptr[j * 64];
+#if NUDF_TQ_SPREAD
+  // the next group's operand requests spread over the four quarters of this group's MFMAs (weights first: the longer
+  // latency) instead of all in front of it: the wave's own request burst no longer sits between two MFMA blocks
+  auto grp = [&](const f32x4 (&ac)[NRT], const f32x4 (&bc)[NCT], f32x4 (&an)[NRT], f32x4 (&bn)[NCT], int gn)
+      __attribute__((always_inline)) {
+    const f32x4* bq = bptr + (size_t)gn * bstride;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      if (jj == 0) bn[0] = bq[0];
+      if (jj == 1 && NCT > 1) bn[NCT - 1] = bq[(NCT - 1) * 64];
+      if (jj == 2) an[0] = *reinterpret_cast<const f32x4*>(arow + gn * 8);
+      if (jj == 3 && NRT > 1) an[NRT - 1] = *reinterpret_cast<const f32x4*>(arow + (NRT - 1) * 32 * CH_LD + gn * 8);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(bc[j][jj], ac[i][jj], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#pragma unroll 1
+  for (int g = 0; g < G - 2; g += 2) {
+    grp(a0, b0, a1, b1, g + 1);
+    grp(a1, b1, a0, b0, g + 2);
+  }
+#else
 #pragma unroll 1
   for (int g = 0; g < G - 2; g += 2) {
     {
@@ -556,6 +585,7 @@ __device__ __forceinline__ void tq_mma(const float* __restrict__ arow, const f32
         for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(b1[j][jj], a1[i][jj], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
   {
     const f32x4* bq = bptr + (size_t)(G - 1) * bstride;
 #pragma unroll
@@ -618,10 +648,30 @@ __device__ __forceinline__ void tq_mma_ring(const float* __restrict__ arow, cons
   for (; g + D <= G; g += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
+#if NUDF_TQ_SPREAD
+      const int nx = (d + D - 1) % D;
+      int gn = g + d + D - 1;
+      gn = (gn < glast) ? gn : glast;
+      const f32x4* bq = bptr + (size_t)gn * bstride;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        if (jj == 0) b[nx][0] = bq[0];
+        if (jj == 1 && NCT > 1) b[nx][NCT - 1] = bq[(NCT - 1) * 64];
+        if (jj == 2) a[nx][0] = *reinterpret_cast<const f32x4*>(arow + gn * 8);
+        if (jj == 3 && NRT > 1) a[nx][NRT - 1] = *reinterpret_cast<const f32x4*>(arow + (NRT - 1) * 32 * CH_LD + gn * 8);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+          for (int j = 0; j < NCT; ++j) acc[i][j] = ch_mfma(b[d][j][jj], a[d][i][jj], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       load(a[(d + D - 1) % D], b[(d + D - 1) % D], g + d + D - 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(a[d], b[d]);
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
   const int rem = G - g;
