@@ -1,13 +1,14 @@
 #!/bin/bash
 # A/B at the config-5 shape (1024 x 256, 16-bit mode) between the shipping library and variant builds of it:
 #   scripts/build_variants.sh <tag> <source.hip> -D<SWITCH>=<value>      (e.g. noring mlp_chain.hip -DNUDF_MMA16_RING=0)
-#   VARIANTS="<tag> ..." scripts/gpurun.sh scripts/gpu_r3l.sh
+#   echo "<tag> ..." > neuraludf_amd/build/ab_variants.txt; scripts/gpurun.sh scripts/gpu_r3l.sh     (the box sees files, not the caller's environment)
 # (used for profiles/r03_chain_experiments.txt items 7-9: NUDF_SEQ16, NUDF_MMA16_RING, the removed packed-pair algebra)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3l
 mkdir -p $O
 B=$GRAFT_REPO_ROOT/neuraludf_amd/build
+VARIANTS=${VARIANTS:-$(cat $B/ab_variants.txt 2>/dev/null)}
 timeout 600 python -m pytest tests/test_gpu_mixed16.py "tests/test_gpu_fullsize_parity.py::test_mixed16_at_cfg5_shape_vs_reference" "tests/test_gpu_fullsize_parity.py::test_mixed16_vs_oracle_psnr_hierarchical" -q -s > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
 grep -E "passed|failed" $O/pytest.log | tail -n 2
