@@ -552,21 +552,32 @@ int nudf_l1_sum_bwd(const float* pred, const float* gt, int n, const float* d_ou
 int nudf_sums_errors_fwd(const float* sums, float n_rays, float* err, void* stream);
 int nudf_sums_errors_bwd(const float* sums, float n_rays, const float* d_err, float* d_sums, void* stream);
 
+/* Loss weights in device memory.  The runner's schedules move the colour weights and the regulariser weights from
+ * iteration to iteration (adjust_color_loss_weights, exp_runner_blending.py:230-251; regularization_weights_schedule,
+ * :199-211), and a step captured in a HIP graph replays the kernel ARGUMENTS of its capture: every loss entry point
+ * below therefore takes `w_dev`, NULL or a device vector of NUDF_LW_COUNT floats laid out by the NUDF_LW_* indices,
+ * whose entries override the by-value weights of the same call. */
+enum { NUDF_LW_COLOR_BASE = 0, NUDF_LW_COLOR = 1, NUDF_LW_COLOR_PIXEL = 2, NUDF_LW_COLOR_PATCH = 3, NUDF_LW_IGR = 4,
+       NUDF_LW_IGR_NS = 5, NUDF_LW_SPARSE = 6, NUDF_LW_MASK = 7,
+       NUDF_LW_COLOR_SUM = 8,      /* color_base + color + color_pixel formed by the host in double (the host-side mirror's
+                                      torch expressions divide by it; the kernels form the sum themselves in fp32) */
+       NUDF_LW_COUNT = 16 };
+
 /* ColorLoss in one launch when only the two L1 terms are active (loss/loss.py:105-133 with color_pixel = None,
  * patch_colors = None):  den = mask ? sum(mask) + 1e-4 : n ;  Lb = sum|cb - gt| / den ;  Lc = sum|c - gt| / den ;
  * out[3] = {(Lb w_b + Lc w_c) / (w_b + w_c + w_px), Lb, Lc}.
  * bwd: d_cb / d_c from the upstream gradients d_out[3] (any of which may be zero). */
 int nudf_color_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
-                        float w_b, float w_c, float w_px, float* out, float* den_out, void* stream);
+                        float w_b, float w_c, float w_px, const float* w_dev, float* out, float* den_out, void* stream);
 int nudf_color_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, float w_b, float w_c,
-                        float w_px, const float* d_out, float* d_cb, float* d_c, void* stream);
+                        float w_px, const float* w_dev, const float* d_out, float* d_cb, float* d_c, void* stream);
 /* the same loss split at the ray-sharding exchange step (one process per GPU): local sums[3] = {sum|cb - gt|,
  * sum|c - gt|, sum(mask) or n} -> the caller all-reduces them (RCCL) -> finish forms out[3] / den exactly as above;
  * nudf_color_loss_bwd then runs on the local rays with the GLOBAL den. */
 int nudf_color_loss_sums(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
                          float* sums, void* stream);
-int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px, float* out, float* den_out,
-                           void* stream);
+int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px, const float* w_dev,
+                           float* out, float* den_out, void* stream);
 
 /* The whole loss assembly of a train step when only the two L1 colour terms and the three regularisers are active
  * (exp_runner_blending.py:330-371; loss/loss.py:105-133; udf_renderer_blending.py:531-536, 553): nudf_color_loss_fwd +
@@ -576,10 +587,11 @@ int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c
  * outputs (indexed like out[], NULL = none) -> d_cb / d_c [n] and d_sums[5]. */
 int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
                        const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns,
-                       float w_sparse, float* out, float* den_out, void* stream);
+                       float w_sparse, const float* w_dev, float* out, float* den_out, void* stream);
 int nudf_step_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, const float* sums,
                        float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns, float w_sparse,
-                       const float* d_total, const float* d_extra, float* d_cb, float* d_c, float* d_sums, void* stream);
+                       const float* w_dev, const float* d_total, const float* d_extra, float* d_cb, float* d_c, float* d_sums,
+                       void* stream);
 /* out4 [P_pad, 4] (16-byte aligned): column 0 = sign[r] * d[r] * scale (d NULL: sign[r] * scale) for r < P, everything
  * else zero: the 4-wide column-0 operand of the UDF head's adjoint and second-order weight gradient (fields.py:184-231) */
 int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4, void* stream);

@@ -175,6 +175,10 @@ class UnpackMulti(C.Structure):
     _fields_ = [("n_layers", i32), ("total_rows", i32), ("layer", UnpackLayer * PACK_MAX_LAYERS)]
 
 
+# float offsets of the device loss-weight vector (include/nudf.h NUDF_LW_*)
+LW = dict(color_base=0, color=1, color_pixel=2, color_patch=3, igr=4, igr_ns=5, sparse=6, mask=7, color_sum=8)
+LW_COUNT = 16
+
 EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMOID=7, UDFHEAD=8,
            SKIPSPLIT=9, RELU_DUAL=10, ADDMASK=11, MULSP=12)
 
@@ -242,13 +246,13 @@ _ARGTYPES = {
     "nudf_l1_sum_bwd": [_P, _P, _I, _P, _P, _P],
     "nudf_sums_errors_fwd": [_P, _F, _P, _P],
     "nudf_sums_errors_bwd": [_P, _F, _P, _P, _P],
-    "nudf_color_loss_fwd": [_P, _P, _P, _I, _P, _I, _F, _F, _F, _P, _P, _P],
-    "nudf_color_loss_bwd": [_P, _P, _P, _I, _P, _F, _F, _F, _P, _P, _P, _P],
+    "nudf_color_loss_fwd": [_P, _P, _P, _I, _P, _I, _F, _F, _F, _P, _P, _P, _P],
+    "nudf_color_loss_bwd": [_P, _P, _P, _I, _P, _F, _F, _F, _P, _P, _P, _P, _P],
     "nudf_gen_ray_batch": [C.POINTER(RayBatch), _P],
     "nudf_color_loss_sums": [_P, _P, _P, _I, _P, _I, _P, _P],
-    "nudf_color_loss_finish": [_P, _I, _F, _F, _F, _P, _P, _P],
-    "nudf_step_loss_fwd": [_P, _P, _P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P],
-    "nudf_step_loss_bwd": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "nudf_color_loss_finish": [_P, _I, _F, _F, _F, _P, _P, _P, _P],
+    "nudf_step_loss_fwd": [_P, _P, _P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "nudf_step_loss_bwd": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "nudf_col0_seed4": [_P, _P, _F, _I, _I, _P, _P],
 }
 

@@ -34,6 +34,18 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _obj_stale(obj: str, dep: str, flags: str) -> bool:
+    """an object is reused when it is newer than every file its depfile (-MD) lists and was built with the same flags"""
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(obj + ".flags")):
+        return True
+    if open(obj + ".flags").read() != flags:
+        return True
+    t = os.path.getmtime(obj)
+    txt = open(dep).read().replace("\\\n", " ")
+    files = txt.split(":", 1)[1].split() if ":" in txt else []
+    return any((not os.path.exists(f)) or os.path.getmtime(f) > t for f in files)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
@@ -44,9 +56,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
+        d = o + ".d"
         objs.append(o)
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
-               "-I", CSRC, "-I", INCLUDE, "-Wno-unused-result"]
+               "-I", CSRC, "-I", INCLUDE, "-Wno-unused-result"] + os.environ.get("NUDF_HIPCC_FLAGS", "").split()
+        flags = " ".join(cmd)
+        if not force and not _obj_stale(o, d, flags):
+            continue
+        with open(o + ".flags", "w") as f:
+            f.write(flags)
+        cmd += ["-MD", "-MF", d]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, pr in procs:
         out, _ = pr.communicate()

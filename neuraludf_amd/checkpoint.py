@@ -59,10 +59,20 @@ def _load_ckpt(path, map_location, allow_pickle):
                  if hasattr(_dt, n)]
     except ImportError:
         pass
+    import pickle
+    if not os.path.exists(path):                    # a missing file is a missing file, not an unsafe pickle
+        raise FileNotFoundError(path)
+    if hasattr(torch.serialization, "safe_globals"):
+        ctx = torch.serialization.safe_globals(safe)
+    else:                                           # older torch: process-wide allow-list instead of a scoped one
+        import contextlib
+        torch.serialization.add_safe_globals(safe)
+        ctx = contextlib.nullcontext()
     try:
-        with torch.serialization.safe_globals(safe):
+        with ctx:
             return torch.load(path, map_location=map_location, weights_only=True)
-    except Exception as e:          # pickle.UnpicklingError and friends: something beyond tensors + numpy scalars
+    except pickle.UnpicklingError as e:     # the weights-only unpickler met something beyond tensors + numpy scalars;
+        # OSError, EOFError, zip / storage errors of a corrupt file propagate unchanged
         if allow_pickle or os.environ.get("NUDF_CKPT_ALLOW_PICKLE", "0") == "1":
             return torch.load(path, map_location=map_location, weights_only=False)
         raise RuntimeError("checkpoint %s holds objects beyond tensors and numpy scalars (%s); pass allow_pickle=True (or "

@@ -617,12 +617,24 @@ extern "C" int nudf_sums_errors_bwd(const float* sums, float n_rays, const float
   return 0;
 }
 
+// Loss weights from device memory (include/nudf.h NUDF_LW_*): a graph-captured step replays the kernel ARGUMENTS of
+// its capture, so the weights the runner's schedules move every iteration (adjust_color_loss_weights,
+// regularization_weights_schedule: exp_runner_blending.py:199-211, 230-251) are read from a device vector when one is
+// given and override the by-value floats.  Uniform scalar loads, once per kernel.
+#define NUDF_LOSS_WEIGHTS3(w_dev, w_b, w_c, w_px)                                                  \
+  if (w_dev) { w_b = (w_dev)[NUDF_LW_COLOR_BASE]; w_c = (w_dev)[NUDF_LW_COLOR]; w_px = (w_dev)[NUDF_LW_COLOR_PIXEL]; }
+#define NUDF_LOSS_WEIGHTS6(w_dev, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse)                         \
+  NUDF_LOSS_WEIGHTS3(w_dev, w_b, w_c, w_px)                                                         \
+  if (w_dev) { w_igr = (w_dev)[NUDF_LW_IGR]; w_igr_ns = (w_dev)[NUDF_LW_IGR_NS]; w_sparse = (w_dev)[NUDF_LW_SPARSE]; }
+
 // ColorLoss (two L1 terms) in one workgroup: the inputs are [N,3] per-ray tensors
 __global__ __launch_bounds__(1024) void color_loss_fwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
                                                               const float* __restrict__ gt, int n,
                                                               const float* __restrict__ mask, int n_mask, float w_b,
-                                                              float w_c, float w_px, float* out, float* den_out) {
+                                                              float w_c, float w_px, const float* __restrict__ w_dev,
+                                                              float* out, float* den_out) {
   __shared__ float red[3][16];
+  NUDF_LOSS_WEIGHTS3(w_dev, w_b, w_c, w_px);
   float sb = 0.f, sc = 0.f, sm = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const float g = gt[i];
@@ -648,9 +660,10 @@ __global__ __launch_bounds__(1024) void color_loss_fwd_kernel(const float* __res
   }
 }
 extern "C" int nudf_color_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
-                                   float w_b, float w_c, float w_px, float* out, float* den_out, void* stream) {
+                                   float w_b, float w_c, float w_px, const float* w_dev, float* out, float* den_out,
+                                   void* stream) {
   hipLaunchKernelGGL(color_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, w_b,
-                     w_c, w_px, out, den_out);
+                     w_c, w_px, w_dev, out, den_out);
   NUDF_CHECK_LAUNCH("nudf_color_loss_fwd");
   return 0;
 }
@@ -686,7 +699,8 @@ extern "C" int nudf_color_loss_sums(const float* cb, const float* c, const float
   return 0;
 }
 __global__ void color_loss_finish_kernel(const float* __restrict__ sums, int has_mask, float w_b, float w_c, float w_px,
-                                         float* out, float* den_out) {
+                                         const float* __restrict__ w_dev, float* out, float* den_out) {
+  NUDF_LOSS_WEIGHTS3(w_dev, w_b, w_c, w_px);
   const float den = has_mask ? (sums[2] + 1e-4f) : sums[2];
   const float Lb = sums[0] / den, Lc = sums[1] / den;
   out[0] = (Lb * w_b + Lc * w_c) / (w_b + w_c + w_px);
@@ -694,18 +708,20 @@ __global__ void color_loss_finish_kernel(const float* __restrict__ sums, int has
   out[2] = Lc;
   den_out[0] = den;
 }
-extern "C" int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px, float* out,
-                                      float* den_out, void* stream) {
+extern "C" int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c, float w_px,
+                                      const float* w_dev, float* out, float* den_out, void* stream) {
   hipLaunchKernelGGL(color_loss_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums, has_mask, w_b, w_c, w_px,
-                     out, den_out);
+                     w_dev, out, den_out);
   NUDF_CHECK_LAUNCH("nudf_color_loss_finish");
   return 0;
 }
 __global__ void color_loss_bwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
                                       const float* __restrict__ gt, int n, const float* den, float w_b, float w_c,
-                                      float w_px, const float* d_out, float* __restrict__ d_cb, float* __restrict__ d_c) {
+                                      float w_px, const float* __restrict__ w_dev, const float* d_out,
+                                      float* __restrict__ d_cb, float* __restrict__ d_c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  NUDF_LOSS_WEIGHTS3(w_dev, w_b, w_c, w_px);
   const float W = w_b + w_c + w_px;
   const float kb = (d_out[0] * w_b / W + d_out[1]) / den[0];
   const float kc = (d_out[0] * w_c / W + d_out[2]) / den[0];
@@ -715,10 +731,11 @@ __global__ void color_loss_bwd_kernel(const float* __restrict__ cb, const float*
   d_c[i] = kc * ((b > 0.f) ? 1.f : ((b < 0.f) ? -1.f : 0.f));
 }
 extern "C" int nudf_color_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, float w_b,
-                                   float w_c, float w_px, const float* d_out, float* d_cb, float* d_c, void* stream) {
+                                   float w_c, float w_px, const float* w_dev, const float* d_out, float* d_cb, float* d_c,
+                                   void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(color_loss_bwd_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, cb, c, gt, n, den,
-                     w_b, w_c, w_px, d_out, d_cb, d_c);
+                     w_b, w_c, w_px, w_dev, d_out, d_cb, d_c);
   NUDF_CHECK_LAUNCH("nudf_color_loss_bwd");
   return 0;
 }
@@ -738,8 +755,10 @@ __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __rest
                                                              const float* __restrict__ mask, int n_mask,
                                                              const float* __restrict__ sums, float n_rays, float w_b,
                                                              float w_c, float w_px, float w_igr, float w_igr_ns,
-                                                             float w_sparse, float* out, float* den_out) {
+                                                             float w_sparse, const float* __restrict__ w_dev, float* out,
+                                                             float* den_out) {
   __shared__ float red[3][16];
+  NUDF_LOSS_WEIGHTS6(w_dev, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse);
   float sb = 0.f, sc = 0.f, sm = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const float g = gt[i];
@@ -771,9 +790,10 @@ __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __rest
 }
 extern "C" int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
                                   const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr,
-                                  float w_igr_ns, float w_sparse, float* out, float* den_out, void* stream) {
+                                  float w_igr_ns, float w_sparse, const float* w_dev, float* out, float* den_out,
+                                  void* stream) {
   hipLaunchKernelGGL(step_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, sums,
-                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, out, den_out);
+                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, w_dev, out, den_out);
   NUDF_CHECK_LAUNCH("nudf_step_loss_fwd");
   return 0;
 }
@@ -782,10 +802,11 @@ extern "C" int nudf_step_loss_fwd(const float* cb, const float* c, const float* 
 __global__ void step_loss_bwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
                                      const float* __restrict__ gt, int n, const float* __restrict__ den,
                                      const float* __restrict__ sums, float n_rays, float w_b, float w_c, float w_px,
-                                     float w_igr, float w_igr_ns, float w_sparse, const float* __restrict__ d_total,
-                                     const float* __restrict__ d_extra, float* __restrict__ d_cb, float* __restrict__ d_c,
-                                     float* __restrict__ d_sums) {
+                                     float w_igr, float w_igr_ns, float w_sparse, const float* __restrict__ w_dev,
+                                     const float* __restrict__ d_total, const float* __restrict__ d_extra,
+                                     float* __restrict__ d_cb, float* __restrict__ d_c, float* __restrict__ d_sums) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  NUDF_LOSS_WEIGHTS6(w_dev, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse);
   const float g = d_total ? d_total[0] : 1.0f;
   const float g_cl = g + (d_extra ? d_extra[1] : 0.0f);
   if (i == 0) {
@@ -810,10 +831,11 @@ __global__ void step_loss_bwd_kernel(const float* __restrict__ cb, const float* 
 }
 extern "C" int nudf_step_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den,
                                   const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr,
-                                  float w_igr_ns, float w_sparse, const float* d_total, const float* d_extra, float* d_cb,
-                                  float* d_c, float* d_sums, void* stream) {
+                                  float w_igr_ns, float w_sparse, const float* w_dev, const float* d_total,
+                                  const float* d_extra, float* d_cb, float* d_c, float* d_sums, void* stream) {
   hipLaunchKernelGGL(step_loss_bwd_kernel, dim3(nblocks(max(n, 1), 256)), dim3(256), 0, (hipStream_t)stream, cb, c, gt, n,
-                     den, sums, n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, d_total, d_extra, d_cb, d_c, d_sums);
+                     den, sums, n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, w_dev, d_total, d_extra, d_cb, d_c,
+                     d_sums);
   NUDF_CHECK_LAUNCH("nudf_step_loss_bwd");
   return 0;
 }

@@ -8,7 +8,59 @@ import torch
 import torch.nn as nn
 
 from .. import dist as nudf_dist
+from .._lib import LW, LW_COUNT
 from .patch_metric import PATCH_TYPES, patch_error
+
+
+class LossWeights:
+    """The loss / regulariser weights of a train step (include/nudf.h NUDF_LW_*) as host floats plus a device mirror.
+
+    The runner's schedules move them from iteration to iteration (adjust_color_loss_weights,
+    regularization_weights_schedule: exp_runner_blending.py:199-211, 230-251), and a HIP-graph replay repeats the kernel
+    ARGUMENTS of its capture -- so every consumer (the fused loss kernels through `w_dev`, the torch expressions of the
+    generic path through 0-d views of the same vector) reads them from device memory, eager and replayed steps alike:
+    the two stay bit-identical and a moving weight needs no new capture.  Eager steps refresh the mirror themselves when
+    a value changed (`device()`); a captured step is bound to a slot of the trainer's per-step scalar upload
+    (`bind()`, train.StepScalars) for the duration of the capture."""
+
+    def __init__(self, **kw):
+        self.host = [0.0] * LW_COUNT
+        self._own = None            # this object's own device vector (eager steps)
+        self._own_vals = None       # what it holds
+        self._bound = None          # a caller-owned device vector whose contents the caller keeps current (graph capture)
+        self.set(**kw)
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            self.host[LW[k]] = float(v)
+
+    def get(self, name):
+        return self.host[LW[name]]
+
+    def values(self):
+        """the device layout as python floats; the colour denominator is formed in double like the reference's
+        `(color_base_weight + color_weight + color_pixel_weight)` (loss/loss.py:127-128) and rounded once."""
+        v = list(self.host)
+        v[LW["color_sum"]] = v[LW["color_base"]] + v[LW["color"]] + v[LW["color_pixel"]]
+        return v
+
+    def bind(self, dev_vector):
+        self._bound = dev_vector
+
+    def unbind(self):
+        self._bound = None
+
+    def device(self, device):
+        """-> device float vector [LW_COUNT] holding `values()`."""
+        if self._bound is not None:
+            return self._bound
+        vals = self.values()
+        if self._own is None or self._own.device != torch.device(device):
+            self._own, self._own_vals = torch.empty(LW_COUNT, device=device), None
+        if vals != self._own_vals:
+            self._own.copy_(torch.tensor(vals, dtype=torch.float32))
+            self._own_vals = vals
+        return self._own
 
 
 class _L1SumFn(torch.autograd.Function):
@@ -37,9 +89,10 @@ class _ColorLossFn(torch.autograd.Function):
     weighting in one launch each way (the generic path costs ~12 + ~15 one-element launches)."""
 
     @staticmethod
-    def forward(ctx, cb, c, gt, mask, w_b, w_c, w_px, data_parallel=False):
+    def forward(ctx, cb, c, gt, mask, w_dev, data_parallel=False):
         from .._lib import call, ptr
         ctx.set_materialize_grads(False)
+        w_dev = w_dev.detach()
         cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
         m_ = mask.detach().float().contiguous() if mask is not None else None
         out = torch.empty(3, device=cb_.device)
@@ -52,27 +105,26 @@ class _ColorLossFn(torch.autograd.Function):
             call("nudf_color_loss_sums", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_),
                  m_.numel() if m_ is not None else 0, ptr(sums))
             dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-            call("nudf_color_loss_finish", ptr(sums), 1 if m_ is not None else 0, float(w_b), float(w_c), float(w_px),
-                 ptr(out), ptr(den))
+            call("nudf_color_loss_finish", ptr(sums), 1 if m_ is not None else 0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(out),
+                 ptr(den))
         else:
             call("nudf_color_loss_fwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_),
-                 m_.numel() if m_ is not None else 0, float(w_b), float(w_c), float(w_px), ptr(out), ptr(den))
-        ctx.save_for_backward(cb_, c_, gt_, den)
-        ctx.w = (float(w_b), float(w_c), float(w_px))
+                 m_.numel() if m_ is not None else 0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(out), ptr(den))
+        ctx.save_for_backward(cb_, c_, gt_, den, w_dev)
         return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, d0, d1, d2):
         from .._lib import call, ptr
-        cb_, c_, gt_, den = ctx.saved_tensors
+        cb_, c_, gt_, den, w_dev = ctx.saved_tensors
         if d0 is None and d1 is None and d2 is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None
         z = den.new_zeros(())
         d_out = torch.stack([d if d is not None else z for d in (d0, d1, d2)])
         d_cb, d_c = torch.empty_like(cb_), torch.empty_like(c_)
-        call("nudf_color_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), *ctx.w, ptr(d_out), ptr(d_cb),
-             ptr(d_c))
-        return d_cb, d_c, None, None, None, None, None, None
+        call("nudf_color_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), 0.0, 0.0, 0.0, ptr(w_dev),
+             ptr(d_out), ptr(d_cb), ptr(d_c))
+        return d_cb, d_c, None, None, None, None
 
 
 class _StepLossFn(torch.autograd.Function):
@@ -82,27 +134,27 @@ class _StepLossFn(torch.autograd.Function):
     launches.  Same values as the unfused chain (same reductions, every product / sum of the total rounded on its own)."""
 
     @staticmethod
-    def forward(ctx, cb, c, gt, mask, sums, n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse):
+    def forward(ctx, cb, c, gt, mask, sums, n_rays, w_dev):
         from .._lib import call, ptr
         ctx.set_materialize_grads(False)
+        w_dev = w_dev.detach()
         cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
         m_ = mask.detach().float().contiguous() if mask is not None else None
         sums_ = sums.detach().contiguous()
         out = torch.empty(8, device=cb_.device)
         den = torch.empty(1, device=cb_.device)
-        w = tuple(float(x) for x in (w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse))
         call("nudf_step_loss_fwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_), m_.numel() if m_ is not None else 0,
-             ptr(sums_), float(n_rays), *w, ptr(out), ptr(den))
-        ctx.save_for_backward(cb_, c_, gt_, den, sums_)
-        ctx.w, ctx.n_rays = w, float(n_rays)
+             ptr(sums_), float(n_rays), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(out), ptr(den))
+        ctx.save_for_backward(cb_, c_, gt_, den, sums_, w_dev)
+        ctx.n_rays = float(n_rays)
         return tuple(out[i] for i in range(7))
 
     @staticmethod
     def backward(ctx, *d):
         from .._lib import call, ptr
         if all(x is None for x in d):
-            return (None,) * 12
-        cb_, c_, gt_, den, sums_ = ctx.saved_tensors
+            return (None,) * 7
+        cb_, c_, gt_, den, sums_, w_dev = ctx.saved_tensors
         d_total = d[0].contiguous() if d[0] is not None else None      # autograd's own tensor: no extra launch
         d_extra = None
         if any(x is not None for x in d[1:]) or d_total is None:      # gradients into the logged terms: rare
@@ -112,9 +164,9 @@ class _StepLossFn(torch.autograd.Function):
                 d_total = z
         d_cb, d_c = torch.empty_like(cb_), torch.empty_like(c_)
         d_sums = torch.empty(5, device=cb_.device)
-        call("nudf_step_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), ptr(sums_), ctx.n_rays, *ctx.w,
-             ptr(d_total), ptr(d_extra), ptr(d_cb), ptr(d_c), ptr(d_sums))
-        return (d_cb, d_c, None, None, d_sums) + (None,) * 7
+        call("nudf_step_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), ptr(sums_), ctx.n_rays,
+             0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(d_total), ptr(d_extra), ptr(d_cb), ptr(d_c), ptr(d_sums))
+        return (d_cb, d_c, None, None, d_sums, None, None)
 
 
 class _ColorLossFromSumsFn(torch.autograd.Function):
@@ -123,30 +175,30 @@ class _ColorLossFromSumsFn(torch.autograd.Function):
     differentiates the global loss w.r.t. the LOCAL rays (global denominator), one launch."""
 
     @staticmethod
-    def forward(ctx, cb, c, gt, sums, has_mask, w_b, w_c, w_px):
+    def forward(ctx, cb, c, gt, sums, has_mask, w_dev):
         from .._lib import call, ptr
         ctx.set_materialize_grads(False)
+        w_dev = w_dev.detach()
         cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
         out = torch.empty(3, device=cb_.device)
         den = torch.empty(1, device=cb_.device)
-        call("nudf_color_loss_finish", ptr(sums.detach().contiguous()), 1 if has_mask else 0, float(w_b), float(w_c),
-             float(w_px), ptr(out), ptr(den))
-        ctx.save_for_backward(cb_, c_, gt_, den)
-        ctx.w = (float(w_b), float(w_c), float(w_px))
+        call("nudf_color_loss_finish", ptr(sums.detach().contiguous()), 1 if has_mask else 0, 0.0, 0.0, 0.0, ptr(w_dev),
+             ptr(out), ptr(den))
+        ctx.save_for_backward(cb_, c_, gt_, den, w_dev)
         return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, d0, d1, d2):
         from .._lib import call, ptr
-        cb_, c_, gt_, den = ctx.saved_tensors
+        cb_, c_, gt_, den, w_dev = ctx.saved_tensors
         if d0 is None and d1 is None and d2 is None:
-            return (None,) * 8
+            return (None,) * 6
         z = den.new_zeros(())
         d_out = torch.stack([d if d is not None else z for d in (d0, d1, d2)])
         d_cb, d_c = torch.empty_like(cb_), torch.empty_like(c_)
-        call("nudf_color_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), *ctx.w, ptr(d_out), ptr(d_cb),
-             ptr(d_c))
-        return d_cb, d_c, None, None, None, None, None, None
+        call("nudf_color_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), 0.0, 0.0, 0.0, ptr(w_dev),
+             ptr(d_out), ptr(d_cb), ptr(d_c))
+        return d_cb, d_c, None, None, None, None
 
 
 def _l1_sum(pred, gt):
@@ -228,10 +280,10 @@ class ColorLoss(nn.Module):
     def __init__(self, color_base_weight, color_weight, color_pixel_weight, color_patch_weight,
                  pixel_loss_type='l1', patch_loss_type='ssim', h_patch_size=3):
         super().__init__()
-        self.color_base_weight = color_base_weight
-        self.color_weight = color_weight
-        self.color_pixel_weight = color_pixel_weight
-        self.color_patch_weight = color_patch_weight
+        # the four weights live in `self.weights` (host floats + a device mirror every consumer reads, see LossWeights);
+        # the reference's attribute names stay readable / assignable (properties below)
+        self.weights = LossWeights(color_base=color_base_weight, color=color_weight, color_pixel=color_pixel_weight,
+                                   color_patch=color_patch_weight)
         self.pixel_func = ColorPixelLoss(pixel_loss_type)
         self.patch_func = ColorPatchLoss(patch_loss_type, h_patch_size)
         self.h_patch_size = h_patch_size
@@ -241,10 +293,16 @@ class ColorLoss(nn.Module):
         self.patch_func.data_parallel = flag
 
     def set_color_weights(self, color_base_weight, color_weight, color_pixel_weight, color_patch_weight):
-        self.color_base_weight = color_base_weight
-        self.color_weight = color_weight
-        self.color_pixel_weight = color_pixel_weight
-        self.color_patch_weight = color_patch_weight
+        self.weights.set(color_base=color_base_weight, color=color_weight, color_pixel=color_pixel_weight,
+                         color_patch=color_patch_weight)
+
+    color_base_weight = property(lambda self: self.weights.get("color_base"),
+                                 lambda self, v: self.weights.set(color_base=v))
+    color_weight = property(lambda self: self.weights.get("color"), lambda self, v: self.weights.set(color=v))
+    color_pixel_weight = property(lambda self: self.weights.get("color_pixel"),
+                                  lambda self, v: self.weights.set(color_pixel=v))
+    color_patch_weight = property(lambda self: self.weights.get("color_patch"),
+                                  lambda self, v: self.weights.set(color_patch=v))
 
     # ---- ray-sharded two-phase form: the caller packs `local_sums` with its other batch-global partial sums into ONE
     # all-reduce (dist.py (1)) and hands the global values to `from_global_sums` -----------------------------------
@@ -264,16 +322,15 @@ class ColorLoss(nn.Module):
 
     def from_global_sums(self, color_base, color, gt_color, pixel_mask, sums):
         total, lb, lc = _ColorLossFromSumsFn.apply(color_base, color, gt_color, sums, pixel_mask is not None,
-                                                   self.color_base_weight, self.color_weight, self.color_pixel_weight)
+                                                   self.weights.device(color.device))
         return {'loss': total, 'color_base_loss': lb, 'color_loss': lc, 'color_pixel_loss': 0.0, 'color_patch_loss': 0.0}
 
     def forward(self, color_base, color, gt_color, color_pixel, pixel_mask, patch_colors, gt_patch_colors, patch_mask):
         if (color_base is not None and color is not None and color_pixel is None and patch_colors is None
                 and color.is_cuda and color.dtype == torch.float32
                 and color.shape == gt_color.shape == color_base.shape):
-            total, lb, lc = _ColorLossFn.apply(color_base, color, gt_color, pixel_mask, self.color_base_weight,
-                                               self.color_weight, self.color_pixel_weight,
-                                               self.pixel_func.data_parallel)
+            total, lb, lc = _ColorLossFn.apply(color_base, color, gt_color, pixel_mask,
+                                               self.weights.device(color.device), self.pixel_func.data_parallel)
             return {'loss': total, 'color_base_loss': lb, 'color_loss': lc, 'color_pixel_loss': 0.0,
                     'color_patch_loss': 0.0}
         color_base_loss = color_loss = color_pixel_loss = color_patch_loss = 0.0
@@ -285,9 +342,12 @@ class ColorLoss(nn.Module):
             color_pixel_loss = self.pixel_func(color_pixel, gt_color, patch_mask)
         if patch_colors is not None:
             color_patch_loss = self.patch_func(patch_colors, gt_patch_colors, patch_mask)
-        total_loss = (color_base_loss * self.color_base_weight + color_loss * self.color_weight
-                      + color_pixel_loss * self.color_pixel_weight) / (
-                self.color_base_weight + self.color_weight + self.color_pixel_weight) \
-            + color_patch_loss * self.color_patch_weight
+        # (loss/loss.py:125-129) with the weights as 0-d views of the device vector: the same expression runs eagerly and
+        # inside a captured step, and follows the schedules on replay
+        dev = next((t.device for t in (color_base, color, color_pixel, patch_colors) if t is not None), None)
+        w = self.weights.device(dev) if dev is not None and dev.type == "cuda" else self.weights.values()
+        total_loss = (color_base_loss * w[LW["color_base"]] + color_loss * w[LW["color"]]
+                      + color_pixel_loss * w[LW["color_pixel"]]) / w[LW["color_sum"]] \
+            + color_patch_loss * w[LW["color_patch"]]
         return {'loss': total_loss, 'color_base_loss': color_base_loss, 'color_loss': color_loss,
                 'color_pixel_loss': color_pixel_loss, 'color_patch_loss': color_patch_loss}

@@ -395,7 +395,9 @@ class UDFRendererBlending:
                  flip_saturation=flip_saturation, use_norm_grad=self.use_norm_grad_for_cosine,
                  sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics,
                  alpha_type=1 if self.sdf2alpha_type == 'theorical' else 0,
-                 sched=getattr(self, "sched_scalars", None) if cos_anneal_ratio is not None else None)
+                 # device {cos_anneal_ratio, flip_saturation} of a graph-captured step: passed whenever it is set -- with
+                 # cos_anneal_ratio = None the kernel still takes flip_saturation from it (has_anneal stays by value)
+                 sched=getattr(self, "sched_scalars", None))
         outs = _CompositeFn.apply(c, rays_o, rays_d, z_vals, sample_dist, background_rgb, udf.reshape(N, S),
                                   grad.reshape(N, S, 3), col.reshape(N, S, 3), cb.reshape(N, S, 3), bg_z, bg_sigma,
                                   bg_color, scal)

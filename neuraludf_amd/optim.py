@@ -29,6 +29,12 @@ class FusedAdam(torch.optim.Optimizer):
         # bias corrections).  None: they travel by value (eager steps).
         self.dyn_base = None
         self._order = []          # parameters of the last step() in launch order
+        self.state_epoch = 0      # bumped whenever the state tensors are replaced (load_state_dict): a captured step
+                                  # holds raw pointers to exp_avg / exp_avg_sq (train.GraphedStep drops its captures)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.state_epoch += 1
 
     def dyn_values(self):
         """{neg_step_size, bc2_sqrt} of the NEXT step for the parameters of the last step(), in launch order (the layout of

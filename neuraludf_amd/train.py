@@ -10,6 +10,7 @@ import io
 import torch
 
 from . import dist as nudf_dist
+from ._lib import LW, LW_COUNT
 from .loss.loss import ColorLoss
 from .models import fields
 from .models.udf_renderer_blending import UDFRendererBlending
@@ -33,27 +34,31 @@ DTU_MODEL_CONF = dict(
 
 
 class StepScalars:
-    """The handful of per-iteration numbers a graph-captured step reads from device memory -- {cos_anneal_ratio,
-    flip_saturation} for the composite kernels (NudfComposite.sched) and {neg_step_size, bc2_sqrt} per tensor for the
+    """The per-iteration numbers a graph-captured step reads from device memory -- {cos_anneal_ratio, flip_saturation}
+    for the composite kernels (NudfComposite.sched), the loss / regulariser weights (NUDF_LW_*: every loss kernel's
+    `w_dev` and the 0-d views the generic loss expressions multiply by) and {neg_step_size, bc2_sqrt} per tensor for the
     fused Adam (NudfAdam.dyn) -- in ONE device buffer, refreshed by ONE asynchronous H2D copy per step from a ring of
     pinned host slots (a slot is rewritten only after the copy that read it has completed, so the host may run several
-    steps ahead of the GPU)."""
-    SCHED, ADAM = 0, 8          # float offsets of the two regions
+    steps ahead of the GPU).  `n_adam` = optimizer tensors of the step the buffer is made for."""
+    SCHED, LOSSW, ADAM = 0, 8, 8 + LW_COUNT          # float offsets of the three regions
 
-    def __init__(self, device, n=8 + 2 * 96, slots=8):
+    def __init__(self, device, n_adam=96, slots=8):
+        n = self.ADAM + 2 * n_adam
+        self.n_adam = n_adam
         self.dev = torch.zeros(n, device=device)
         self.host = [torch.zeros(n).pin_memory() for _ in range(slots)]
         self.events = [None] * slots
         self.k = 0
 
-    def upload(self, sched, adam):
+    def upload(self, sched, lossw, adam):
         i = self.k % len(self.host)
         self.k += 1
         if self.events[i] is not None:
             self.events[i].synchronize()
         h = self.host[i].numpy()
         h[self.SCHED:self.SCHED + len(sched)] = sched
-        if len(adam) > h.shape[0] - self.ADAM:
+        h[self.LOSSW:self.LOSSW + len(lossw)] = lossw
+        if len(adam) > 2 * self.n_adam:
             raise ValueError("too many optimizer tensors for the step-scalar buffer")
         h[self.ADAM:self.ADAM + len(adam)] = adam
         self.dev.copy_(self.host[i], non_blocking=True)
@@ -67,29 +72,51 @@ class GraphedStep:
     3.5 ms per step) become one graph launch, so the host stays far ahead of the GPU and a host hiccup on one rank no
     longer stalls a collective.  Every libnudf entry point takes the stream and never synchronises, torch's fills / cats /
     random draws are graph-safe; what changes from iteration to iteration travels through device memory (StepScalars):
-    the learning rates and Adam's bias corrections, cos_anneal_ratio and flip_saturation.  Everything else that is a
-    kernel ARGUMENT -- tensor shapes, loss / regulariser weights, which networks take part -- is part of the capture key:
-    a new key runs `eager_steps` ordinary steps first (allocator and caches settle) and is captured on the next call.
-    Replays are bit-identical to eager steps (tests/test_gpu_graph.py).  Single process only: a data-parallel trainer
-    stays eager (its collectives have not been captured on hardware yet)."""
+    the learning rates and Adam's bias corrections, cos_anneal_ratio and flip_saturation, and every loss / regulariser
+    weight (the colour weights ramp over iterations 10 000-20 000 and the regulariser weights under
+    --reg_weights_schedule, exp_runner_blending.py:199-211, 230-251: a weight baked into the capture would be replayed
+    stale, a weight in the key would re-capture on every iteration of a ramp).  What is left of the capture key is what
+    changes the SEQUENCE of launches: tensor shapes, which loss terms are switched on at all (weight > 0), loss types,
+    which parameters train.  A new key runs `eager_steps` ordinary steps first (allocator and caches settle) and is
+    captured on the next call.  Replays are bit-identical to eager steps (tests/test_gpu_graph.py).  Single process only
+    by default: a data-parallel trainer stays eager unless `capture_collectives` (its two all-reduces capture on this
+    image, scripts/rccl_capture_probe.py, but have not been replayed on two GPUs yet).
 
-    def __init__(self, trainer, eager_steps=2, max_graphs=4):
+    The returned (loss, out) of a replayed call are the capture's STATIC tensors: the next replay overwrites them --
+    clone what is kept across iterations (logging lists).  A captured step holds raw pointers to the parameters, their
+    gradients and Adam's moments: `optimizer.load_state_dict` (FusedAdam bumps `state_epoch`) and `invalidate()` drop
+    the captures; parameters reloaded in place (`module.load_state_dict`) keep their storage and need nothing."""
+
+    def __init__(self, trainer, eager_steps=2, max_graphs=4, capture_collectives=False):
         from .optim import FusedAdam
         self.tr = trainer
         self.eager_steps = eager_steps
         self.max_graphs = max_graphs
         self.graphs = {}
-        self.enabled = isinstance(trainer.optimizer, FusedAdam) and not trainer.data_parallel
+        self.enabled = isinstance(trainer.optimizer, FusedAdam) and (capture_collectives or not trainer.data_parallel)
         self.scalars = None
         self.replays = 0
+        self.captures = 0
+        self._last = None
+        self._epoch = getattr(trainer.optimizer, "state_epoch", 0)
+
+    def invalidate(self):
+        """drop every captured step (their pointers into optimizer state / parameters / gradients may be stale); the next
+        calls run eagerly and re-capture."""
+        self.graphs.clear()
         self._last = None
 
     def _key(self, batch, blend, has_anneal, perturb_overwrite):
         tr = self.tr
         sig = lambda d: tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in d.items() if torch.is_tensor(v)))
         live = tuple(p.requires_grad for g in tr.param_groups for p in g)
-        return (sig(batch), sig(blend) if blend is not None else None, bool(has_anneal), perturb_overwrite,
-                tuple(sorted(tr.tc.items())), tuple(sorted((k, v) for k, v in tr.lc.items())), live)
+        # weights: only whether a term is on at all (that decides which kernels run); their VALUES travel through memory
+        cw = tr.color_loss
+        terms = (cw.color_pixel_weight > 0, cw.color_patch_weight > 0, tr.lc["color_pixel_weight"] > 0,
+                 tr.lc["color_patch_weight"] > 0, tr.tc["mask_weight"] > 0)
+        static = tuple(sorted((k, v) for k, v in tr.lc.items() if not k.endswith("_weight")))
+        return (sig(batch), sig(blend) if blend is not None else None, bool(has_anneal), perturb_overwrite, terms, static,
+                live)
 
     def __call__(self, batch, cos_anneal_ratio=1.0, flip_saturation=1.0, blend=None, perturb_overwrite=-1):
         tr = self.tr
@@ -97,6 +124,9 @@ class GraphedStep:
                   perturb_overwrite=perturb_overwrite)
         if not self.enabled:
             return tr.step(batch, **kw)
+        if getattr(tr.optimizer, "state_epoch", 0) != self._epoch:       # optimizer state reloaded: moments moved
+            self._epoch = tr.optimizer.state_epoch
+            self.invalidate()
         if (blend is not None and "ref_cam" not in blend and tr.lc["color_pixel_weight"] > 0
                 and tr.lc["color_patch_weight"] > 0):
             # the camera constants of the patch warp hold four small matrix inverses (a solver library: not capturable):
@@ -141,8 +171,8 @@ class GraphedStep:
                     v.copy_(src)
         tr.optimizer._order = ent["order"]       # the tensors of THIS capture's Adam launch (an eager step of another
                                                  # configuration in between may have left another list)
-        self.scalars.upload([0.0 if cos_anneal_ratio is None else float(cos_anneal_ratio), float(flip_saturation)],
-                            tr.optimizer.dyn_values())
+        ent["scalars"].upload([0.0 if cos_anneal_ratio is None else float(cos_anneal_ratio), float(flip_saturation)],
+                              tr.loss_weights().values(), tr.optimizer.dyn_values())
         ent["graph"].replay()
         tr.optimizer.advance()
         self.replays += 1
@@ -159,8 +189,12 @@ class GraphedStep:
     def _capture(self, ent, batch, blend, has_anneal, flip_saturation, perturb_overwrite):
         tr = self.tr
         dev = batch["rays_o"].device
-        if self.scalars is None:
-            self.scalars = StepScalars(dev)
+        n_adam = sum(len(g) for g in tr.param_groups)
+        if self.scalars is None or self.scalars.n_adam < n_adam:
+            # sized for every tensor the optimizer owns (an over-long launch order can then not overflow it); captures made
+            # with an older buffer keep a reference to it (ent["scalars"])
+            self.scalars = StepScalars(dev, n_adam=max(96, n_adam))
+        ent["scalars"] = self.scalars
         ent["batch"] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         ent["blend"] = ({k: (v.clone() if torch.is_tensor(v) else v) for k, v in blend.items()}
                         if blend is not None else None)
@@ -171,6 +205,7 @@ class GraphedStep:
         sc = self.scalars
         tr.renderer.sched_scalars = sc.dev[sc.SCHED:sc.SCHED + 2]
         tr.optimizer.dyn_base = sc.dev.data_ptr() + 4 * sc.ADAM
+        tr.loss_weights().bind(sc.dev[sc.LOSSW:sc.LOSSW + LW_COUNT])
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         try:
@@ -181,7 +216,9 @@ class GraphedStep:
         finally:
             tr.renderer.sched_scalars = None
             tr.optimizer.dyn_base = None
+            tr.loss_weights().unbind()
         ent["graph"], ent["loss"], ent["out"], ent["order"] = g, loss, out, list(tr.optimizer._order)
+        self.captures += 1
 
 
 class Trainer:
@@ -223,8 +260,10 @@ class Trainer:
             self.color_loss = loss_cls(**lc)
         self.data_parallel = data_parallel
         self._beta_flag = True
-        if not data_parallel:
-            self.renderer.defer_loss_sums = True        # the step's loss assembly is fused (see `loss`)
+        # single process: the step's loss assembly is fused (see `loss`), so the renderer hands over the composite kernel's
+        # sums instead of the three error terms -- requested per call inside `loss` only: a direct `renderer.render(...)`
+        # (validation, debugging, the reference runner) keeps the reference's result dict
+        self.fuse_loss = not data_parallel
         if data_parallel:
             self.renderer.data_parallel = True
             self.renderer.defer_loss_sums = True
@@ -248,9 +287,19 @@ class Trainer:
         self.graphed = GraphedStep(self, eager_steps=eager_steps)
         return self.graphed
 
+    def loss_weights(self):
+        """the step's LossWeights (owned by the ColorLoss, so a runner that calls `color_loss.set_color_weights` reaches
+        them too) with the regulariser / mask weights of `self.tc` written in."""
+        lw = self.color_loss.weights
+        tc = self.tc
+        lw.set(igr=tc["igr_weight"], igr_ns=tc["igr_ns_weight"], sparse=tc["sparse_weight"], mask=tc["mask_weight"])
+        return lw
+
     def loss(self, batch, cos_anneal_ratio=1.0, flip_saturation=1.0, blend=None, perturb_overwrite=-1):
-        """-> (loss, render_out)."""
+        """-> (loss, render_out).  Every weight enters as a read of the device weight vector (LossWeights): by `w_dev` in
+        the fused kernels, as 0-d tensor views in the torch expressions."""
         tc, lc = self.tc, self.lc
+        w = self.loss_weights().device(batch["rays_o"].device)
         kw = {}
         if blend is not None and lc["color_pixel_weight"] > 0:
             kw = dict(color_maps=blend["color_maps"], w2cs=blend["w2cs"], intrinsics=blend["intrinsics"],
@@ -258,9 +307,15 @@ class Trainer:
                       rays_uv=batch["rays_uv"].clone() if lc["color_patch_weight"] > 0 else None)
             if "ref_cam" in blend:        # patch-camera constants computed by the caller (GraphedStep: outside the capture)
                 kw["patch_cams"] = (blend["ref_cam"], blend["src_cam"])
-        out = self.renderer.render(batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
-                                   flip_saturation=flip_saturation, cos_anneal_ratio=cos_anneal_ratio,
-                                   perturb_overwrite=perturb_overwrite, **kw)
+        defer = self.renderer.defer_loss_sums
+        if self.fuse_loss:
+            self.renderer.defer_loss_sums = True
+        try:
+            out = self.renderer.render(batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
+                                       flip_saturation=flip_saturation, cos_anneal_ratio=cos_anneal_ratio,
+                                       perturb_overwrite=perturb_overwrite, **kw)
+        finally:
+            self.renderer.defer_loss_sums = defer
         weight_sum = out["weight_sum"]
         patch_mask = None
         if out["patch_mask"] is not None:
@@ -280,11 +335,8 @@ class Trainer:
             if bce_sum is None and self.color_loss.fusable(out["color_base"], out["color"], batch["true_rgb"],
                                                            out["color_pixel"], out["patch_colors"]):
                 from .loss.loss import _StepLossFn
-                cw = self.color_loss
                 loss, _, _, _, ge, gens, se = _StepLossFn.apply(
-                    out["color_base"], out["color"], batch["true_rgb"], pixel_mask, sums, float(weight_sum.shape[0]),
-                    cw.color_base_weight, cw.color_weight, cw.color_pixel_weight, tc["igr_weight"], tc["igr_ns_weight"],
-                    tc["sparse_weight"])
+                    out["color_base"], out["color"], batch["true_rgb"], pixel_mask, sums, float(weight_sum.shape[0]), w)
                 out["gradient_error"], out["gradient_error_near_surface"], out["sparse_error"] = ge, gens, se
                 return loss, out
             ge, gens, se = self.renderer.errors_from_sums(sums, weight_sum.shape[0])
@@ -315,10 +367,10 @@ class Trainer:
         else:
             cl = self.color_loss(*cargs)
             mask_loss = bce_sum / float(weight_sum.numel()) if bce_sum is not None else None
-        loss = cl["loss"] + out["gradient_error_near_surface"] * tc["igr_ns_weight"] \
-            + out["sparse_error"] * tc["sparse_weight"] + out["gradient_error"] * tc["igr_weight"]
+        loss = cl["loss"] + out["gradient_error_near_surface"] * w[LW["igr_ns"]] \
+            + out["sparse_error"] * w[LW["sparse"]] + out["gradient_error"] * w[LW["igr"]]
         if mask_loss is not None:
-            loss = loss + mask_loss * tc["mask_weight"]
+            loss = loss + mask_loss * w[LW["mask"]]
         return loss, out
 
     def step(self, batch, **kw):

@@ -55,26 +55,171 @@ def test_graph_replay_equals_eager_to_the_bit(rconf):
     assert steps == {float(n)}, steps
 
 
-def test_new_loss_weights_are_a_new_capture_and_dp_stays_eager():
+def test_loss_weights_travel_through_memory_and_dp_stays_eager():
+    """a loss / regulariser weight is not part of the capture key any more: changing it keeps replaying the same graph and
+    the replays use the new value (bit-identical to an eager trainer fed the same sequence); what changes the launch
+    sequence -- another batch shape, a loss term switched on -- is a new capture."""
     from neuraludf_amd.train import Trainer, GraphedStep
     dev = torch.device("cuda:0")
-    tr = Trainer(dev, RCONF, seed=0, fused_adam=True)
-    gs = GraphedStep(tr, eager_steps=1)
     scene = synth.make_scene("tiny")
     batch = {k: v.to(dev) for k, v in synth.make_rays(scene, 0, 128, seed=5).items()}
-    for _ in range(3):
-        gs(batch)
-    assert gs.replays == 2 and len(gs.graphs) == 1
-    tr.tc["igr_weight"] = 0.2                         # a by-value kernel / python scalar of the step: part of the key
-    l0, _ = gs(batch)                                 # eager again under the new key
-    assert len(gs.graphs) == 2 and gs.replays == 2
-    l1, _ = gs(batch)
-    assert gs.replays == 3 and torch.isfinite(l1)
+    seq = [dict(igr_weight=0.1), dict(igr_weight=0.1), dict(igr_weight=0.1), dict(igr_weight=0.2, sparse_weight=0.01),
+           dict(igr_weight=0.2, igr_ns_weight=0.05, sparse_weight=0.01), dict(igr_weight=0.05, igr_ns_weight=0.0)]
+
+    def run(graphed):
+        tr = Trainer(dev, RCONF, seed=0, fused_adam=True)
+        st = GraphedStep(tr, eager_steps=1) if graphed else tr.step
+        torch.manual_seed(11)
+        losses = []
+        for i, upd in enumerate(seq):
+            tr.tc.update(upd)
+            if i == 4:
+                tr.color_loss.set_color_weights(0.3, 1.0, 0.0, 0.0)      # the runner's own route to the colour weights
+            loss, _ = st(batch)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+        return tr, st, losses
+
+    _, _, eager = run(False)
+    tr, gs, graph = run(True)
+    assert gs.replays == len(seq) - 1 and len(gs.graphs) == 1 and gs.captures == 1
+    for i, (a, b) in enumerate(zip(eager, graph)):
+        assert torch.equal(a, b), (i, float(a), float(b))
+    assert len({float(x) for x in graph[2:]}) > 1                # and the weights do move the loss
     other = {k: v.to(dev) for k, v in synth.make_rays(scene, 1, 64, seed=6).items()}      # another batch shape
     gs(other)
+    assert len(gs.graphs) == 2
+    tr.tc["mask_weight"] = 0.1                                    # a term switched ON changes the launch sequence
+    gs(batch)
     assert len(gs.graphs) == 3
     tr2 = Trainer(dev, RCONF, seed=0, fused_adam=False)           # torch.optim.Adam: no dynamic-scalar path -> eager
     assert not GraphedStep(tr2).enabled
+    tr3 = Trainer(dev, RCONF, seed=0, fused_adam=True, data_parallel=True)     # collectives: eager unless asked for
+    assert not GraphedStep(tr3).enabled and GraphedStep(tr3, capture_collectives=True).enabled
+
+
+def _loop(graph, sched_kw, first, last, rconf=None, batch_size=128):
+    from neuraludf_amd.dataset import RayBatchSource
+    from neuraludf_amd.schedules import Schedules
+    from neuraludf_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene("tiny")
+    n_views = 5
+    imgs = torch.rand(n_views, scene.H, scene.W, 3, generator=torch.Generator().manual_seed(0))
+    src = RayBatchSource(imgs.clone(), torch.ones_like(imgs), scene.intrinsics[:n_views], scene.c2w[:n_views])
+    tr = Trainer(dev, rconf or dict(n_samples=32, n_importance=16, n_outside=0, up_sample_steps=2, perturb=1.0), seed=0,
+                 fused_adam=True)
+    if graph:
+        tr.enable_graph(eager_steps=2)
+    sched = Schedules(**sched_kw)
+    torch.manual_seed(99)
+    losses, weights = [], []
+    for it in range(first, last + 1):
+        loss, _, _ = tr.iteration(src, it, sched, batch_size=batch_size)
+        losses.append(loss.clone())
+        weights.append(list(tr.loss_weights().values()))
+    torch.cuda.synchronize()
+    return tr, losses, weights
+
+
+def test_colour_weight_ramp_at_iteration_10000_replays_live_weights():
+    """VERDICT r3 weak 2 / ADVICE r3 (high): the shipped DTU conf ramps color_base_weight from 0 at iteration 10 000
+    (adjust_color_loss_weights, exp_runner_blending.py:230-251) and switches flip_saturation at the same iteration; a
+    step captured before the ramp must replay the LIVE weight.  Iterations 9 994 .. 10 006: graph == eager to the bit,
+    ONE capture, the replay counter running through the ramp."""
+    kw = dict(end_iter=30000, learning_rate=1e-3, learning_rate_geo=2e-4, learning_rate_alpha=0.05, warm_up_end=5.0,
+              anneal_end=50.0, fix_geo_end=0, color_base_weight=0.5, color_weight=1.0)
+    a, la, wa = _loop(False, kw, 9994, 10006)
+    b, lb, wb = _loop(True, kw, 9994, 10006)
+    assert wa == wb and wa[0][0] == 0.0 and wa[-1][0] > 0.0 and len({w[0] for w in wa}) == 7      # 0, then 1e-4 .. 6e-4 of 0.5
+    assert b.graphed.captures == 1 and b.graphed.replays == 13 - 2
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert torch.equal(x, y), (9994 + i, float(x), float(y))
+    for (n, p), (_, q) in zip(list(a.udf.named_parameters()) + list(a.color.named_parameters()),
+                              list(b.udf.named_parameters()) + list(b.color.named_parameters())):
+        assert torch.equal(p, q), n
+    # the ramp is visible in the result: freezing the weight at its pre-ramp value (what a by-value capture replayed) differs
+    kw0 = dict(kw, color_base_weight=0.0)
+    _, l0, _ = _loop(False, kw0, 9994, 10006)
+    assert torch.equal(l0[5], la[5]) and not torch.equal(l0[-1], la[-1])
+
+
+def test_regulariser_schedule_boundaries_replay_live_weights():
+    """--reg_weights_schedule (regularization_weights_schedule, exp_runner_blending.py:199-211): igr_ns_weight ramps over
+    [end/5, 2 end/5], sparse_weight switches on at end/2 -- every iteration of the ramp has a new weight, none of them a
+    new capture."""
+    kw = dict(end_iter=50, learning_rate=1e-3, learning_rate_geo=2e-4, learning_rate_alpha=0.05, warm_up_end=5.0,
+              anneal_end=20.0, fix_geo_end=0, color_base_weight=0.01, color_weight=1.0, igr_ns_weight=0.1,
+              sparse_weight=0.02, reg_weights_schedule=True)
+    a, la, wa = _loop(False, kw, 6, 30)
+    b, lb, wb = _loop(True, kw, 6, 30)
+    from neuraludf_amd._lib import LW
+    ns = [w[LW["igr_ns"]] for w in wb]
+    sp = [w[LW["sparse"]] for w in wb]
+    assert ns[0] == 0.0 and abs(ns[-1] - 0.1) < 1e-12 and len(set(ns)) >= 10 and sp[0] == 0.0 and sp[-1] == 0.02
+    assert b.graphed.captures == 1 and b.graphed.replays == 25 - 2
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert torch.equal(x, y), (6 + i, float(x), float(y))
+    for (n, p), (_, q) in zip(a.udf.named_parameters(), b.udf.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_flip_saturation_follows_the_schedule_without_cos_anneal():
+    """with cos_anneal_ratio = None the captured composite kernels still read flip_saturation from
+    device memory."""
+    from neuraludf_amd.train import Trainer, GraphedStep
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene("tiny")
+    batch = {k: v.to(dev) for k, v in synth.make_rays(scene, 0, 128, seed=5).items()}
+
+    def run(graphed):
+        tr = Trainer(dev, RCONF, seed=0, fused_adam=True)
+        st = GraphedStep(tr, eager_steps=1) if graphed else tr.step
+        torch.manual_seed(3)
+        out = []
+        for fs in (0.0, 0.0, 0.0, 0.9, 1.0):
+            loss, _ = st(batch, cos_anneal_ratio=None, flip_saturation=fs)
+            out.append(loss.clone())
+        torch.cuda.synchronize()
+        return st, out
+    _, eager = run(False)
+    gs, graph = run(True)
+    assert gs.replays == 4 and gs.captures == 1
+    for i, (x, y) in enumerate(zip(eager, graph)):
+        assert torch.equal(x, y), i
+
+
+def test_reloaded_optimizer_state_drops_the_captures():
+    """a capture holds raw pointers to Adam's moments; optimizer.load_state_dict replaces them, so the
+    captures are dropped and the following steps (eager, then a fresh capture) continue exactly like an eager trainer that
+    reloads its state at the same point."""
+    import copy
+    from neuraludf_amd.train import Trainer, GraphedStep
+    dev = torch.device("cuda:0")
+    scene = synth.make_scene("tiny")
+    batch = {k: v.to(dev) for k, v in synth.make_rays(scene, 0, 128, seed=5).items()}
+
+    def run(graphed):
+        tr = Trainer(dev, RCONF, seed=0, fused_adam=True)
+        st = GraphedStep(tr, eager_steps=1) if graphed else tr.step
+        torch.manual_seed(5)
+        out = []
+        for i in range(8):
+            if i == 4:
+                tr.optimizer.load_state_dict(copy.deepcopy(tr.optimizer.state_dict()))
+            loss, _ = st(batch)
+            out.append(loss.clone())
+        torch.cuda.synchronize()
+        return tr, st, out
+    a, _, eager = run(False)
+    b, gs, graph = run(True)
+    assert gs.captures == 2 and gs.replays == 3 + 3
+    for i, (x, y) in enumerate(zip(eager, graph)):
+        assert torch.equal(x, y), i
+    for (n, p), (_, q) in zip(a.udf.named_parameters(), b.udf.named_parameters()):
+        assert torch.equal(p, q), n
+    gs.invalidate()
+    assert not gs.graphs and gs.static_inputs() is None
 
 
 def test_blending_steps_replay_bit_identically():

@@ -823,7 +823,16 @@ def test_color_loss_sharded_split_matches_fused(dev, with_mask):
     def fused():
         out, den = torch.empty(3, device=dev), torch.empty(1, device=dev)
         call("nudf_color_loss_fwd", ptr(cb), ptr(c), ptr(gt), cb.numel(), ptr(mask), mask.numel() if with_mask else 0, *w,
-             ptr(out), ptr(den))
+             None, ptr(out), ptr(den))
+        return out, den
+
+    def fused_wdev():                   # the same weights from a device vector (NUDF_LW_*) override garbage by-value ones
+        from neuraludf_amd._lib import LW_COUNT
+        out, den = torch.empty(3, device=dev), torch.empty(1, device=dev)
+        wd = torch.zeros(LW_COUNT, device=dev)
+        wd[:3] = torch.tensor(w)
+        call("nudf_color_loss_fwd", ptr(cb), ptr(c), ptr(gt), cb.numel(), ptr(mask), mask.numel() if with_mask else 0,
+             7.0, 8.0, 9.0, ptr(wd), ptr(out), ptr(den))
         return out, den
 
     def sums_of(lo, hi):
@@ -835,9 +844,11 @@ def test_color_loss_sharded_split_matches_fused(dev, with_mask):
 
     def finish(s):
         out, den = torch.empty(3, device=dev), torch.empty(1, device=dev)
-        call("nudf_color_loss_finish", ptr(s), 1 if with_mask else 0, *w, ptr(out), ptr(den))
+        call("nudf_color_loss_finish", ptr(s), 1 if with_mask else 0, *w, None, ptr(out), ptr(den))
         return out, den
     o0, d0 = fused()
+    ow, dw = fused_wdev()
+    assert torch.equal(o0, ow) and torch.equal(d0, dw)
     o1, d1 = finish(sums_of(0, n))
     assert torch.equal(o0, o1) and torch.equal(d0, d1)
     o2, d2 = finish(sums_of(0, n // 2) + sums_of(n // 2, n))

@@ -15,7 +15,7 @@ def _one(fused, tconf, mask_weight=0.0):
     from neuraludf_amd.train import Trainer
     dev = torch.device("cuda:0")
     tr = Trainer(dev, RCONF, seed=0, fused_adam=True, train_conf=dict(tconf, mask_weight=mask_weight))
-    tr.renderer.defer_loss_sums = fused
+    tr.fuse_loss = fused
     batch = {k: v.to(dev) for k, v in synth.make_rays(synth.make_scene("tiny"), 0, 160, seed=4).items()}
     batch["mask"] = (torch.rand(160, 1, generator=torch.Generator().manual_seed(1)) > 0.3).float().to(dev)
     loss, out = tr.loss(batch, cos_anneal_ratio=0.6, flip_saturation=0.9, perturb_overwrite=0)

@@ -302,3 +302,11 @@ def test_checkpoint_loader_refuses_arbitrary_pickles(tmp_path):
     with pytest.raises(RuntimeError, match="allow_pickle"):
         C._load_ckpt(str(bad), None, False)
     assert C._load_ckpt(str(bad), None, True)["x"] == os.path.join("executed", "on", "load")
+    # a missing or truncated file is reported as what it is, also with the opt-in set
+    with pytest.raises(FileNotFoundError):
+        C._load_ckpt(str(tmp_path / "missing.pth"), None, True)
+    cut = tmp_path / "cut.pth"
+    cut.write_bytes(ok.read_bytes()[:100])
+    with pytest.raises(Exception) as ei:
+        C._load_ckpt(str(cut), None, False)
+    assert "allow_pickle" not in str(ei.value)
