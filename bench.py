@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("NUDF_BENCH_GRAPH", "1")),
                     help="1: the timed steps are replays of the train step captured in a HIP graph (train.GraphedStep: "
                          "bit-identical to eager steps, one graph launch per step); 0: eager launches")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "mixed16"],
+    ap.add_argument("--precision", default=os.environ.get("NUDF_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "mixed16"],
                     help="fp32 = the parity path and the headline; mixed16 = BASELINE config 5 (16-bit MFMA operands, "
                          "fp32 accumulate) -- reported for reference only, never the headline number")
     args = ap.parse_args()

@@ -72,7 +72,9 @@ typedef struct NudfGemmTN {
   int32_t M, NA, NB;
   int32_t rows_per_block;                       /* 0 = choose                             */
   int32_t prec;                                 /* MFMA operand precision: 0 = fp32 (exact), 2 = bf16 operands converted
-                                                   from the fp32 tiles on the fly, fp32 accumulate (config-5 mode)   */
+                                                   from the fp32 tiles on the fly, fp32 accumulate (config-5 mode),
+                                                   3 = bf16x3: fp32 emulated on the bf16 pipe (both operands split exactly
+                                                   into three bf16 parts, six products; see NudfChainStep.prec)      */
 } NudfGemmTN;
 
 /* C[NA,NB] += A1^T B1 (+ A2^T B2): weight gradients, reduction over the M points */
@@ -221,13 +223,26 @@ typedef struct NudfUpsample {
   float inv_s, beta, gamma;
   float* z_new;                                /* [N,K] ascending                           */
   float* pts_new;                              /* [N*K,3] o + d*z_new, or NULL              */
+  float* dbg;                                  /* NULL, or [N, NUDF_UP_DBG_ROWS, M]: the intermediates of up_sample_unbias per
+                                                  section -- rows cos_val, vis_prob, alpha_plus, alpha_minus, alpha, weights
+                                                  (before sample_pdf's + 1e-5), cdf -- for the stage-wise comparison with the
+                                                  reference's tensors (scripts/upsample_first_diff.py); mode 0 only */
 } NudfUpsample;
+#define NUDF_UP_DBG_ROWS 7
 #define NUDF_UP_THEORICAL 256
 #define NUDF_UP_SERIAL 512      /* the three scans in torch-CPU order: one running DOUBLE accumulator per row, every output
                                    rounded to float (cumprod / cumsum of a float tensor on the CPU); default: wave-parallel
                                    fp32 scans (what the same torch ops do on a GPU) */
 #define NUDF_UP_NOCONTRACT 1024 /* kernel build without floating-point contraction: every product / sum of the reference's
                                    op chain rounded separately, as separate torch ops round them */
+#define NUDF_UP_SLEEF 2048      /* sigmoid as torch's CPU kernel forms it: 1 / (1 + exp(-x)) with a true division and
+                                   Vectorized<float>::exp = Sleef expf u10 (Cody-Waite ln 2 split, degree-5 polynomial in FMAs,
+                                   two-step ldexp), restated bit for bit (scripts/sleef_expf_check.py: 1 of 4.5 M sigmoids
+                                   differs from torch's on an AVX-512 host).  torch.exp itself goes through MKL's vsExp on
+                                   contiguous tensors and is NOT covered: those call sites keep libm's expf */
+#define NUDF_UP_EXPCR 4096      /* the exp call sites (udf2logistic, alpha_occ: torch.exp = MKL vsExp HA on the CPU) evaluated in
+                                   double and rounded once: the correctly rounded value, which MKL's result equals on 98.9 % of
+                                   arguments; default: libm expf */
 int nudf_upsample(const NudfUpsample* args, void* stream);
 int nudf_merge(const float* z, const float* udf, const float* z_new, const float* udf_new, int N, int M,
                int K, float* z_out, float* udf_out, void* stream);
@@ -416,8 +431,13 @@ typedef struct NudfChainStep {
   int32_t iparam;
   int32_t ldx1, ldx2, ldc1, ldc2;
   int32_t ldr1;                    /* element stride of r1_row                                       */
-  int32_t prec;                    /* MFMA operand precision: 0 = fp32 (exact), 1 = fp16, 2 = bf16 (fp32 accumulate;
-                                      Bp then holds the 16-bit fragment layout of nudf_weightnorm_pack_multi)     */
+  int32_t prec;                    /* MFMA operand precision: 0 = fp32 (v_mfma_f32_32x32x2_f32), 1 = fp16, 2 = bf16 (fp32
+                                      accumulate; Bp then holds the 16-bit fragment layout of
+                                      nudf_weightnorm_pack_multi), 3 = bf16x3: fp32 EMULATED on the bf16 matrix pipe --
+                                      both operands split exactly into three bf16 parts (x = hi + mid + lo), the six
+                                      products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid on v_mfma_f32_32x32x16_bf16
+                                      with fp32 accumulation; the dropped terms are <= 2^-23 |x| |y| per product, the size
+                                      of one fp32 rounding (Bp: the three-plane layout of NudfPackFrag.dtype 3)     */
   int32_t act_write;               /* 1: the outputs become the next step's activation tile          */
   int32_t act_col0;                /* ... at tile columns [act_col0, act_col0 + N)                   */
   int32_t pe_tail_col;             /* >= 0: afterwards write PE(x)*pe_tail_scale at these tile columns ...       */
@@ -497,7 +517,9 @@ typedef struct NudfPackFrag {
   int32_t K, N;
   int32_t dtype;                   /* 0: fp32 fragments (nudf_pack_frag layout); 1 / 2: fp16 / bf16 fragments for
                                       v_mfma_f32_32x32x16_*: dst16[((g*NT + T)*64 + lane)*8 + j] =
-                                      B[16g + 8(lane>>5) + j][32T + (lane&31)], round-to-nearest-even             */
+                                      B[16g + 8(lane>>5) + j][32T + (lane&31)], round-to-nearest-even;
+                                      3: bf16x3 split, three planes hi / mid / lo of that layout stored back to back per
+                                      (g, T): dst16[(((g*NT + T)*3 + plane)*64 + lane)*8 + j]  (3x the 16-bit size)   */
 } NudfPackFrag;
 typedef struct NudfPackLayer {
   const float* v; const float* g;  /* weight_v [out,in], weight_g [out] (NULL: plain Linear)                    */

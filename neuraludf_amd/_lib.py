@@ -82,7 +82,7 @@ class Upsample(C.Structure):
                 ("sample_dist", c_fp), ("gamma_dev", c_fp),
                 ("N", i32), ("M", i32), ("K", i32), ("mode", i32),
                 ("inv_s", f32), ("beta", f32), ("gamma", f32),
-                ("z_new", c_fp), ("pts_new", c_fp)]
+                ("z_new", c_fp), ("pts_new", c_fp), ("dbg", c_fp)]
 
 
 class PixelBlend(C.Structure):

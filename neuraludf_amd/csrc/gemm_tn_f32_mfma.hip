@@ -26,6 +26,9 @@
 #include <string.h>
 #include <type_traits>
 
+#ifndef NUDF_MMA16_REPEAT
+#define NUDF_MMA16_REPEAT 1  // timing probe (see mlp_chain.hip)
+#endif
 #define BM 128
 #define BN 128
 #define BK 32
@@ -41,6 +44,7 @@
 #define TNF_NO_XCD_MAP 64           // plain tile-major blockIdx (A/B of the XCD-aware order)
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 #define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
+#define TNF_NO_SPLIT_IMAGE 512      // bf16x3 mode through the generic kernel (split on the way out of the fp32 image; A/B of gemm_tn3_group_kernel)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -317,6 +321,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
           b16[j] = __builtin_convertvector(v, bf16x8);
         }
 #pragma unroll
+        for (int rep = 0; rep < NUDF_MMA16_REPEAT; ++rep)
+#pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -337,8 +343,51 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = vr[(16 * kk + e) * LDT + 32 * s];
         const bf16x8 v16 = __builtin_convertvector(v, bf16x8);
+        for (int rep = 0; rep < NUDF_MMA16_REPEAT; ++rep)
         acc[s] = kLay == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(v16, f16, acc[s], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(f16, v16, acc[s], 0, 0, 0);
+      }
+    }
+  };
+  // bf16x3 mode (prec == 3, see NudfChainStep.prec): fp32 emulated on the bf16 pipe.  Both operand fragments are split
+  // exactly into three bf16 parts on their way out of the SAME fp32 LDS image (8 ds_read_b32 + the split per fragment),
+  // six partial products per sub-tile and k step, smallest first, fp32 accumulate.  Quadrant layout only (tn_plan).
+  auto split3 = [](const f32x8& x, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    p0 = __builtin_convertvector(x, bf16x8);
+    const f32x8 r1 = x - __builtin_convertvector(p0, f32x8);
+    p1 = __builtin_convertvector(r1, bf16x8);
+    const f32x8 r2 = r1 - __builtin_convertvector(p1, f32x8);
+    p2 = __builtin_convertvector(r2, bf16x8);
+  };
+  auto mma16x3 = [&](int cur) {
+    const float* as = As + cur * T_TILE + (8 * (lane >> 5)) * LDT + (wave >> 1) * 64 + (lane & 31);
+    const float* bs = Bs + cur * T_TILE + (8 * (lane >> 5)) * LDT + (wave & 1) * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 a3[2][3], b3[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = as[(16 * kk + e) * LDT + 32 * i];
+        split3(v, a3[i][0], a3[i][1], a3[i][2]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bs[(16 * kk + e) * LDT + 32 * j];
+        split3(v, b3[j][0], b3[j][1], b3[j][2]);
+      }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int pa = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1 ? 2 : 1);     // h l m h m h
+        const int pb = (t == 0) ? 2 : ((t == 2 || t == 3) ? 1 : 0);              // l h m m h h
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i][pa], b3[j][pb], acc[i * 2 + j], 0, 0, 0);
       }
     }
   };
@@ -489,7 +538,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
         if (kt + 1 < nk) gload(kt + 1);
         __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
         if constexpr (decltype(N)::value > 0) {
-          if constexpr (decltype(P16)::value != 0) mma16(N, LAY, cur);
+          if constexpr (decltype(P16)::value == 3) mma16x3(cur);
+          else if constexpr (decltype(P16)::value != 0) mma16(N, LAY, cur);
           else mma(N, LAY, cur);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -498,7 +548,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
       }
     };
     auto by_prec = [&](auto N, auto LAY) {
-      if (g.prec != 0) kloop(N, LAY, I1{});
+      if (g.prec == 3) kloop(N, LAY, I3{});
+      else if (g.prec != 0) kloop(N, LAY, I1{});
       else kloop(N, LAY, I0{});
     };
     if (n_w == 0) { by_prec(I0{}, I0{}); return; }
@@ -811,6 +862,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
       for (int kk = 0; kk < BK16 / 16; ++kk) {
         if (kk + 1 < BK16 / 16) rd((kk + 1) & 1, kk + 1);
 #pragma unroll
+        for (int rep = 0; rep < NUDF_MMA16_REPEAT; ++rep)
+#pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -902,6 +955,197 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
   }
 }
 
+// =======================================================================================================
+// bf16x3 mode (NudfGemmTNGroup.prec == 3): fp32 EMULATED on the bf16 matrix pipe, see NudfChainStep.prec.  Same tiles,
+// quadrant layout, workspace slots and reduce as above; both operands are fp32 row-major (the bf16x3 chains keep fp32
+// state).  The LDS image is the MFMA operand THREE TIMES: planes hi / mid / lo of the k-pair layout of
+// gemm_tn16_group_kernel, filled by splitting every element ONCE on its way in (x = hi + mid + lo exactly; 11 VALU
+// operations per pair of values), so the k loop holds no conversion at all: per 16 rows and sub-tile pair 3 + 3 operand
+// fragments of 4 ds_read_b32 and 6 MFMAs (hi lo, lo hi, mid mid, hi mid, mid hi, hi hi; fp32 accumulate).  k-steps of 32
+// rows, ONE LDS buffer of 50.7 KB (3 planes x 2 operands x 16 k-pair rows x 132 dwords): the global loads of step k + 1 are
+// in flight under step k's 48 MFMAs per wave, the split + LDS stores sit between two barriers, and the co-resident
+// workgroups of the CU (2-3) run their MFMA phases meanwhile.
+// =======================================================================================================
+#define BK3 32
+#define LD3 132
+#define T3 (16 * LD3)
+__device__ __forceinline__ void tn_split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float r0 = x0 - __builtin_bit_cast(float, p0 << 16);
+  const float r1 = x1 - __builtin_bit_cast(float, p0 & 0xffff0000u);
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float s0 = r0 - __builtin_bit_cast(float, p1 << 16);
+  const float s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
+  __shared__ __attribute__((aligned(16))) unsigned smem[6 * T3];
+  unsigned* As = smem;             // planes at As + pl * T3
+  unsigned* Bs = smem + 3 * T3;
+
+  const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
+  const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  int t, chunk;
+  tn_decode(g, t, chunk);
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const int slot_id = tl.blk_start + chunk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const int mbeg = chunk * tl.rows_per_block;
+  const int mend = min(mbeg + tl.rows_per_block, g.M);
+  const int nk = (mend - mbeg + BK3 - 1) / BK3;
+  const int pr = tid >> 4, pc = (tid & 15) * 8;     // k-pair of the step (rows 2 pr, 2 pr + 1), first of 8 columns
+  const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
+  f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+
+  // this thread's 8 columns of an operand as two 4-column pieces, each clamped into the buffer (columns past NA / NB only
+  // feed outputs that are never stored); rows are clamped per load
+  const int ca = i0 + pc, cb = j0 + pc;
+  const char* pa = reinterpret_cast<const char*>(q.A1) + (size_t)min(ca, q.lda1 - 4) * 4;
+  const char* pb = reinterpret_cast<const char*>(q.B1) + (size_t)min(cb, q.ldb1 - 4) * 4;
+  const int pa2 = (min(ca + 4, q.lda1 - 4) - min(ca, q.lda1 - 4)) * 4;
+  const int pb2 = (min(cb + 4, q.ldb1 - 4) - min(cb, q.ldb1 - 4)) * 4;
+  const size_t rowa = (size_t)q.lda1 * 4, rowb = (size_t)q.ldb1 * 4;
+  f32x4 sa[2][2], sb[2][2];        // [row of the pair][piece]
+  auto load = [&](const char* p, int p2, size_t rowbytes, f32x4 (&st)[2][2], int kt) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = min(mbeg + kt * BK3 + 2 * pr + rr, g.M - 1);
+      const char* src = p + (size_t)row * rowbytes;
+      st[rr][0] = *reinterpret_cast<const f32x4*>(src);
+      st[rr][1] = *reinterpret_cast<const f32x4*>(src + p2);
+    }
+  };
+  auto store = [&](const f32x4 (&st)[2][2], int kt, unsigned* tile, bool bias) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const int k0 = mbeg + kt * BK3 + 2 * pr;
+    const bool v0 = k0 < mend, v1 = k0 + 1 < mend;
+    const f32x4 r0l = v0 ? st[0][0] : z, r0h = v0 ? st[0][1] : z;
+    const f32x4 r1l = v1 ? st[1][0] : z, r1h = v1 ? st[1][1] : z;
+    u32x4 h0, m0, l0, h1, m1, l1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned a, b, d;
+      tn_split3_pair(r0l[c], r1l[c], a, b, d);
+      h0[c] = a; m0[c] = b; l0[c] = d;
+      tn_split3_pair(r0h[c], r1h[c], a, b, d);
+      h1[c] = a; m1[c] = b; l1[c] = d;
+    }
+    if (bias) {
+      bias_lo += r0l + r1l;
+      bias_hi += r0h + r1h;
+    }
+    unsigned* dst = tile + pr * LD3 + pc;
+    *reinterpret_cast<u32x4*>(dst) = h0;
+    *reinterpret_cast<u32x4*>(dst + 4) = h1;
+    *reinterpret_cast<u32x4*>(dst + T3) = m0;
+    *reinterpret_cast<u32x4*>(dst + T3 + 4) = m1;
+    *reinterpret_cast<u32x4*>(dst + 2 * T3) = l0;
+    *reinterpret_cast<u32x4*>(dst + 2 * T3 + 4) = l1;
+  };
+  // one k-step: 2 groups of 16 rows; per group 2 + 2 operand sub-tiles x 3 planes and 24 MFMAs
+  auto mma = [&]() {
+    const unsigned* as = As + (4 * (lane >> 5)) * LD3 + (wave >> 1) * 64 + (lane & 31);
+    const unsigned* bs = Bs + (4 * (lane >> 5)) * LD3 + (wave & 1) * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK3 / 16; ++kk) {
+      u32x4 a[2][3], b[2][3];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[s2][pl][e] = as[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
+            b[s2][pl][e] = bs[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
+          }
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt) {
+        const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
+        const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][qa]),
+                                                                     __builtin_bit_cast(bf16x8, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+      }
+    }
+  };
+  if (nk > 0) {
+    load(pa, pa2, rowa, sa, 0);
+    load(pb, pb2, rowb, sb, 0);
+    store(sa, 0, As, do_bias);
+    store(sb, 0, Bs, false);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      load(pa, pa2, rowa, sa, kt + 1);
+      load(pb, pb2, rowb, sb, kt + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+    mma();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // every wave is done reading the image
+    if (kt + 1 < nk) {
+      store(sa, kt + 1, As, do_bias);
+      store(sb, kt + 1, Bs, false);
+    }
+    __syncthreads();
+  }
+
+  if (g.dbg && tid == 0) {
+    long long* d = g.dbg + 4 * (size_t)blockIdx.x;
+    d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = 2 * 16 + 4;
+    d[3] = nk | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 16);
+  }
+  if (g.flags & TNF_NO_EPILOGUE) return;
+  float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
+  if (do_bias) {   // the loop's last barrier has passed: the operand image is free
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
+    *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
+    __syncthreads();
+    if (tid < BM) {
+      float sum = 0.0f;
+      for (int k = 0; k < 16; ++k) sum += red[k * BM + tid];
+      if (slot) slot[BM * BN + tid] = sum;
+      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (slot) {   // accumulator register order, 64 contiguous bytes per lane (tn_reduce_kernel decodes it)
+      float* w = slot + ((wave * 4 + s) * 64 + lane) * 16;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {acc[s][4 * qd], acc[s][4 * qd + 1], acc[s][4 * qd + 2], acc[s][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
+      }
+    } else {
+      const int col = j0 + 32 * tn_jsub(2, wave, s) + (lane & 31);
+      if (col >= q.NB) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 32 * tn_isub(2, wave, s) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s][r]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side: the plan (tiles, layouts, cost-weighted row chunks) and the C ABI
 // ---------------------------------------------------------------------------------------
@@ -950,7 +1194,7 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
     {
       const bool ap4 = (q.flags & NUDF_TN_A_P4) != 0, bp4 = (q.flags & NUDF_TN_B_P4) != 0;
       const bool a16 = (q.flags & NUDF_TN_A16) != 0, b16 = (q.flags & NUDF_TN_B16) != 0;
-      if ((ap4 && !a16) || (bp4 && !b16) || ((ap4 || bp4) && g.prec == 0) || (ap4 && b16 && !bp4) || (bp4 && a16 && !ap4) ||
+      if ((ap4 && !a16) || (bp4 && !b16) || ((ap4 || bp4) && (g.prec == 0 || g.prec == 3)) || (ap4 && b16 && !bp4) || (bp4 && a16 && !ap4) ||
           ((ap4 || bp4) && (flags & TNF_NO_PACK16)) || ((ap4 || bp4) && g.rows_per_block % 4)) {
         nudf_set_error("nudf_gemm_tn_grouped: a 4-point packed operand is a bf16 operand of the 16-bit MFMA mode "
                        "(NUDF_TN_x16 set, prec != 0, rows_per_block a multiple of 4); a problem's other operand is packed "
@@ -1109,7 +1353,7 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   // 16-bit MFMA mode: the packed-image kernel, unless an operand is in the blocked fp32 layout (generic kernel only) or
   // most operands are stored as fp32 (its staging of an fp32 operand is heavier: 262 -> 278 us with all-fp32 operands,
   // 228 -> 183 us with all-bf16 ones at 65 536 points)
-  bool packed16 = pl.prec != 0 && !(pl.flags & TNF_NO_PACK16);
+  bool packed16 = pl.prec != 0 && pl.prec != 3 && !(pl.flags & TNF_NO_PACK16);   // (bf16x3 splits from the fp32 image)
   int n16 = 0;
   for (int i = 0; i < args->n_problems && packed16; ++i) {
     const int f = args->prob[i].flags;
@@ -1127,7 +1371,13 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
       }
     packed16 = true;
   }
-  if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  // bf16x3 mode: the split-image kernel when every operand is fp32 row-major (what the bf16x3 chains store); anything else
+  // goes through the generic kernel, which splits on the way OUT of its fp32 image (NUDF_TN_FLAGS & 512 forces that: A/B)
+  bool split3 = pl.prec == 3 && !(pl.flags & TNF_NO_SPLIT_IMAGE);
+  for (int i = 0; i < args->n_problems && split3; ++i)
+    if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;
+  if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
   if (pl.ws && !(pl.flags & TNF_NO_EPILOGUE)) {

@@ -135,6 +135,9 @@ __device__ __forceinline__ void ch_mma(const float* __restrict__ arow, const f32
 #ifndef NUDF_STAGGER32
 #define NUDF_STAGGER32 2u    // the same for the fp32 instantiation's 64-point tiles (0 also switches the 32-point tiles' stagger off)
 #endif
+#ifndef NUDF_MMA16_REPEAT
+#define NUDF_MMA16_REPEAT 1  // timing probe: every 16-bit MFMA issued this many times (what a split-operand fp32 emulation costs)
+#endif
 #ifndef NUDF_MMA16_RING
 #define NUDF_MMA16_RING 1    // A/B build switch (scripts/build_variants.sh): 0 = one k step of weight fragments in flight
 #endif
@@ -160,6 +163,8 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
     for (int j = 0; j < NCT; ++j) b[j] = bq[j * 64];
   };
   auto mma = [&](f32x4 (&a)[NRT][2], uint4 (&b)[NCT]) {
+#pragma unroll
+    for (int rep = 0; rep < NUDF_MMA16_REPEAT; ++rep)     // > 1: timing probes only (results are garbage)
 #pragma unroll
     for (int i = 0; i < NRT; ++i) {
       const f32x8 av = {a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]};
@@ -241,6 +246,97 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
   }
   if (g < G16) mma(a0, b0);   // odd number of 16-wide k steps
 #endif
+}
+
+// bf16x3 K loop (NudfChainStep.prec == 3): the fp32 product EMULATED on the bf16 matrix pipe, which is 16x faster than
+// the fp32 one.  Every fp32 value is the exact sum of three bf16 parts, x = hi + mid + lo (round to nearest each: 8 + 8 + 8
+// significant bits with signed remainders cover fp32's 24); the weights are split once per optimizer step by the pack kernel
+// (three fragment planes), the activations on the fly from the fp32 LDS tile (3 v_cvt_pk + 4 subtractions / shifts per
+// pair).  Six of the nine partial products are formed -- hi hi, hi mid, mid hi, hi lo, lo hi, mid mid -- with fp32
+// accumulation; the three dropped ones (mid lo, lo mid, lo lo) are bounded by 2^-23 |x| |y| per product, the size of one
+// fp32 rounding, and random in sign.  12 matrix-pipe cycles per k and tile instead of the fp32 MFMA's 32.
+// Lane (i, h) contracts k = 16 g + 8 h .. + 7 as in ch_mma16; per k step a wave issues 6 NRT NCT MFMAs (768 cycles for
+// 2 x 2 tiles) against 3 NCT weight loads, 2 NRT LDS reads and ~7 VALU operations per activation element.
+typedef float ch_f32x8v __attribute__((ext_vector_type(8)));
+typedef float ch_f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 ch_bf16x2v __attribute__((ext_vector_type(2)));
+// two values at a time: ONE v_cvt_pk_bf16_f32 gives both leading parts, the shift / mask widen them back, two exact
+// subtractions leave the remainders -- 5 + 5 + 1 VALU operations per pair (the vector form below let the compiler convert
+// every element a second time on its own to widen it: 7.5 per element)
+__device__ __forceinline__ void ch_split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(ch_f32x2v{x0, x1}, ch_bf16x2v));
+  const float r0 = x0 - __builtin_bit_cast(float, p0 << 16);
+  const float r1 = x1 - __builtin_bit_cast(float, p0 & 0xffff0000u);
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(ch_f32x2v{r0, r1}, ch_bf16x2v));
+  const float s0 = r0 - __builtin_bit_cast(float, p1 << 16);
+  const float s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(ch_f32x2v{s0, s1}, ch_bf16x2v));
+}
+__device__ __forceinline__ void ch_split3(const f32x4& lo4, const f32x4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+  uint4 a, b, c;
+  ch_split3_pair(lo4[0], lo4[1], a.x, b.x, c.x);
+  ch_split3_pair(lo4[2], lo4[3], a.y, b.y, c.y);
+  ch_split3_pair(hi4[0], hi4[1], a.z, b.z, c.z);
+  ch_split3_pair(hi4[2], hi4[3], a.w, b.w, c.w);
+  p0 = __builtin_bit_cast(bf16x8, a);
+  p1 = __builtin_bit_cast(bf16x8, b);
+  p2 = __builtin_bit_cast(bf16x8, c);
+}
+template <int NRT, int NCT>
+__device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride3,
+                                           int G16, f32x16 (&acc)[2][2]) {
+  // bptr: this lane's uint4 of plane 0 of column tile ct0 in k step 0; planes 64 uint4 apart, column tiles 192, k steps
+  // bstride3 = 3 * NT * 64
+  f32x4 a0[NRT][2], a1[NRT][2];
+  uint4 b0[NCT][3], b1[NCT][3];
+  auto lda = [&](f32x4 (&a)[NRT][2], int g) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+      a[i][0] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16);
+      a[i][1] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16 + 4);
+    }
+  };
+  auto ldb = [&](uint4 (&b)[NCT][3], int g) {
+    const uint4* bq = bptr + (size_t)g * bstride3;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[j][pl] = bq[j * 192 + pl * 64];
+  };
+  auto mma = [&](f32x4 (&a)[NRT][2], uint4 (&b)[NCT][3]) {
+    bf16x8 ah[NRT], am[NRT], al[NRT];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) ch_split3(a[i][0], a[i][1], ah[i], am[i], al[i]);
+    // smallest terms first; (A part, B plane) pairs
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+          const bf16x8 av = (t == 0 || t == 3 || t == 5) ? ah[i] : ((t == 1) ? al[i] : am[i]);          // h l m h m h
+          const uint4 bv = (t == 0) ? b[j][2] : ((t == 2 || t == 3) ? b[j][1] : b[j][0]);              // l h m m h h
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
+        }
+  };
+  lda(a0, 0);
+  ldb(b0, 0);
+  int g = 0;
+#pragma unroll 1
+  for (; g + 1 < G16; g += 2) {
+    lda(a1, g + 1);
+    ldb(b1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int gn = (g + 2 < G16) ? g + 2 : g + 1;
+    lda(a0, gn);
+    ldb(b0, gn);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (g < G16) mma(a0, b0);   // odd number of 16-wide k steps
 }
 
 // 16-bit stored state, 4-point packed (ch_p4_off): the 16 accumulator rows of a lane are 4 groups of 4 consecutive
@@ -521,17 +617,63 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
   }
 }
 
+// bf16x3 mode (fp32 stored state, no operand prefetch under the K loop: the split needs those registers): BOTH stored
+// operands of tile t + 1 are requested before tile t is computed and stored, as in ch_epilogue_seq16.
+template <int EPI, int NRT, int NCT>
+__device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
+                                                  int ln, f32x16 (&acc)[2][2]) {
+  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
+  float xa[2][16], xb[2][16];
+  auto issue = [&](float (&a1)[16], float (&a2)[16], int i, int j) {
+    const int col = (ct0 + j) * 32 + ln;
+    const unsigned colc = (unsigned)((col < st.N) ? col : 0);
+    const unsigned row0 = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h);
+    if (U1) {
+      const unsigned vo = row0 * (unsigned)st.ldx1 + colc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[vo];
+    }
+    if (U2) {
+      if (st.X2) {
+        const unsigned vo = row0 * (unsigned)st.ldx2 + colc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[vo];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0.0f;
+      }
+    }
+  };
+  constexpr int NTL = NRT * NCT;
+  issue(xa[0], xb[0], 0, 0);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (t + 1 < NTL) issue(xa[(t + 1) & 1], xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
+    ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t & 1], false,
+                                xb[t & 1]);
+  }
+}
+
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
-template <int EPI, bool ANY16>
+template <int EPI, int MODE>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
                                             const float (&px1)[2][2][16]) {
+  constexpr bool ANY16 = MODE == 1, X3 = MODE == 2;
   constexpr bool PF = CH_USES_X1(EPI);
   if constexpr (CH_USES_X2(EPI)) {
-    if (st.prec == 0 && nrt == 2 && !(ANY16 && (st.layout & NUDF_CH_STATE16))) {
+    if (!X3 && st.prec == 0 && nrt == 2 && !(ANY16 && (st.layout & NUDF_CH_STATE16))) {
       float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
       if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1);
       else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1);
+      return;
+    }
+  }
+  if constexpr (X3 && CH_USES_X1(EPI)) {
+    if (st.prec == 3 && nrt * nct >= 2) {
+      if (nrt == 2 && nct == 2) ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc);
+      else if (nrt == 2) ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc);
+      else ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc);
       return;
     }
   }
@@ -587,14 +729,17 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
       }
     }
     constexpr bool RT16 = ANY16 && (EPI == NUDF_CH_RELU || EPI == NUDF_CH_MULMASK || EPI == NUDF_CH_ADDMASK);
-    ch_epilogue_tile<EPI, false, false, RT16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16);
+    ch_epilogue_tile<EPI, false, false, RT16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3);
   }
 }
 
 // ANY16: some step of the chain uses 16-bit MFMA operands (config-5 mode).  The fp32 chains get a kernel without any of
 // the 16-bit code: its register pressure (conversions, raw-bf16 operand prefetch) would otherwise spill into them.
-template <int TM, bool ANY16>
+// MODE 2: some step runs the bf16x3 K loop (fp32 emulated on the bf16 pipe, fp32 stored state): its own instantiation for
+// the same reason -- the split's registers next to the 16-bit state code spilled.
+template <int TM, int MODE>
 __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_arg) {
+  constexpr bool ANY16 = MODE == 1, X3 = MODE == 2;
   // The descriptor is read where it lies, in the kernarg segment: the by-value parameter is otherwise a private copy that
   // the optimiser has to prove away, and once it fails (it did when the 16-bit epilogues grew) all 2 KB go to scratch and
   // every K loop pays vmcnt(0) for it.
@@ -656,7 +801,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
   // that one workgroup's epilogues run under the other's MFMA phases.  Speed only.
   const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
   if (gridDim.x > 256) {
-    const unsigned k = ANY16 ? (slot & 1u) * NUDF_STAGGER16 : ((TM == 64) ? (slot & 1u) * NUDF_STAGGER32 : (slot % 3u) * (NUDF_STAGGER32 ? 1u : 0u));
+    const unsigned k = (ANY16 || X3) ? (slot & 1u) * NUDF_STAGGER16 : ((TM == 64) ? (slot & 1u) * NUDF_STAGGER32 : (slot % 3u) * (NUDF_STAGGER32 ? 1u : 0u));
     for (unsigned d = 0; d < k; ++d) __builtin_amdgcn_s_sleep(127);
   }
 
@@ -708,7 +853,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
       const size_t bstride = (size_t)NT * 64;  // float4 per k group
       // the 16-bit instantiation never prefetches X1 under the K loop (its conversions need the registers; the fp32 steps
       // of a 16-bit chain -- the abs-head column -- have no stored operand): px1 stays dead there, the epilogues load X1
-      const bool pfx = !ANY16 && CH_USES_X1(st.epi);
+      const bool pfx = !ANY16 && !X3 && CH_USES_X1(st.epi);
       ChPrefetch pf;
       pf.X1 = st.X1;
       pf.ldx1 = st.ldx1;
@@ -719,7 +864,16 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
           const int col = (ct0 + j) * 32 + ln;
           pf.vo[i][j] = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx1 + (unsigned)((col < st.N) ? col : 0);
         }
-      if (ANY16 && st.prec != 0) {
+      if (X3 && st.prec == 3) {
+        const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
+        const uint4* bp3 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 192 + lane;
+        const size_t bstride3 = (size_t)NT * 192;
+        const int G16 = st.K >> 4;
+        if (nrt == 2 && nct == 2) ch_mma16x3<2, 2>(arow16, bp3, bstride3, G16, acc);
+        else if (nrt == 2) ch_mma16x3<2, 1>(arow16, bp3, bstride3, G16, acc);
+        else if (nct == 2) ch_mma16x3<1, 2>(arow16, bp3, bstride3, G16, acc);
+        else ch_mma16x3<1, 1>(arow16, bp3, bstride3, G16, acc);
+      } else if (ANY16 && st.prec != 0) {
         const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
         const uint4* bp16 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 64 + lane;
         const int G16 = st.K >> 4;
@@ -746,17 +900,17 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        default: ch_epilogue<NUDF_CH_UDFHEAD, ANY16>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
       }
     }
     if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -812,7 +966,7 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   for (int i = 0; i < p.n_steps && !bad; ++i) {
     const NudfChainStep& s = p.step[i];
     bad = (s.K & 15) || s.K <= 0 || s.K > 288 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
-          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 2 ||
+          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 3 ||
           ((s.layout & NUDF_CH_STATE16) && s.epi != NUDF_CH_SOFTPLUS && s.epi != NUDF_CH_MULSP &&
            s.epi != NUDF_CH_TANGENT && s.epi != NUDF_CH_BWD) ||
           ((s.layout & NUDF_CH_P4_X1) && s.epi != NUDF_CH_MULMASK && s.epi != NUDF_CH_ADDMASK) ||
@@ -824,9 +978,16 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     return (int)hipErrorInvalidValue;
   }
   hipStream_t st = (hipStream_t)stream;
-  bool any16 = false;
-  for (int i = 0; i < p.n_steps; ++i)
-    any16 = any16 || p.step[i].prec != 0 || (p.step[i].layout & (NUDF_CH_STATE16 | NUDF_CH_P4_X1 | NUDF_CH_P4_C1));
+  bool any16 = false, any3 = false;
+  for (int i = 0; i < p.n_steps; ++i) {
+    any3 = any3 || p.step[i].prec == 3;
+    any16 = any16 || (p.step[i].prec != 0 && p.step[i].prec != 3) ||
+            (p.step[i].layout & (NUDF_CH_STATE16 | NUDF_CH_P4_X1 | NUDF_CH_P4_C1));
+  }
+  if (any3 && any16) {
+    nudf_set_error("nudf_mlp_chain: bf16x3 steps (prec 3) do not mix with 16-bit steps / 16-bit stored state", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
   // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of
   // that kernel is 1024 waves = 32 768 points, so it is chosen when the last round is at least ~80 % full; the
   // up-sampling rounds (5-8 k points) and awkward sizes keep the workgroup-shared tiles below.
@@ -861,17 +1022,19 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   }
   // NUDF_CHAIN_PAIR=2: paired tiles (mlp_chain_pair_kernel, reached through the transposed-product launcher) for every
   // fp32 launch of at least 32 768 points that meets that kernel's contract -- a measured counter-example, off by default
-  if (p.tile_rows == 0 && p.P >= 32768 && !any16 && nudf_chain_pair_mode() >= 2) {
+  if (p.tile_rows == 0 && p.P >= 32768 && !any16 && !any3 && nudf_chain_pair_mode() >= 2) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0) return nudf_mlp_chain_tq_launch(p, cls, st);
   }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {
-    if (any16) hipLaunchKernelGGL((mlp_chain_kernel<32, true>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((mlp_chain_kernel<32, false>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
+    if (any3) hipLaunchKernelGGL((mlp_chain_kernel<32, 2>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
+    else if (any16) hipLaunchKernelGGL((mlp_chain_kernel<32, 1>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((mlp_chain_kernel<32, 0>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
   } else {
-    if (any16) hipLaunchKernelGGL((mlp_chain_kernel<64, true>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((mlp_chain_kernel<64, false>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    if (any3) hipLaunchKernelGGL((mlp_chain_kernel<64, 2>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    else if (any16) hipLaunchKernelGGL((mlp_chain_kernel<64, 1>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((mlp_chain_kernel<64, 0>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
   }
   NUDF_CHECK_LAUNCH("nudf_mlp_chain");
   return 0;

@@ -426,6 +426,21 @@ __device__ __forceinline__ void frag_store(const NudfPackFrag& f, int o, int c, 
     const int g = k >> 3, r = k & 7;
     const int lane = 32 * (r >> 2) + (n & 31);
     f.dst[((size_t)(g * NT + (n >> 5)) * 64 + lane) * 4 + (r & 3)] = w;
+  } else if (f.dtype == 3) {
+    // bf16x3 split fragments (fp32 emulated on the bf16 matrix pipe): w = hi + mid + lo EXACTLY, each part the bf16
+    // nearest to what the previous parts left (w has 24 significant bits, a round-to-nearest part takes 8 and leaves a
+    // remainder of at most 16, then 8 bits).  The three planes of a (k group, column tile) are stored back to back:
+    // dst16[(((g*NT + T)*3 + plane)*64 + lane)*8 + j].
+    const int g = k >> 4, r = k & 15;
+    const int lane = 32 * (r >> 3) + (n & 31);
+    const __bf16 hi = (__bf16)w;
+    const float r1 = w - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(f.dst) + ((size_t)(g * NT + (n >> 5)) * 3 * 64 + lane) * 8 + (r & 7);
+    d16[0] = __builtin_bit_cast(unsigned short, hi);
+    d16[512] = __builtin_bit_cast(unsigned short, mid);
+    d16[1024] = __builtin_bit_cast(unsigned short, lo);
   } else {   // 16-bit fragments of v_mfma_f32_32x32x16_{f16,bf16}
     const int g = k >> 4, r = k & 15;
     const int lane = 32 * (r >> 3) + (n & 31);

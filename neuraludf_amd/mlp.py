@@ -187,7 +187,7 @@ def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
     a.C, a.ldc = ptr(C), C.shape[1]
     a.dbias = ptr(dbias)
     a.M, a.NA, a.NB, a.rows_per_block = M, NA, NB, 0
-    a.prec = 0 if PRECISION == "fp32" else 2
+    a.prec = _tn_prec()
     if PROFILE is not None:
         _timed("gemm_tn", 2.0 * M * NA * NB * (2 if A2 is not None else 1), lambda: call("nudf_gemm_tn", a))
         return
@@ -371,7 +371,7 @@ def gemm_tn_grouped(jobs, M):
         chunk = jobs[base:base + _lib.TN_MAX_PROBLEMS]
         g = _lib.GemmTNGroup()
         g.n_problems, g.M, g.rows_per_block = len(chunk), M, 0
-        g.prec = 0 if PRECISION == "fp32" else 2       # mixed16: bf16 operands for the weight gradients as well
+        g.prec = _tn_prec()                            # mixed16: bf16 operands for the weight gradients as well
         flops = nbytes = 0.0
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
@@ -509,8 +509,20 @@ class PackedLinear:
 # input gradient, colour), bf16 operands in the backward sweeps (tiny adjoints need fp32's exponent range), fp32
 # accumulation, fp32 activations / stored state / epilogues / weight gradients / optimizer.  The abs-head column
 # (the UDF value itself) stays in fp32.
-PRECISION = os.environ.get("NUDF_PRECISION", "fp32")
-_PREC = {"f32": 0, "f16": 1, "bf16": 2}
+# "bf16x3": fp32 EMULATED on the bf16 matrix pipe (NudfChainStep.prec = 3): weights and activations split exactly into
+# three bf16 parts, six partial products per fp32 product, fp32 accumulation -- fp32-level accuracy (the dropped terms are
+# the size of one fp32 rounding) at 12 instead of 32 matrix-pipe cycles per k; state, epilogues, optimizer: fp32.
+PRECISION = os.environ.get("NUDF_PRECISION", "bf16x3")
+_PREC = {"f32": 0, "f16": 1, "bf16": 2, "bf16x3": 3}
+TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too
+
+
+def _tn_prec():
+    if PRECISION == "fp32":
+        return 0
+    if PRECISION == "bf16x3":
+        return 3 if TN_SPLIT else 0
+    return 2
 
 
 # 16-bit mode: the UDF engine's saved-for-backward arrays (X, DA, R, EX, ABAR) are stored as bf16 -- half the HBM
@@ -529,13 +541,13 @@ def _state_blocked(P):
 
 
 def _state_dtype():
-    return torch.bfloat16 if (PRECISION != "fp32" and STATE16) else torch.float32
+    return torch.bfloat16 if (PRECISION == "mixed16" and STATE16) else torch.float32
 
 
 def set_precision(name):
     global PRECISION
-    if name not in ("fp32", "mixed16"):
-        raise ValueError("precision must be 'fp32' or 'mixed16'")
+    if name not in ("fp32", "mixed16", "bf16x3"):
+        raise ValueError("precision must be 'fp32', 'bf16x3' or 'mixed16'")
     PRECISION = name
 
 
@@ -543,6 +555,8 @@ def _sweep_dtype(sweep):
     """operand dtype of a sweep: 'fwd' (value / input-gradient / colour forward) or 'bwd' (tangent / adjoint)."""
     if PRECISION == "fp32":
         return "f32"
+    if PRECISION == "bf16x3":
+        return "bf16x3"
     return "f16" if sweep == "fwd" else "bf16"
 
 
@@ -585,6 +599,7 @@ def pack_group(layers, kinds=None):
     kinds = kinds or [()] * len(layers)
     dev = layers[0].params()[0].device
     stale = False
+    kinds = [tuple(dict.fromkeys(ks)) for ks in kinds]     # (bf16x3: the forward and backward sweeps share one dtype)
     for pl, ks in zip(layers, kinds):
         ps = pl.params()
         ver = tuple((p.data_ptr(), p._version) for p in ps[:-1])
@@ -617,7 +632,7 @@ def pack_group(layers, kinds=None):
                 f = pl._frags.get(kind)
                 if f is None:
                     nfl = k8(K) // 8 * ((N + 31) // 32) * 256          # fp32 fragments; 16-bit ones take half
-                    f = torch.zeros(nfl if dtype == 0 else nfl // 2, device=dev, dtype=torch.float32)
+                    f = torch.zeros({0: nfl, 3: 3 * (nfl // 2)}.get(dtype, nfl // 2), device=dev, dtype=torch.float32)
                     f.k_true, f.n_true, f.prec = K, N, dtype
                     pl._frags[kind] = f
                 F = L.frag[fi]

@@ -32,7 +32,8 @@ from .. import dist as nudf_dist
 # double like torch's CPU cumprod / cumsum; 1024 = NUDF_UP_NOCONTRACT, no floating-point contraction (separate torch ops
 # round separately).  Together they reproduce the CPU reference's weights on rays that miss the surface, whose pdf sits on
 # sample_pdf's 1e-5 floor and turns 1e-7 of scan noise into 1 % (profiles/r03_parity_localisation.txt).  NUDF_UP_FLAGS=0
-# restores the wave-parallel fp32 scans of rounds 1-2 (what the same ops do on a GPU).
+# restores the wave-parallel fp32 scans of rounds 1-2 (what the same ops do on a GPU).  2048 = NUDF_UP_SLEEF: sigmoid as
+# torch's CPU kernel forms it (Sleef expf u10 restated bit for bit + a true division).
 UPSAMPLE_FLAGS = int(os.environ.get("NUDF_UP_FLAGS", str(512 | 1024)))
 
 _DIAG = ["alpha", "alpha_plus", "alpha_minus", "vis_prob", "alpha_occ", "raw_occ", "true_cos", "grad_mag", "mid_z",
@@ -299,7 +300,8 @@ class UDFRendererBlending:
         call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z), ptr(sample_dist), N, M, 0, ptr(pts))
         return self.udf_network.udf_only(pts).reshape(N, M)
 
-    def _upsample(self, rays_o, rays_d, z, udf, sample_dist, k, mode, inv_s, beta, gamma, gamma_dev=None):
+    def _upsample(self, rays_o, rays_d, z, udf, sample_dist, k, mode, inv_s, beta, gamma, gamma_dev=None, dbg=None):
+        """`dbg`: optional [N, 7, M] device tensor for the kernel's per-section intermediates (include/nudf.h)."""
         N, M = z.shape
         dev = z.device
         a = Upsample()
@@ -309,7 +311,7 @@ class UDFRendererBlending:
         a.inv_s, a.beta, a.gamma = float(inv_s), float(beta), float(gamma)
         z_new = torch.empty(N, k, device=dev)
         pts_new = torch.empty(N * k, 3, device=dev)
-        a.z_new, a.pts_new = ptr(z_new), ptr(pts_new)
+        a.z_new, a.pts_new, a.dbg = ptr(z_new), ptr(pts_new), ptr(dbg)
         call("nudf_upsample", a)
         return z_new, pts_new
 

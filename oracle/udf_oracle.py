@@ -302,12 +302,14 @@ def excl_cumprod(x: Tensor) -> Tensor:
     return torch.cumprod(torch.cat([one, x], -1), -1)[:, :-1]
 
 
-def sample_pdf_det(bins: Tensor, weights: Tensor, k: int) -> Tensor:
-    """sample_pdf(..., det=True)  (udf_renderer_blending.py:66-104)."""
+def sample_pdf_det(bins: Tensor, weights: Tensor, k: int, dbg: Optional[dict] = None) -> Tensor:
+    """sample_pdf(..., det=True)  (udf_renderer_blending.py:66-104).  `dbg`: receives the intermediates (tests only)."""
     w = weights + 1e-5
     pdf = w / torch.sum(w, -1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if dbg is not None:
+        dbg.update(w_sum=torch.sum(w, -1), pdf=pdf, cdf=cdf)
     u = torch.linspace(0.5 / k, 1.0 - 0.5 / k, steps=k).expand(list(cdf.shape[:-1]) + [k]).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = (inds - 1).clamp(min=0)
@@ -322,8 +324,9 @@ def sample_pdf_det(bins: Tensor, weights: Tensor, k: int) -> Tensor:
     return b0 + t * (b1 - b0)
 
 
-def up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k, inv_s, beta, gamma, kind="numerical") -> Tensor:
-    """udf_renderer_blending.py:197-272 -> new z [N,k]."""
+def up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k, inv_s, beta, gamma, kind="numerical",
+                     dbg: Optional[dict] = None) -> Tensor:
+    """udf_renderer_blending.py:197-272 -> new z [N,k].  `dbg`: receives the per-section intermediates (tests only)."""
     n, m = z.shape
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z[..., :, None]
     radius = torch.linalg.norm(pts, ord=2, dim=-1)
@@ -348,7 +351,9 @@ def up_sample_unbias(rays_o, rays_d, z, udf, sample_dist, k, inv_s, beta, gamma,
     a_m = sdf2alpha(-mid_udf, cos_val, dists, inv_s, kind=kind)
     alpha = a_p * sp + a_m * (1 - sp)
     w = alpha * excl_cumprod(1.0 - alpha + 1e-7)
-    return sample_pdf_det(z, w, k)
+    if dbg is not None:
+        dbg.update(cos_val=cos_val, vis=sp, alpha_plus=a_p, alpha_minus=a_m, alpha=alpha, weights=w)
+    return sample_pdf_det(z, w, k, dbg)
 
 
 def up_sample_no_occ_aware(z, udf, sample_dist, k, beta, gamma) -> Tensor:

@@ -10,3 +10,20 @@ for p in (ROOT, HERE):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _restore_mlp_precision():
+    """tests switch the MFMA operand mode (mlp.set_precision); whatever a test leaves behind, the next one starts from the
+    mode this process was started with (the library default bf16x3, or NUDF_PRECISION)."""
+    try:
+        from neuraludf_amd import mlp
+    except Exception:          # pragma: no cover - the package always imports (no GPU needed for that)
+        yield
+        return
+    old = mlp.PRECISION
+    yield
+    mlp.PRECISION = old

@@ -1,0 +1,163 @@
+"""The bf16x3 operand mode (mlp.PRECISION = "bf16x3", the library default; NudfChainStep.prec / NudfGemmTNGroup.prec = 3):
+fp32 products EMULATED on the bf16 matrix pipe -- both operands split exactly into three bf16 parts, six partial products,
+fp32 accumulation.  The claim to hold up is "fp32-level accuracy", so every quantity is measured against a FLOAT64
+evaluation of the same network (the oracle run in double) next to the exact-fp32 MFMA kernels:
+
+  * UDF value, features, d udf / d x at 4 096 points: the error of the bf16x3 chains against float64 is no larger than
+    1.5x the error of the exact-fp32 chains (it is smaller on most quantities: the dropped partial products are bounded
+    by 2^-23 |x| |y|, one fp32 rounding, and the accumulation is the same fp32);
+  * every chain output and all parameter gradients of the full backward (second order included): bf16x3 against exact
+    fp32 -- 3e-5 in the max norm on the smooth (softplus) network, the ReLU networks' gradients in the 2-norm;
+  * the weight-gradient GEMM at ragged widths: split-image kernel (gemm_tn3_group_kernel), the generic kernel's
+    split-on-the-way-out loop and the exact fp32 kernel against the float64 contraction;
+  * the split itself: hi + mid + lo == x bit for bit, on the packed weight planes the chains read.
+
+(The parity tests proper -- tests/test_gpu_fullsize_parity.py and friends, against fixtures the reference produced -- run
+in this mode by default, with unchanged tolerances.)"""
+import numpy as np
+import pytest
+import torch
+
+from common import build_modules, perturb_, state_dicts, oracle_nets
+from oracle import udf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _err(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    return float((a - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
+
+
+def test_chain_outputs_against_float64(dev):
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = perturb_(build_modules(fields, seed=0))
+    sds = state_dicts(mods)
+    udf = mods["udf"].to(dev)
+    eng = udf.engine()
+    P = 4096
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(P, 3, generator=g) * 2 - 1
+    n64 = oracle_nets(sds, dtype=torch.float64)
+    with torch.no_grad():
+        ref = O.udf_forward(n64.udf, x.double())
+    gref = O.udf_gradient(n64.udf, x.double(), create_graph=False)
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        mlp.set_precision(mode)
+        eng.invalidate() if hasattr(eng, "invalidate") else None
+        xd = x.to(dev)
+        st = eng.forward(xd, need_grad_state=True, feat_ld=288)
+        gr, _ = eng.gradient(xd, st)
+        torch.cuda.synchronize()
+        res[mode] = dict(udf=_err(st["udf"][:P].reshape(-1), ref[:, 0]), feat=_err(st["feat"][:P, :256], ref[:, 1:]),
+                         grad=_err(gr[:P], gref))
+    print("max error / max|ref| against float64:", res)
+    for k in ("udf", "feat", "grad"):
+        assert res["bf16x3"][k] <= 1.5 * res["fp32"][k] + 1e-8, (k, res)
+        assert res["bf16x3"][k] < 2e-5, (k, res)
+
+
+def test_full_backward_parameter_gradients_match_exact_fp32(dev):
+    """every chain launch of a train step's MLP work (tests/chain_sweeps.py): values and all parameter gradients of the
+    bf16x3 mode against the exact-fp32 kernels."""
+    import chain_sweeps as CS
+    from neuraludf_amd import mlp
+    outs = {}
+    for mode in ("fp32", "bf16x3"):
+        mlp.set_precision(mode)
+        outs[mode] = {k: v.detach().float().clone() for k, v in CS.sweeps(dev, 8192, 0, seed=3).items()}
+        torch.cuda.synchronize()
+    a, b = outs["fp32"], outs["bf16x3"]
+    assert set(a) == set(b)
+    # The UDF network is smooth (softplus): max-norm.  The colour net and the NeRF are ReLU networks: a pre-activation within
+    # an ulp of zero takes the other branch in one of the two modes (a handful of the ~10^7 unit evaluations here), which
+    # changes that point's gradient by a finite amount in EITHER direction -- fp32 summation orders differ from each other
+    # in the same way -- so everything downstream of a ReLU mask is held in the 2-norm, plus a bound on how many elements
+    # moved at all.
+    smooth = {"udf", "sign", "feat", "X4", "X8", "g", "DA0", "DA3", "DA7", "uo"}
+    worst = ("", 0.0)
+    for k in a:
+        if a[k].dtype != torch.float32 or a[k].numel() == 0:
+            continue
+        d = (a[k] - b[k]).double()
+        if k in smooth:
+            e = float(d.abs().max() / a[k].abs().max().clamp(min=1e-30))
+        else:
+            e = float(d.norm() / a[k].double().norm().clamp(min=1e-30))
+            moved = float((d.abs() > 1e-3 * a[k].abs().max()).double().mean())
+            assert moved < 2e-4, (k, moved)
+        if e > worst[1]:
+            worst = (k, e)
+        # (3e-3: the bound tests/test_gpu_chain_rows.py holds the exact-fp32 kernels to AGAINST EACH OTHER on these tensors)
+        assert e < (3e-5 if k in smooth else 3e-3), (k, e)
+    print("largest relative difference bf16x3 vs exact fp32:", worst)
+
+
+@pytest.mark.parametrize("M", [333, 4096])
+def test_weight_gradient_gemm_against_float64(dev, M):
+    from neuraludf_amd import mlp, _lib
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 256), (217, 256), (256, 40), (3, 128), (129, 72), (1, 256)]
+    ops = []
+    for NA, NB in shapes:
+        lda, ldb = (NA + 3) // 4 * 4, (NB + 3) // 4 * 4
+        A = torch.randn(M, lda, generator=g) * torch.exp(torch.randn(1, lda, generator=g))      # columns of mixed scale
+        B = torch.randn(M, ldb, generator=g)
+        ops.append((A, B, NA, NB))
+    ref = [((A[:, :NA].double().t() @ B[:, :NB].double()), A[:, :NA].double().sum(0)) for A, B, NA, NB in ops]
+
+    def run(mode, flags=0):
+        mlp.set_precision(mode)
+        old = _lib.lib().nudf_set_tn_flags(flags)
+        try:
+            jobs = [(A.to(dev), NA, B.to(dev), NB, torch.zeros(mlp.pad32(NA), B.shape[1], device=dev),
+                     torch.zeros(mlp.pad32(NA), device=dev)) for A, B, NA, NB in ops]
+            mlp.gemm_tn_grouped(jobs, M)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().nudf_set_tn_flags(old)
+        return [(_err(j[4][:NA, :NB], r[0]), _err(j[5][:NA], r[1])) for j, (A, B, NA, NB), r in zip(jobs, ops, ref)]
+
+    e32 = run("fp32")
+    e3 = run("bf16x3")                 # split-image kernel
+    e3g = run("bf16x3", flags=512)     # generic kernel, split on the way out of the fp32 image
+    print("C error vs float64, exact fp32 / split image / generic split:", [(round(a[0] * 1e7, 2), round(b[0] * 1e7, 2), round(c[0] * 1e7, 2))
+                                                                          for a, b, c in zip(e32, e3, e3g)], "x 1e-7")
+    for (c32, b32), (c3, b3), (c3g, b3g) in zip(e32, e3, e3g):
+        assert c3 <= 1.5 * c32 + 2e-7 and c3g <= 1.5 * c32 + 2e-7, (c32, c3, c3g)
+        assert b3 <= 1.5 * b32 + 2e-7 and b3g <= 1.5 * b32 + 2e-7       # bias sums: fp32 additions of the unsplit values
+
+
+def test_packed_weight_planes_sum_to_the_weight_bit_for_bit(dev):
+    """NudfPackFrag.dtype 3: the three bf16 planes of a fragment-ordered weight copy add up to the fp32 weight exactly."""
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = build_modules(fields, seed=0)
+    udf = mods["udf"].to(dev)
+    mlp.set_precision("bf16x3")
+    eng = udf.engine()
+    x = torch.rand(64, 3, device=dev)
+    eng.forward(x, need_grad_state=False, udf_only=True)            # packs the weights
+    pl = eng.layers[2]
+    f3 = pl._frags["fwd@bf16x3"]
+    K, N = pl.inp, pl.out
+    NT = (N + 31) // 32
+    G16 = mlp.k8(K) // 16
+    planes = f3.view(torch.int16).reshape(G16, NT, 3, 64, 8)
+    w = (planes.to(torch.int32) << 16).view(torch.float32)           # bf16 -> fp32, exact
+    total = (w[:, :, 0] + w[:, :, 1]) + w[:, :, 2]                   # hi + mid exact (<= 16 bits), + lo exact (24 bits)
+    # element (g, T, lane, j) <-> B[16 g + 8 (lane >> 5) + j][32 T + (lane & 31)], B = W^T
+    Wt = pl.Wt[:K, :N]
+    ref = torch.zeros(G16 * 16, NT * 32, device=dev)
+    ref[:K, :N] = Wt
+    ref = ref.reshape(G16, 2, 8, NT, 32).permute(0, 3, 1, 4, 2).reshape(G16, NT, 64, 8)
+    assert torch.equal(total, ref)
+    assert float(w[:, :, 1].abs().max()) > 0 and float(w[:, :, 2].abs().max()) > 0

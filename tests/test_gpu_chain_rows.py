@@ -21,6 +21,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _exact_fp32_mode():
+    """these are statements about the exact-fp32 MFMA kernels (mlp.PRECISION = "fp32": bit-identity between the three
+    fp32 chain kernels, the blocked state layout, the paired tiles); the library default is the bf16x3 mode
+    (tests/test_gpu_bf16x3.py).  conftest restores the mode after every test."""
+    from neuraludf_amd import mlp
+    mlp.set_precision("fp32")
+    yield
+
+
 @pytest.mark.parametrize("P", [1, 31, 33, 97, 128, 129, 1000, 4133])
 def test_rows_kernel_matches_shared_kernel_ragged_sizes(dev, P):
     a = sweeps(dev, P, 64, seed=P)
