@@ -966,6 +966,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
 // in flight under step k's 48 MFMAs per wave, the split + LDS stores sit between two barriers, and the co-resident
 // workgroups of the CU (2-3) run their MFMA phases meanwhile.
 // =======================================================================================================
+#ifndef NUDF_TN3_DIST2
+#define NUDF_TN3_DIST2 1
+#endif
 #define BK3 32
 #define LD3 132
 #define T3 (16 * LD3)
@@ -1083,27 +1086,46 @@ __global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
       }
     }
   };
+  // the operand rows of k-step kt + 2 are requested before step kt's MFMAs (two staging sets): a panel's first reader
+  // among the tiles of its XCD pays an HBM round trip, which is longer than one step's 48 MFMAs per wave
+  f32x4 sa2[2][2], sb2[2][2];
   if (nk > 0) {
     load(pa, pa2, rowa, sa, 0);
     load(pb, pb2, rowb, sb, 0);
+    if (nk > 1) {
+      load(pa, pa2, rowa, sa2, 1);
+      load(pb, pb2, rowb, sb2, 1);
+    }
     store(sa, 0, As, do_bias);
     store(sb, 0, Bs, false);
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      load(pa, pa2, rowa, sa, kt + 1);
-      load(pb, pb2, rowb, sb, kt + 1);
+  auto kstep = [&](int kt, f32x4 (&la)[2][2], f32x4 (&lb)[2][2], f32x4 (&ua)[2][2], f32x4 (&ub)[2][2]) {
+    // la / lb: free set, receives step kt + 2; ua / ub: holds step kt + 1 (requested one step ago), stored after the MFMAs
+#if NUDF_TN3_DIST2
+    if (kt + 2 < nk) {
+      load(pa, pa2, rowa, la, kt + 2);
+      load(pb, pb2, rowb, lb, kt + 2);
     }
+#else      // A/B: requests one step ahead only (into the set that is stored after this step's MFMAs)
+    if (kt + 1 < nk && kt > 0) {
+      load(pa, pa2, rowa, ua, kt + 1);
+      load(pb, pb2, rowb, ub, kt + 1);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
     mma();
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                     // every wave is done reading the image
     if (kt + 1 < nk) {
-      store(sa, kt + 1, As, do_bias);
-      store(sb, kt + 1, Bs, false);
+      store(ua, kt + 1, As, do_bias);
+      store(ub, kt + 1, Bs, false);
     }
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, sa, sb, sa2, sb2);
+    if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb);
   }
 
   if (g.dbg && tid == 0) {

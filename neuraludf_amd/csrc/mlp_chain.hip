@@ -282,61 +282,92 @@ __device__ __forceinline__ void ch_split3(const f32x4& lo4, const f32x4& hi4, bf
   p1 = __builtin_bit_cast(bf16x8, b);
   p2 = __builtin_bit_cast(bf16x8, c);
 }
+#ifndef NUDF_X3_PIPE
+#define NUDF_X3_PIPE 0      // A/B build switch: 1 = the next step's split interleaved with this step's MFMAs (measured slower:
+                            // 4.63 vs 4.44 ms per step -- two in-phase waves per SIMD already cover each other's split)
+#endif
 template <int NRT, int NCT>
 __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride3,
                                            int G16, f32x16 (&acc)[2][2]) {
   // bptr: this lane's uint4 of plane 0 of column tile ct0 in k step 0; planes 64 uint4 apart, column tiles 192, k steps
-  // bstride3 = 3 * NT * 64
-  f32x4 a0[NRT][2], a1[NRT][2];
-  uint4 b0[NCT][3], b1[NCT][3];
-  auto lda = [&](f32x4 (&a)[NRT][2], int g) {
+  // bstride3 = 3 * NT * 64.
+  // Software pipeline: the split of step g + 1's activations (VALU) is interleaved with step g's MFMAs, four VALU
+  // operations behind every MFMA (sched_group_barrier pins the pattern) -- a wave that runs the split in front of its MFMAs
+  // leaves the matrix pipe to its partner alone for ~350 cycles per step, and with both workgroups of a CU in phase that
+  // is idle time (measured: forward sweep 436 us back to back).
+  f32x4 raw[NRT][2];
+  bf16x8 pa[2][NRT][3];
+  uint4 b[2][NCT][3];
+  auto lda = [&](int g) {
 #pragma unroll
     for (int i = 0; i < NRT; ++i) {
-      a[i][0] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16);
-      a[i][1] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16 + 4);
+      raw[i][0] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16);
+      raw[i][1] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16 + 4);
     }
   };
-  auto ldb = [&](uint4 (&b)[NCT][3], int g) {
+  auto ldb = [&](uint4 (&bb)[NCT][3], int g) {
     const uint4* bq = bptr + (size_t)g * bstride3;
 #pragma unroll
     for (int j = 0; j < NCT; ++j)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[j][pl] = bq[j * 192 + pl * 64];
+      for (int pl = 0; pl < 3; ++pl) bb[j][pl] = bq[j * 192 + pl * 64];
   };
-  auto mma = [&](f32x4 (&a)[NRT][2], uint4 (&b)[NCT][3]) {
-    bf16x8 ah[NRT], am[NRT], al[NRT];
+  auto split = [&](bf16x8 (&q)[NRT][3]) {
 #pragma unroll
-    for (int i = 0; i < NRT; ++i) ch_split3(a[i][0], a[i][1], ah[i], am[i], al[i]);
-    // smallest terms first; (A part, B plane) pairs
+    for (int i = 0; i < NRT; ++i) ch_split3(raw[i][0], raw[i][1], q[i][0], q[i][1], q[i][2]);
+  };
+  auto mfmas = [&](const bf16x8 (&q)[NRT][3], const uint4 (&bb)[NCT][3]) {
+    // smallest terms first; (A part, B plane) pairs: hi lo, lo hi, mid mid, hi mid, mid hi, hi hi
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int i = 0; i < NRT; ++i)
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
-          const bf16x8 av = (t == 0 || t == 3 || t == 5) ? ah[i] : ((t == 1) ? al[i] : am[i]);          // h l m h m h
-          const uint4 bv = (t == 0) ? b[j][2] : ((t == 2 || t == 3) ? b[j][1] : b[j][0]);              // l h m m h h
+          const bf16x8 av = (t == 0 || t == 3 || t == 5) ? q[i][0] : ((t == 1) ? q[i][2] : q[i][1]);
+          const uint4 bv = (t == 0) ? bb[j][2] : ((t == 2 || t == 3) ? bb[j][1] : bb[j][0]);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
         }
   };
-  lda(a0, 0);
-  ldb(b0, 0);
+  auto pattern = [&]() {
+#if NUDF_X3_PIPE
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRT, 0);     // the next step's LDS reads ...
+    __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCT, 0);     // ... and weight loads first
+#pragma unroll
+    for (int m = 0; m < 6 * NRT * NCT; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (44 * NRT + 6 * NRT * NCT - 1) / (6 * NRT * NCT), 0);
+    }
+#endif
+  };
+  const int gl = G16 - 1;
+  lda(0);
+  ldb(b[0], 0);
+  split(pa[0]);
   int g = 0;
 #pragma unroll 1
-  for (; g + 1 < G16; g += 2) {
-    lda(a1, g + 1);
-    ldb(b1, g + 1);
+  for (; g + 2 <= G16; g += 2) {
     __builtin_amdgcn_sched_barrier(0);
-    mma(a0, b0);
+    lda(min(g + 1, gl));
+    ldb(b[1], min(g + 1, gl));
+#if !NUDF_X3_PIPE
     __builtin_amdgcn_sched_barrier(0);
-    const int gn = (g + 2 < G16) ? g + 2 : g + 1;
-    lda(a0, gn);
-    ldb(b0, gn);
+#endif
+    mfmas(pa[0], b[0]);
+    split(pa[1]);
+    pattern();
     __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1);
+    lda(min(g + 2, gl));
+    ldb(b[0], min(g + 2, gl));
+#if !NUDF_X3_PIPE
     __builtin_amdgcn_sched_barrier(0);
+#endif
+    mfmas(pa[1], b[1]);
+    split(pa[0]);
+    pattern();
   }
-  if (g < G16) mma(a0, b0);   // odd number of 16-wide k steps
+  __builtin_amdgcn_sched_barrier(0);
+  if (g < G16) mfmas(pa[0], b[0]);   // odd number of 16-wide k steps
 }
 
 // 16-bit stored state, 4-point packed (ch_p4_off): the 16 accumulator rows of a lane are 4 groups of 4 consecutive
@@ -617,13 +648,16 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
   }
 }
 
+#ifndef NUDF_X3_EPI_AHEAD
+#define NUDF_X3_EPI_AHEAD 2  // A/B build switch: tiles the epilogue's stored operands are requested ahead (1 = as the fp32 kernels)
+#endif
 // bf16x3 mode (fp32 stored state, no operand prefetch under the K loop: the split needs those registers): BOTH stored
 // operands of tile t + 1 are requested before tile t is computed and stored, as in ch_epilogue_seq16.
 template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
                                                   int ln, f32x16 (&acc)[2][2]) {
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
-  float xa[2][16], xb[2][16];
+  float xa[NUDF_X3_EPI_AHEAD + 1][16], xb[NUDF_X3_EPI_AHEAD + 1][16];
   auto issue = [&](float (&a1)[16], float (&a2)[16], int i, int j) {
     const int col = (ct0 + j) * 32 + ln;
     const unsigned colc = (unsigned)((col < st.N) ? col : 0);
@@ -645,12 +679,18 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
     }
   };
   constexpr int NTL = NRT * NCT;
-  issue(xa[0], xb[0], 0, 0);
+  // Stored operands requested AHEAD tiles in advance (ring of AHEAD + 1 register sets).  The K loop's operand registers
+  // are dead here (this mode prefetches nothing under the K loop), so there is room for more than the one tile of the
+  // fp32 kernels: per-wave timelines showed the tangent epilogue at 32 k cycles per layer against 25 k for the K loop --
+  // one exposed HBM round trip per tile.  (All four tiles up front = 128 registers: 33 spilled.)
+  constexpr int AH = (NUDF_X3_EPI_AHEAD < NTL) ? NUDF_X3_EPI_AHEAD : NTL - 1;
+#pragma unroll
+  for (int t = 0; t < AH; ++t) issue(xa[t % (AH + 1)], xb[t % (AH + 1)], t / NCT, t % NCT);
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
-    if (t + 1 < NTL) issue(xa[(t + 1) & 1], xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
-    ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t & 1], false,
-                                xb[t & 1]);
+    if (t + AH < NTL) issue(xa[(t + AH) % (AH + 1)], xb[(t + AH) % (AH + 1)], (t + AH) / NCT, (t + AH) % NCT);
+    ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
+                                xb[t % (AH + 1)]);
   }
 }
 

@@ -339,9 +339,9 @@ class ChainBuilder:
         elif self.c.tile_rows == 128:
             kern = "mlp_chain_rows_kernel"
         else:
-            any16 = PRECISION != "fp32"
+            mode = {"fp32": 0, "mixed16": 1, "bf16x3": 2}[PRECISION]
             t32 = self.c.tile_rows == 32 or (self.c.tile_rows != 64 and P <= 256 * 64)
-            kern = "mlp_chain_kernel<%d, %s>" % (32 if t32 else 64, "true" if any16 else "false")
+            kern = "mlp_chain_kernel<%d, %d>" % (32 if t32 else 64, mode)
         sweep = ("tangent" if "TANGENT" in e else "adjoint" if "BWD" in e else "input-gradient" if "MULSP" in e
                  else "relu-backward" if e & {"MULMASK", "ADDMASK"} else "udf-forward" if "SOFTPLUS" in e
                  else "relu-forward")
@@ -537,6 +537,8 @@ BLOCKED_STATE = os.environ.get("NUDF_BLOCKED_STATE", "1") != "0"
 
 
 def _state_blocked(P):
+    # (bf16x3: measured with the split K loop ported into the transposed-product kernel -- chains 2.752 vs 2.758 ms, and the
+    # weight-gradient GEMM loses its split-image kernel on blocked operands, 1.14 -> 2.09 ms: row-major state there)
     return BLOCKED_STATE and PRECISION == "fp32" and USE_CHAIN and CHAIN_TILE in (0, 66, 130) and P > 256 * 64
 
 

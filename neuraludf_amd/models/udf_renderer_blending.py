@@ -28,13 +28,19 @@ import os
 from .._lib import Composite, CompositeGrad, Upsample, call, ptr
 from .. import dist as nudf_dist
 
-# Arithmetic of the up-sampling kernel (include/nudf.h): 512 = NUDF_UP_SERIAL, the three scans accumulated serially in
-# double like torch's CPU cumprod / cumsum; 1024 = NUDF_UP_NOCONTRACT, no floating-point contraction (separate torch ops
-# round separately).  Together they reproduce the CPU reference's weights on rays that miss the surface, whose pdf sits on
-# sample_pdf's 1e-5 floor and turns 1e-7 of scan noise into 1 % (profiles/r03_parity_localisation.txt).  NUDF_UP_FLAGS=0
-# restores the wave-parallel fp32 scans of rounds 1-2 (what the same ops do on a GPU).  2048 = NUDF_UP_SLEEF: sigmoid as
-# torch's CPU kernel forms it (Sleef expf u10 restated bit for bit + a true division).
-UPSAMPLE_FLAGS = int(os.environ.get("NUDF_UP_FLAGS", str(512 | 1024)))
+# Arithmetic of the up-sampling kernel (include/nudf.h), all four on by default -- together they reproduce the CPU
+# reference's new samples on EVERY ray of BASELINE config 2 when fed the reference's own (z, udf) (0 of 512 rays moved by
+# > 1e-4 in each of the four rounds, worst |dz| 7e-7; profiles/r04_upsample_first_diff.txt):
+#   512  = NUDF_UP_SERIAL      the three scans accumulated serially in double like torch's CPU cumprod / cumsum;
+#   1024 = NUDF_UP_NOCONTRACT  no floating-point contraction (separate torch ops round separately);
+#   2048 = NUDF_UP_SLEEF       sigmoid as torch's CPU kernel forms it (Sleef expf u10 restated bit for bit + a true
+#                              division): alpha_plus / alpha_minus become bit-identical to the reference's on all rays;
+#   4096 = NUDF_UP_EXPCR       the exp call sites (torch.exp = MKL vsExp HA on the CPU) correctly rounded: THE term that
+#                              moved rays -- on rays that miss the surface one ulp of exp is the visibility product
+#                              (first differing stage on every moved ray: vis_prob, 1-4 ulp, with libm's expf).
+# Why any of it matters: such rays' pdf sits on sample_pdf's 1e-5 floor, where 1e-7 of noise is 1 %.  NUDF_UP_FLAGS=0
+# restores the wave-parallel fp32 scans and libm transcendentals of rounds 1-2 (what the same ops do on a GPU).
+UPSAMPLE_FLAGS = int(os.environ.get("NUDF_UP_FLAGS", str(512 | 1024 | 2048 | 4096)))
 
 _DIAG = ["alpha", "alpha_plus", "alpha_minus", "vis_prob", "alpha_occ", "raw_occ", "true_cos", "grad_mag", "mid_z",
          "dists", "inside", "flip"]

@@ -92,8 +92,8 @@ def test_full_backward_parameter_gradients_match_exact_fp32(dev):
             e = float(d.abs().max() / a[k].abs().max().clamp(min=1e-30))
         else:
             e = float(d.norm() / a[k].double().norm().clamp(min=1e-30))
-            moved = float((d.abs() > 1e-3 * a[k].abs().max()).double().mean())
-            assert moved < 2e-4, (k, moved)
+            moved = int((d.abs() > 1e-3 * a[k].abs().max()).sum())
+            assert moved <= max(2, int(2e-4 * d.numel())), (k, moved, d.numel())
         if e > worst[1]:
             worst = (k, e)
         # (3e-3: the bound tests/test_gpu_chain_rows.py holds the exact-fp32 kernels to AGAINST EACH OTHER on these tensors)

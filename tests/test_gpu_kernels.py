@@ -674,9 +674,10 @@ def test_upsample_and_merge_stagewise(dev, nets, kind):
     # difference is an ulp-quantised 1e-7-ish number, so one ulp of the sigmoid moves those small weights by tens of
     # percent -- in the fp32 reference just the same -- and a few more bins flip)
     print(f"upsample stagewise [{kind}, {a_kind}]: {n_bad} of {len(trace) * 53} ray-rounds moved by > 1e-4")
-    # bound: 2.5 % of the ray-rounds (round 2 allowed 5 %; measured with the serial double-accumulator scans: 2 / 265
-    # unbias, 4 / 318 noocc); 'theorical' 8 % (measured 14 / 265)
-    assert n_bad <= max(2, len(trace) * 53 // (12 if a_kind == "theorical" else 40)), n_bad
+    # bound: 1 % of the ray-rounds (round 2 allowed 5 %, round 3 2.5 %: with the reference's transcendentals -- Sleef
+    # sigmoid, correctly rounded exp -- on top of the serial double scans the kernel reproduces the CPU reference's bins;
+    # 'theorical' 2.5 %)
+    assert n_bad <= max(1, len(trace) * 53 // (40 if a_kind == "theorical" else 100)), n_bad
 
 
 @pytest.mark.parametrize("case", ["cfg1_flat", "classical_bg", "mix", "theorical_bg", "square_bg", "idr_bg"])
