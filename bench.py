@@ -11,11 +11,13 @@ Workload (BASELINE.json configs[1]): 512 rays x 128 samples per GPU (64 coarse +
 packed loss all-reduce + one gradient all-reduce per step (weak scaling).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel of the step (the fused fp32 MFMA layer-chain kernel `mlp_chain_kernel`):
-                  algorithmic FLOPs of its launches / their summed duration, measured with HIP
-                  events on the launch stream during one extra instrumented step; peak = 157.3 TFLOP/s
-                  (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); traffic = HBM bytes per launch from the
-                  committed rocprofv3 PMC passes over this command (profiles/r02_traffic_mlp_chain.json).
+  roofline     -- the dominant kernel class of the step (the fused layer-chain kernel `mlp_chain_kernel`): flops its
+                  launches execute / their summed duration, measured with HIP events on the launch stream during one extra
+                  instrumented step.  Default mode bf16x3 (fp32 emulated on the bf16 matrix pipe, six bf16 MFMA products per
+                  fp32 product): executed flops = 6 x 2 M N K against the dense bf16 peak 2.5 PFLOP/s, with the
+                  fp32-equivalent rate beside the 157.3 TFLOP/s of the fp32 MFMA pipe (`--precision fp32`: the exact
+                  v_mfma_f32_32x32x2_f32 kernels against 157.3); traffic = HBM bytes per launch from the committed rocprofv3
+                  PMC passes over this command (profiles/r04_traffic_mlp_chain_bf16x3.json).
   roofline_composite -- the fused sample+composite kernels against the 8 TB/s HBM roof
                   (48 B/sample + 68 B/ray forward, 84 B/sample + 68 B/ray backward).
   cpu_baseline -- the reference's own classes (oracle/_ref/reference_tree, kind "reference"; the oracle's port when that
@@ -36,6 +38,13 @@ import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 (MI355X_MICROARCH.md)
+# bf16x3 (the default mode): every fp32 product is SIX bf16 MFMA products (both operands split exactly into three bf16
+# parts; hi hi, hi mid, mid hi, hi lo, lo hi, mid mid; fp32 accumulate) -- the flops a launch EXECUTES on the bf16 pipe
+X3_PRODUCTS = 6
+DTYPE = {"fp32": "f32",
+         "bf16x3": "f32 emulated on the bf16 matrix pipe: operands split exactly into 3 bf16 parts, 6 bf16 MFMA products per "
+                   "f32 product, f32 accumulate (fp32-level accuracy, tests/test_gpu_bf16x3.py); f32 state, epilogues, optimizer",
+         "mixed16": "f16/bf16 MFMA operands, f32 accumulate, bf16 saved state (config 5 mode)"}
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -388,7 +397,7 @@ def main():
         "metric": "ray-samples/sec (train step)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f16/bf16 MFMA operands, f32 accumulate, bf16 saved state (config 5 mode)",
+        "dtype": DTYPE[args.precision],
         "data": "synthetic",
         "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
@@ -445,31 +454,52 @@ def main():
             b[4] += nbytes
         dom = max(agg, key=lambda k: agg[k][2])
         n, fl, sec = agg[dom]
+        # flops the launches EXECUTE on the pipe they run on: algorithmic (2 M N K) for the fp32 and 16-bit modes, six bf16
+        # products per fp32 product in the bf16x3 mode (weight-gradient GEMMs only when they take split operands)
+        x3 = args.precision == "bf16x3"
+        factor = {k: (X3_PRODUCTS if x3 and (k != "gemm_tn" or mlp.TN_SPLIT) else 1) for k in agg}
         peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS
-        result["roofline"] = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": fl / sec / 1e12,
-                              "peak": peak, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / peak,
+        result["roofline"] = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": factor[dom] * fl / sec / 1e12,
+                              "peak": peak, "unit": "TFLOP/s", "frac": factor[dom] * fl / sec / 1e12 / peak,
                               "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
-                              "algorithmic_gflop_per_step": fl / 1e9}
+                              "algorithmic_gflop_per_step": fl / 1e9, "executed_flops_per_algorithmic_flop": factor[dom]}
+        if x3:
+            result["roofline"]["what"] = (
+                "achieved = EXECUTED bf16 MFMA flops (6 x the algorithmic fp32 flops 2 M N K) / summed HIP-event time of the "
+                "class, against the dense bf16 peak; fp32_equivalent = the algorithmic flops per second, next to the 157.3 "
+                "TFLOP/s of the fp32 MFMA pipe this mode replaces")
+            result["roofline"]["fp32_equivalent"] = {"achieved": fl / sec / 1e12, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
+                                                     "ratio": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        cls_bytes = sum(b[4] for b in per.values() if b[0] == dom)
+        result["roofline"]["vs_hbm_algorithmic"] = {"achieved": cls_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": cls_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                                                   "what": "the class's algorithmic stored-state bytes (every operand / output "
+                                                           "array of every step once) / the same time"}
         if dom == "mlp_chain":
             # the class is several instantiations in a rocprofv3 summary: sum them when comparing the average duration
-            result["roofline"]["kernel_names"] = ["mlp_chain_tq_kernel<0|1|2> (UDF sweeps, > 16384 points, fp32)",
-                                                  "mlp_chain_kernel<64|32, false|true> (all other chain launches)"]
+            result["roofline"]["kernel_names"] = (
+                ["mlp_chain_kernel<64|32, 2> (every chain launch of the bf16x3 mode)"] if x3 else
+                ["mlp_chain_tq_kernel<0|1|2> (UDF sweeps, > 16384 points, fp32)",
+                 "mlp_chain_kernel<64|32, 0|1> (all other chain launches)"])
         # every MFMA launch class of the step on its own: instantiation + sweep + size, launches, algorithmic GFLOP, summed
         # HIP-event time, and BOTH roofs -- MFMA (fp32 157.3 TFLOP/s, or 2.5 PFLOP/s for 16-bit chains) and HBM (the
         # launch's algorithmic stored-state bytes, every operand / output array once, against 8 TB/s); "binding" names the
         # larger of the two floors, i.e. the roof that launch could at best run into
         pk = []
         for detail, (name, cnt, f, t, by) in sorted(per.items(), key=lambda kv: -kv[1][3]):
-            # mixed16: chains AND weight-gradient GEMMs take bf16 / f16 MFMA operands -> the 16-bit dense peak for both
+            # executed flops against the peak of the pipe the launch runs on (bf16x3 / mixed16: the dense 16-bit peak)
             pkp = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS
-            t_mfma, t_hbm = f / (pkp * 1e12), by / (HBM_PEAK_GBS * 1e9)
-            pk.append({"kernel": detail, "class": name, "launches": cnt, "gflop": f / 1e9, "us": t * 1e6,
-                       "tflops": f / t / 1e12, "frac_mfma": f / t / 1e12 / pkp,
+            fx = f * factor.get(name, 1)
+            t_mfma, t_hbm = fx / (pkp * 1e12), by / (HBM_PEAK_GBS * 1e9)
+            pk.append({"kernel": detail, "class": name, "launches": cnt, "gflop": f / 1e9, "executed_gflop": fx / 1e9,
+                       "us": t * 1e6, "tflops": fx / t / 1e12, "frac_mfma": fx / t / 1e12 / pkp,
+                       "fp32_equivalent_tflops": f / t / 1e12,
                        "algorithmic_mb": by / 1e6, "gbs": by / t / 1e9, "frac_hbm": by / t / 1e9 / HBM_PEAK_GBS,
                        "binding": "hbm" if t_hbm > t_mfma else "mfma", "frac_of_binding_roof": max(t_mfma, t_hbm) / t})
         result["roofline"]["per_kernel"] = pk
         result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
-                                 "tflops": v[1] / v[2] / 1e12} for k, v in agg.items()}
+                                 "tflops": v[1] / v[2] / 1e12, "executed_tflops": factor[k] * v[1] / v[2] / 1e12}
+                             for k, v in agg.items()}
         result["roofline"]["traffic"] = pmc_traffic(dom, args.workload, args.precision)
         result["roofline"]["traffic_source"] = getattr(pmc_traffic, "source", None) if result["roofline"]["traffic"] else None
         if args.precision != "fp32" and result["roofline"]["traffic"]:
@@ -504,7 +534,9 @@ def pmc_traffic(kernel, workload, precision="fp32"):
     WRITE_SIZE, separate passes, scripts/pmc_traffic.sh; committed under profiles/).  rocprofv3 cannot wrap the
     timed process from inside, so the counters are collected beforehand; corrected as MI355X_MICROARCH.md
     prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
-    if (workload, precision) == ("dtu_scan24_512x128", "fp32"):
+    if (workload, precision) == ("dtu_scan24_512x128", "bf16x3"):
+        names = ["r04_traffic_%s_bf16x3.json" % kernel]
+    elif (workload, precision) == ("dtu_scan24_512x128", "fp32"):
         names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (3, 2, 1)]
     elif (workload, precision) == ("dtu_scan24_1024x256", "mixed16"):
         names = ["r%02d_traffic_%s_cfg5_mixed16.json" % (r, kernel) for r in (3, 2)]
