@@ -406,7 +406,7 @@ __device__ __forceinline__ void ch_p4_store(float* C, int ld, unsigned q0, unsig
 template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
-                                                 const float* x2in = nullptr) {
+                                                 const float* x2in = nullptr, const float* bias_pre = nullptr) {
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -414,7 +414,8 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
   const unsigned grow0 = (unsigned)(m0 + r0);
   float v[16], out[16];
   {
-    const float bias = st.bias ? st.bias[colc] : 0.0f;
+    // (bias_pre: requested by the caller before the K loop -- the load here is an exposed L2 round trip per tile)
+    const float bias = bias_pre ? *bias_pre : (st.bias ? st.bias[colc] : 0.0f);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = a[r] + bias;
   }
@@ -574,7 +575,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 // and the prefetched X1 are read from their home registers (no per-tile copies), which pays for the second buffer.
 template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
-                                                int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16]) {
+                                                int ln, f32x16 (&acc)[2][2], float (&px1)[2][2][16], const float (&bpre)[2]) {
   float xb[2][16];
   auto issue = [&](float (&x)[16], int i, int j) {
     const int col = (ct0 + j) * 32 + ln;
@@ -593,7 +594,7 @@ __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* 
   for (int t = 0; t < NTL; ++t) {
     if (t + 1 < NTL) issue(xb[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
     ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT],
-                                px1[t / NCT][t % NCT], false, xb[t & 1]);
+                                px1[t / NCT][t % NCT], false, xb[t & 1], &bpre[t % NCT]);
   }
 }
 
@@ -608,7 +609,7 @@ __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* 
 #endif
 template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
-                                                  int ln, f32x16 (&acc)[2][2]) {
+                                                  int ln, f32x16 (&acc)[2][2], const float (&bpre)[2]) {
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
   uint2 r1[2][4], r2[2][4];      // raw 4-point packs of tile t and t + 1
   auto issue = [&](uint2 (&a1)[4], uint2 (&a2)[4], int i, int j) {
@@ -644,7 +645,8 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 #pragma unroll
       for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
     }
-    ch_epilogue_tile<EPI, true, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1, false, x2);
+    ch_epilogue_tile<EPI, true, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1, false, x2,
+                                      &bpre[t % NCT]);
   }
 }
 
@@ -655,7 +657,7 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 // operands of tile t + 1 are requested before tile t is computed and stored, as in ch_epilogue_seq16.
 template <int EPI, int NRT, int NCT>
 __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
-                                                  int ln, f32x16 (&acc)[2][2]) {
+                                                  int ln, f32x16 (&acc)[2][2], const float (&bpre)[2]) {
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
   float xa[NUDF_X3_EPI_AHEAD + 1][16], xb[NUDF_X3_EPI_AHEAD + 1][16];
   auto issue = [&](float (&a1)[16], float (&a2)[16], int i, int j) {
@@ -690,7 +692,7 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
   for (int t = 0; t < NTL; ++t) {
     if (t + AH < NTL) issue(xa[(t + AH) % (AH + 1)], xb[(t + AH) % (AH + 1)], (t + AH) / NCT, (t + AH) % NCT);
     ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
-                                xb[t % (AH + 1)]);
+                                xb[t % (AH + 1)], &bpre[t % NCT]);
   }
 }
 
@@ -698,29 +700,29 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
 template <int EPI, int MODE>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
-                                            const float (&px1)[2][2][16]) {
+                                            const float (&px1)[2][2][16], const float (&bpre)[2]) {
   constexpr bool ANY16 = MODE == 1, X3 = MODE == 2;
   constexpr bool PF = CH_USES_X1(EPI);
   if constexpr (CH_USES_X2(EPI)) {
     if (!X3 && st.prec == 0 && nrt == 2 && !(ANY16 && (st.layout & NUDF_CH_STATE16))) {
       float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
-      if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1);
-      else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1);
+      if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1, bpre);
+      else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1, bpre);
       return;
     }
   }
   if constexpr (X3 && CH_USES_X1(EPI)) {
     if (st.prec == 3 && nrt * nct >= 2) {
-      if (nrt == 2 && nct == 2) ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc);
-      else if (nrt == 2) ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc);
-      else ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc);
+      if (nrt == 2 && nct == 2) ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else if (nrt == 2) ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
       return;
     }
   }
   if constexpr (ANY16 && (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
     if (NUDF_SEQ16 && (st.layout & NUDF_CH_STATE16) && nrt == 2) {
-      if (nct == 2) ch_epilogue_seq16<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc);
-      else ch_epilogue_seq16<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc);
+      if (nct == 2) ch_epilogue_seq16<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else ch_epilogue_seq16<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
       return;
     }
   }
@@ -764,12 +766,12 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
     }
     if constexpr (ANY16 && (EPI == NUDF_CH_SOFTPLUS || EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
       if (st.layout & NUDF_CH_STATE16) {
-        ch_epilogue_tile<EPI, false, true>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true);
+        ch_epilogue_tile<EPI, false, true>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true, nullptr, &bpre[j]);
         continue;
       }
     }
     constexpr bool RT16 = ANY16 && (EPI == NUDF_CH_RELU || EPI == NUDF_CH_MULMASK || EPI == NUDF_CH_ADDMASK);
-    ch_epilogue_tile<EPI, false, false, RT16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3);
+    ch_epilogue_tile<EPI, false, false, RT16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3, nullptr, &bpre[j]);
   }
 }
 
@@ -886,6 +888,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
           acc[i][j][r] = 0.0f;
           px1[i][j][r] = 0.0f;
         }
+    // this lane's bias values (column tiles ct0, ct0 + 1), requested now: they arrive under the K loop
+    float bpre[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (ct0 + j) * 32 + ln;
+      bpre[j] = st.bias ? st.bias[(col < st.N) ? col : 0] : 0.0f;
+    }
 
     if (nct > 0) {
       const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
@@ -940,17 +949,17 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
-        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1); break;
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
       }
     }
     if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
