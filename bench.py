@@ -347,7 +347,9 @@ def main():
             dist.barrier()
 
     from neuraludf_amd.train import GraphedStep
-    gstep = GraphedStep(tr, eager_steps=2) if args.graph else None
+    # a ray-sharded step (world > 1) is captured only on request (NUDF_DP_GRAPH=1): its two RCCL all-reduces capture and
+    # replay on this image (tests/test_gpu_dist.py), but no 2-GPU run has confirmed it yet -- eager is the multi-GPU default
+    gstep = GraphedStep(tr, eager_steps=2, capture_collectives=os.environ.get("NUDF_DP_GRAPH", "0") == "1") if args.graph else None
     use_graph = bool(gstep is not None and gstep.enabled)
     run_step = (lambda: gstep(batch, **step_kw)) if use_graph else (lambda: tr.step(batch, **step_kw))
     if use_graph:                      # set-up, not warm-up: two eager steps, then the capture (+ its first replay)

@@ -33,6 +33,17 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# With ONE rank every collective is the identity and is skipped.  FORCE_COLLECTIVES = True issues them anyway (the process
+# group must be initialised): what lets a one-GPU box run -- and CAPTURE in a HIP graph -- the exact launch sequence of a
+# ray-sharded step, RCCL calls included (tests/test_gpu_dist.py).
+FORCE_COLLECTIVES = False
+
+
+def exchanging() -> bool:
+    """do the collectives of a ray-sharded step run in this process?"""
+    return world_size() > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -53,7 +64,7 @@ class _AllReduceSum(torch.autograd.Function):
 
 
 def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
-    if world_size() == 1:
+    if not exchanging():
         return x
     return _AllReduceSum.apply(x)
 
@@ -112,7 +123,7 @@ class GradBucket:
         self.last_message_floats = 0
 
     def all_reduce(self):
-        if world_size() == 1 or not self.params:
+        if not exchanging() or not self.params:
             return
         # parameters that took no part in this step have grad None on EVERY rank -- the ranks run the same graph on
         # their ray shards -- and Adam skips them exactly as in the single-process step

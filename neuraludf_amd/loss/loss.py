@@ -97,7 +97,7 @@ class _ColorLossFn(torch.autograd.Function):
         m_ = mask.detach().float().contiguous() if mask is not None else None
         out = torch.empty(3, device=cb_.device)
         den = torch.empty(1, device=cb_.device)
-        if data_parallel and nudf_dist.world_size() > 1:
+        if data_parallel and nudf_dist.exchanging():
             # ray-sharded: local sums -> ONE all-reduce of 3 floats -> the same final arithmetic on every rank; the
             # backward below then differentiates the global loss w.r.t. the local rays (global denominator)
             import torch.distributed as dist
@@ -246,7 +246,7 @@ class ColorPatchLoss(nn.Module):
         error = patch_error(pred, gt, self.h_patch_size, self.type)      # [N]
         m = mask.reshape(-1).bool()
         error = error * m.float()
-        if self.data_parallel and nudf_dist.world_size() > 1:
+        if self.data_parallel and nudf_dist.exchanging():
             # order statistics over the whole ray batch: gather errors + masks, trim identically everywhere
             return _global_trimmed_mean(error, m, penalize_ratio)
         err_s, idx = torch.sort(error, descending=True)

@@ -412,7 +412,7 @@ class UDFRendererBlending:
         color, color_base, weights, depth, normals, wsum, wsum_all, sums = outs[:8]
         diag = dict(zip(_DIAG, outs[8:])) if self.diagnostics else {}
         local_sums = None
-        if self.defer_loss_sums and (not self.data_parallel or nudf_dist.world_size() > 1):
+        if self.defer_loss_sums and (not self.data_parallel or nudf_dist.exchanging()):
             # ray-sharded step: the caller packs these five LOCAL sums with its other batch-global partial sums into ONE
             # all-reduce and finishes with `errors_from_sums` (train.Trainer.loss; dist.py (1))
             local_sums = sums

@@ -47,6 +47,49 @@ def test_rccl_collectives_single_rank():
         dist.destroy_process_group()
 
 
+def test_ray_sharded_step_with_its_rccl_collectives_captures_and_replays():
+    """the data-parallel step -- packed loss-sum all-reduce + gradient-bucket all-reduce, both RCCL --
+    captured in a HIP graph (GraphedStep(capture_collectives=True)) and replayed.  One rank: dist.FORCE_COLLECTIVES issues
+    the two collectives although they are the identity, so the captured launch sequence is the multi-GPU one; replays must
+    equal the eager ray-sharded step bit for bit.  (Eager stays the multi-GPU default until a 2-GPU run exists.)"""
+    from neuraludf_amd import dist as nd, synth
+    from neuraludf_amd.train import Trainer, GraphedStep
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    nd.FORCE_COLLECTIVES = True
+    try:
+        rconf = dict(n_samples=32, n_importance=16, n_outside=0, up_sample_steps=2, perturb=1.0)
+        batch = {k: v.to(dev) for k, v in synth.make_rays(synth.make_scene("tiny"), 0, 128, seed=5).items()}
+
+        def run(graphed):
+            tr = Trainer(dev, rconf, seed=0, data_parallel=True, fused_adam=True)
+            st = GraphedStep(tr, eager_steps=2, capture_collectives=True) if graphed else tr.step
+            torch.manual_seed(21)
+            nd.collective_counts(reset=True)
+            out = []
+            for i in range(6):
+                loss, _ = st(batch, cos_anneal_ratio=0.2 * i, flip_saturation=0.9)
+                out.append(loss.clone())
+            torch.cuda.synchronize()
+            return tr, st, out, nd.collective_counts()
+
+        a, _, eager, ce = run(False)
+        b, gs, graph, cg = run(True)
+        assert ce == {"all_reduce": 12, "all_gather": 0}, ce                # two per step, six steps
+        assert gs.enabled and gs.captures == 1 and gs.replays == 4
+        assert cg["all_reduce"] == 2 * 3, cg                                  # 2 eager steps + the capture issue them from Python
+        for i, (x, y) in enumerate(zip(eager, graph)):
+            assert torch.equal(x, y), (i, float(x), float(y))
+        for (n, p), (_, q) in zip(a.udf.named_parameters(), b.udf.named_parameters()):
+            assert torch.equal(p, q), n
+    finally:
+        nd.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
+
+
 def _run(cmd, env_extra, timeout=600):
     import subprocess
     import sys
