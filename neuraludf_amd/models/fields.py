@@ -177,12 +177,38 @@ class UDFNetwork(nn.Module):
         return g.unsqueeze(1)
 
 
-class SDFNetwork(nn.Module):
-    """Only the name is needed: exp_runner_blending.py:16 imports it and never instantiates it."""
+class SDFNetwork(UDFNetwork):
+    """`SDFNetwork` of the reference (fields.py:10-112; imported by exp_runner_blending.py:16, never instantiated there):
+    the same MLP as UDFNetwork with the identity head -- constructor arguments, parameter names / shapes / registration
+    order and the geometric initialisation (incl. `inside_outside`, :50-56) as there, so `torch.manual_seed` gives the same
+    weights and `state_dict`s interchange; evaluated by the same HIP chains (`udf_type='sdf'`: value, features, d sdf / d x
+    and their double backward), no torch path."""
 
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("SDFNetwork is dead code in the reference (never constructed by the runner)")
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, bias=0.5, scale=1, geometric_init=True,
+                 weight_norm=True, inside_outside=False):
+        super().__init__(d_in, d_out, d_hidden, n_layers, skip_in=skip_in, multires=multires, bias=bias, scale=scale,
+                         geometric_init=geometric_init, weight_norm=weight_norm, udf_type='sdf')
+        if geometric_init and inside_outside:
+            # cameras inside the scene (:54-56): the last layer's mean and bias change sign.  The draw above consumed the
+            # generator exactly like the reference's normal_(mean=+sqrt(pi)/sqrt(d)): a normal_ with the negated mean is the
+            # mirrored sample about 0 of the same draw, i.e. -(w - m) - m ... written on the un-normalised direction
+            # tensor (weight_v under weight_norm; g = |v| is re-derived), which is what the reference initialises too.
+            lin = getattr(self, "lin" + str(self.num_layers - 2))
+            m = float(np.sqrt(np.pi) / np.sqrt(lin.weight_v.shape[1] if hasattr(lin, "weight_v") else lin.weight.shape[1]))
+            with torch.no_grad():
+                w = lin.weight_v if hasattr(lin, "weight_v") else lin.weight
+                w.copy_((w - m) - m)                     # N(+m, s) sample -> the N(-m, s) sample of the same draw
+                if hasattr(lin, "weight_g"):
+                    lin.weight_g.copy_(w.norm(dim=1, keepdim=True))
+                lin.bias.fill_(bias)
+            self.invalidate()
+        self.inside_outside = inside_outside
+
+    def sdf(self, x):
+        return self.udf(x)
+
+    def sdf_hidden_appearance(self, x):
+        return self.forward(x)
 
 
 # ------------------------------------------------------------------------------------------

@@ -400,6 +400,30 @@ def test_udf_type_variants(dev, udf_type, path):
         assert rel(p.grad, on.udf[n].grad) < GTOL, n
 
 
+def test_sdf_network_class_on_the_hip_chains(dev):
+    """the reference's SDFNetwork surface (sdf / sdf_hidden_appearance / gradient / forward, fields.py:84-112) served by the
+    same chains as UDFNetwork with the identity head, against the oracle's forward with udf_type 'sdf'."""
+    from neuraludf_amd.models import fields
+    torch.manual_seed(5)
+    net = fields.SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6, bias=0.5, scale=1.0,
+                            geometric_init=True, weight_norm=True, inside_outside=True)
+    gp = torch.Generator().manual_seed(1)
+    with torch.no_grad():          # trained-like weights (the init zeroes the encoding columns), as common.perturb_ does
+        for p in net.parameters():
+            p.add_(torch.randn(p.shape, generator=gp) * 0.02 * (p.abs().mean() + 0.05))
+    sd = {n: t.detach().clone() for n, t in net.state_dict().items()}
+    net = net.to(dev)
+    x = torch.randn(700, 3, generator=torch.Generator().manual_seed(6)) * 0.6
+    cfg = O.UDFCfg(udf_type="sdf")
+    y_ref = O.udf_forward(sd, x, cfg)
+    g_ref = O.udf_gradient(sd, x, cfg, create_graph=False)
+    assert float(y_ref[:, 0].min()) < 0 < float(y_ref[:, 0].max())          # signed: the head is not the abs one
+    xd = x.to(dev)
+    assert rel(net.sdf(xd), y_ref[:, :1]) < VTOL
+    assert rel(net.sdf_hidden_appearance(xd), y_ref) < VTOL and rel(net(xd), y_ref) < VTOL
+    assert rel(net.gradient(xd)[:, 0], g_ref) < VTOL
+
+
 @pytest.mark.parametrize("mode", ["chain64", "layers"])
 def test_udf_other_paths_match_the_default(dev, nets, mode):
     """the 64-point-tile chain kernel (used for P > 16 k) and the per-layer GEMM path against the default

@@ -171,3 +171,25 @@ def test_plain_rendering_network_matches_reference(ref, case):
         assert _maxrel(color, out[0].detach()) < 1e-6 and _maxrel(extra, out[1].detach()) < 1e-6
     else:
         assert _maxrel(color, out.detach()) < 1e-6 and extra.shape[1] == 0
+
+
+@pytest.mark.parametrize("inside_outside", [False, True])
+def test_sdf_network_initialises_like_the_reference(ref, inside_outside):
+    """SDFNetwork (fields.py:10-112, dead code in the runner but part of the module's surface): same parameter names, order and
+    seeded values as the reference class, both camera conventions of the geometric initialisation."""
+    import contextlib
+    import io
+    from neuraludf_amd.models import fields
+    rf = ref[0]
+    kw = dict(d_in=3, d_out=257, d_hidden=64, n_layers=5, skip_in=(3,), multires=4, bias=0.6, scale=1.5, geometric_init=True,
+              weight_norm=True, inside_outside=inside_outside)
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = rf.SDFNetwork(**kw)
+    torch.manual_seed(3)
+    b = fields.SDFNetwork(**kw)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    a.load_state_dict(b.state_dict())
