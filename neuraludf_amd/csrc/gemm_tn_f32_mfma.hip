@@ -44,6 +44,7 @@
 #define TNF_NO_XCD_MAP 64           // plain tile-major blockIdx (A/B of the XCD-aware order)
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 #define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
+#define TNF_WSPEC 1024              // bf16x3 mode: the wave-specialised kernel (one 8-wave workgroup per CU) instead of the default (A/B: slower)
 #define TNF_NO_SPLIT_IMAGE 512      // bf16x3 mode through the generic kernel (split on the way out of the fp32 image; A/B of gemm_tn3_group_kernel)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -969,9 +970,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
 #ifndef NUDF_TN3_DIST2
 #define NUDF_TN3_DIST2 1
 #endif
+#ifndef NUDF_TN3_WGS
+#define NUDF_TN3_WGS 2       // workgroups per CU the split-image kernel is register-allocated for (3: 13 spilled registers)
+#endif
+#ifndef NUDF_TN3W_DEPTH
+#define NUDF_TN3W_DEPTH 4    // wave-specialised kernel: k-steps of operand rows in flight per staging wave
+#endif
 #define BK3 32
 #define LD3 132
 #define T3 (16 * LD3)
+#define T3Q (4 * 128 * 4)    // dwords per plane and operand of the [k-pair group][column][4] image
 __device__ __forceinline__ void tn_split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
   p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
   const float r0 = x0 - __builtin_bit_cast(float, p0 << 16);
@@ -982,10 +990,16 @@ __device__ __forceinline__ void tn_split3_pair(float x0, float x1, unsigned& p0,
   p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
-  __shared__ __attribute__((aligned(16))) unsigned smem[6 * T3];
-  unsigned* As = smem;             // planes at As + pl * T3
-  unsigned* Bs = smem + 3 * T3;
+__global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPlan g) {
+  // image: [operand 2][plane 3][k-pair group 4][column 128][4 dwords] -- the four k-pairs (8 rows) a lane's MFMA operand
+  // needs for one column are ONE 16-byte unit: a fragment is one conflict-free ds_read_b128 (the [k-pair][column] layout of
+  // the 16-bit kernel costs four ds_read_b32 at half the LDS rate, and its 32-byte-per-lane staging writes hit every bank
+  // twice: at six planes the loop was LDS-bound, ~2 000 LDS cycles per k-step against 1 536 of MFMA).  A staging thread owns
+  // ONE column and 16 rows (two k-pair groups): 16 coalesced 4-byte loads per operand (a wave = 256 contiguous bytes of a
+  // row), 8 pair splits, and per plane two 16-byte stores at a 16-byte lane stride.
+  __shared__ __attribute__((aligned(16))) unsigned smem[6 * T3Q];
+  unsigned* As = smem;             // planes at As + pl * T3Q
+  unsigned* Bs = smem + 3 * T3Q;
 
   const long long t_begin = g.dbg ? (long long)wall_clock64() : 0;
   const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -1002,7 +1016,187 @@ __global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
   const int mbeg = chunk * tl.rows_per_block;
   const int mend = min(mbeg + tl.rows_per_block, g.M);
   const int nk = (mend - mbeg + BK3 - 1) / BK3;
-  const int pr = tid >> 4, pc = (tid & 15) * 8;     // k-pair of the step (rows 2 pr, 2 pr + 1), first of 8 columns
+  const int sc = tid & 127, sg = tid >> 7;          // staging: column of the tile, half of the k-step (rows 16 sg .. + 15)
+  const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
+  float bias_acc = 0.0f;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+
+  // this thread's column of each operand, clamped into the buffer (columns past NA / NB only feed outputs that are never
+  // stored); rows are clamped per load and zeroed past mend at the split
+  const float* pa = q.A1 + min(i0 + sc, q.lda1 - 1);
+  const float* pb = q.B1 + min(j0 + sc, q.ldb1 - 1);
+  const size_t lda = (size_t)q.lda1, ldb = (size_t)q.ldb1;
+  auto load = [&](const float* p, size_t ld, float (&st)[16], int kt) {
+    const int r0 = mbeg + kt * BK3 + 16 * sg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = p[(size_t)min(r0 + r, g.M - 1) * ld];
+  };
+  auto store = [&](const float (&st)[16], int kt, unsigned* tile, bool bias) {
+    const int r0 = mbeg + kt * BK3 + 16 * sg;
+    u32x4 hq[2], mq[2], lq[2];
+    float ps[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      const float x0 = (r0 + 2 * pp < mend) ? st[2 * pp] : 0.0f;
+      const float x1 = (r0 + 2 * pp + 1 < mend) ? st[2 * pp + 1] : 0.0f;
+      unsigned a, b, d;
+      tn_split3_pair(x0, x1, a, b, d);
+      hq[pp >> 2][pp & 3] = a; mq[pp >> 2][pp & 3] = b; lq[pp >> 2][pp & 3] = d;
+      ps[pp] = x0 + x1;
+    }
+    // bias gradient: the step's 16 rows summed as a tree, then one addition into the running sum (a plain running sum over
+    // all rows of the chunk was 10x the exact kernel's error against float64)
+    if (bias) bias_acc += ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    unsigned* dst = tile + ((2 * sg) * 128 + sc) * 4;
+    *reinterpret_cast<u32x4*>(dst) = hq[0];
+    *reinterpret_cast<u32x4*>(dst + 512) = hq[1];
+    *reinterpret_cast<u32x4*>(dst + T3Q) = mq[0];
+    *reinterpret_cast<u32x4*>(dst + T3Q + 512) = mq[1];
+    *reinterpret_cast<u32x4*>(dst + 2 * T3Q) = lq[0];
+    *reinterpret_cast<u32x4*>(dst + 2 * T3Q + 512) = lq[1];
+  };
+  // one k-step: 2 groups of 16 rows; per group 2 + 2 operand sub-tiles x 3 planes (one ds_read_b128 each) and 24 MFMAs
+  auto mma = [&]() {
+    const unsigned* as = As + ((lane >> 5) * 128 + (wave >> 1) * 64 + (lane & 31)) * 4;
+    const unsigned* bs = Bs + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK3 / 16; ++kk) {
+      u32x4 a[2][3], b[2][3];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[s2][pl] = *reinterpret_cast<const u32x4*>(as + pl * T3Q + (2 * kk) * 512 + 128 * s2);
+          b[s2][pl] = *reinterpret_cast<const u32x4*>(bs + pl * T3Q + (2 * kk) * 512 + 128 * s2);
+        }
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt) {
+        const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
+        const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][qa]),
+                                                                     __builtin_bit_cast(bf16x8, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+      }
+    }
+  };
+  // the operand rows of k-step kt + 2 are requested before step kt's MFMAs (two staging sets): a panel's first reader
+  // among the tiles of its XCD pays an HBM round trip, which is longer than one step's 48 MFMAs per wave
+  float sa[16], sb[16], sa2[16], sb2[16];
+  if (nk > 0) {
+    load(pa, lda, sa, 0);
+    load(pb, ldb, sb, 0);
+    if (nk > 1) {
+      load(pa, lda, sa2, 1);
+      load(pb, ldb, sb2, 1);
+    }
+    store(sa, 0, As, do_bias);
+    store(sb, 0, Bs, false);
+  }
+  __syncthreads();
+  auto kstep = [&](int kt, float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+    // la / lb: free set, receives step kt + 2; ua / ub: holds step kt + 1 (requested one step ago), stored after the MFMAs
+#if NUDF_TN3_DIST2
+    if (kt + 2 < nk) {
+      load(pa, lda, la, kt + 2);
+      load(pb, ldb, lb, kt + 2);
+    }
+#else      // A/B: requests one step ahead only (into the set that is stored after this step's MFMAs)
+    if (kt + 1 < nk && kt > 0) {
+      load(pa, lda, ua, kt + 1);
+      load(pb, ldb, ub, kt + 1);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+    mma();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // every wave is done reading the image
+    if (kt + 1 < nk) {
+      store(ua, kt + 1, As, do_bias);
+      store(ub, kt + 1, Bs, false);
+    }
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, sa, sb, sa2, sb2);
+    if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb);
+  }
+
+  if (g.dbg && tid == 0) {
+    long long* d = g.dbg + 4 * (size_t)blockIdx.x;
+    d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = 2 * 16 + 4;
+    d[3] = nk | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 16);
+  }
+  if (g.flags & TNF_NO_EPILOGUE) return;
+  float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
+  if (do_bias) {   // the loop's last barrier has passed: the operand image is free
+    float* red = reinterpret_cast<float*>(smem);
+    red[sg * BM + sc] = bias_acc;
+    __syncthreads();
+    if (tid < BM) {
+      const float sum = red[tid] + red[BM + tid];
+      if (slot) slot[BM * BN + tid] = sum;
+      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (slot) {   // accumulator register order, 64 contiguous bytes per lane (tn_reduce_kernel decodes it)
+      float* w = slot + ((wave * 4 + s) * 64 + lane) * 16;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {acc[s][4 * qd], acc[s][4 * qd + 1], acc[s][4 * qd + 2], acc[s][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
+      }
+    } else {
+      const int col = j0 + 32 * tn_jsub(2, wave, s) + (lane & 31);
+      if (col >= q.NB) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 32 * tn_isub(2, wave, s) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s][r]);
+      }
+    }
+  }
+}
+
+// =======================================================================================================
+// bf16x3 mode, WAVE-SPECIALISED form (gemm_tn3w_group_kernel): one workgroup of EIGHT waves per CU -- waves 0..3 ("matrix
+// waves", one per SIMD) only read operand fragments from the split image and issue MFMAs, waves 4..7 ("staging waves", the
+// other wave slot of each SIMD) only load operand rows from HBM, split them and write the image.  The image is
+// double-buffered (2 x 50.7 KB), ONE barrier per 32-row k-step: while the matrix waves contract step k out of buffer k & 1
+// the staging waves fill buffer (k + 1) & 1 with step k + 1 (rows requested two steps ahead).  On every SIMD a matrix-pipe
+// wave sits beside a VALU / memory wave -- the complementary pairing -- instead of two workgroups whose split-and-store
+// phases stop their own MFMAs (gemm_tn3_group_kernel: 35 % of the bf16 peak; this form: see DESIGN 4.2).  Same tiles,
+// quadrant layout, workspace slots, reduce and arithmetic (bit-identical C and bias sums).
+// =======================================================================================================
+__global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
+  __shared__ __attribute__((aligned(16))) unsigned smem[2 * 6 * T3];
+
+  int t, chunk;
+  tn_decode(g, t, chunk);
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const int slot_id = tl.blk_start + chunk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool staging = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int lt = tid & 255;
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const int mbeg = chunk * tl.rows_per_block;
+  const int mend = min(mbeg + tl.rows_per_block, g.M);
+  const int nk = (mend - mbeg + BK3 - 1) / BK3;
+  const int pr = lt >> 4, pc = (lt & 15) * 8;
   const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
   f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
 
@@ -1012,15 +1206,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
 
-  // this thread's 8 columns of an operand as two 4-column pieces, each clamped into the buffer (columns past NA / NB only
-  // feed outputs that are never stored); rows are clamped per load
   const int ca = i0 + pc, cb = j0 + pc;
   const char* pa = reinterpret_cast<const char*>(q.A1) + (size_t)min(ca, q.lda1 - 4) * 4;
   const char* pb = reinterpret_cast<const char*>(q.B1) + (size_t)min(cb, q.ldb1 - 4) * 4;
   const int pa2 = (min(ca + 4, q.lda1 - 4) - min(ca, q.lda1 - 4)) * 4;
   const int pb2 = (min(cb + 4, q.ldb1 - 4) - min(cb, q.ldb1 - 4)) * 4;
   const size_t rowa = (size_t)q.lda1 * 4, rowb = (size_t)q.ldb1 * 4;
-  f32x4 sa[2][2], sb[2][2];        // [row of the pair][piece]
   auto load = [&](const char* p, int p2, size_t rowbytes, f32x4 (&st)[2][2], int kt) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -1057,88 +1248,100 @@ __global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
     *reinterpret_cast<u32x4*>(dst + 2 * T3) = l0;
     *reinterpret_cast<u32x4*>(dst + 2 * T3 + 4) = l1;
   };
-  // one k-step: 2 groups of 16 rows; per group 2 + 2 operand sub-tiles x 3 planes and 24 MFMAs
-  auto mma = [&]() {
-    const unsigned* as = As + (4 * (lane >> 5)) * LD3 + (wave >> 1) * 64 + (lane & 31);
-    const unsigned* bs = Bs + (4 * (lane >> 5)) * LD3 + (wave & 1) * 64 + (lane & 31);
+  // matrix waves: fragments of one 16-row group = 2 + 2 sub-tiles x 3 planes x 4 dwords
+  struct Frag { u32x4 a[2][3], b[2][3]; };
+  auto rd = [&](Frag& f, const unsigned* img, int kk) {
+    const unsigned* as = img + (4 * (lane >> 5)) * LD3 + (wave >> 1) * 64 + (lane & 31);
+    const unsigned* bs = img + 3 * T3 + (4 * (lane >> 5)) * LD3 + (wave & 1) * 64 + (lane & 31);
 #pragma unroll
-    for (int kk = 0; kk < BK3 / 16; ++kk) {
-      u32x4 a[2][3], b[2][3];
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int e = 0; e < 4; ++e) {
+          f.a[s2][pl][e] = as[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
+          f.b[s2][pl][e] = bs[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
+        }
+  };
+  auto mfmas = [&](const Frag& f) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a[s2][pl][e] = as[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
-            b[s2][pl][e] = bs[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
+    for (int tt = 0; tt < 6; ++tt) {
+      const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
+      const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i][qa]),
+                                                                   __builtin_bit_cast(bf16x8, f.b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+    }
+  };
+
+  if (staging) {
+    // ring of D staging sets: the operand rows of step k + D are requested while step k + 1 is split and stored.  ONE
+    // workgroup per CU means this wave's requests are all the memory-level parallelism the CU has (D = 2: 64 KB in flight
+    // per CU, a third of what 10 B / cycle / CU of HBM need at ~2 us)
+    constexpr int D = NUDF_TN3W_DEPTH;
+    f32x4 sa[D][2][2], sb[D][2][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < nk) {
+        load(pa, pa2, rowa, sa[d], d);
+        load(pb, pb2, rowb, sb[d], d);
+      }
+    if (nk > 0) {
+      store(sa[0], 0, smem, do_bias);
+      store(sb[0], 0, smem + 3 * T3, false);
+    }
+    __syncthreads();                                   // image 0 holds step 0
+    for (int kt0 = 0; kt0 < nk; kt0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int kt = kt0 + d;
+        if (kt < nk) {
+          if (kt + D < nk) {                             // slot d held step kt (stored one iteration ago): free
+            load(pa, pa2, rowa, sa[d], kt + D);
+            load(pb, pb2, rowb, sb[d], kt + D);
           }
-#pragma unroll
-      for (int tt = 0; tt < 6; ++tt) {
-        const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
-        const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][qa]),
-                                                                     __builtin_bit_cast(bf16x8, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+          if (kt + 1 < nk) {
+            unsigned* img = smem + ((kt + 1) & 1) * 6 * T3;
+            store(sa[(d + 1) % D], kt + 1, img, do_bias);
+            store(sb[(d + 1) % D], kt + 1, img + 3 * T3, false);
+          }
+          __syncthreads();
+        }
       }
     }
-  };
-  // the operand rows of k-step kt + 2 are requested before step kt's MFMAs (two staging sets): a panel's first reader
-  // among the tiles of its XCD pays an HBM round trip, which is longer than one step's 48 MFMAs per wave
-  f32x4 sa2[2][2], sb2[2][2];
-  if (nk > 0) {
-    load(pa, pa2, rowa, sa, 0);
-    load(pb, pb2, rowb, sb, 0);
-    if (nk > 1) {
-      load(pa, pa2, rowa, sa2, 1);
-      load(pb, pb2, rowb, sb2, 1);
+  } else {
+    // Fragment reads are always one 16-row group ahead of the MFMAs that use them, and the step's barrier sits BETWEEN its
+    // two groups: at barrier k the matrix waves hold both groups of image k in registers (the staging waves may overwrite
+    // it) and image k + 1 is complete (its first group is requested right behind the barrier, under group 1's MFMAs).
+    __builtin_amdgcn_s_setprio(1);
+    Frag f0, f1;
+    __syncthreads();                                   // image 0 holds step 0
+    if (nk > 0) rd(f0, smem, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned* img = smem + (kt & 1) * 6 * T3;
+      rd(f1, img, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      if (kt + 1 < nk) rd(f0, smem + ((kt + 1) & 1) * 6 * T3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(f1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    store(sa, 0, As, do_bias);
-    store(sb, 0, Bs, false);
-  }
-  __syncthreads();
-  auto kstep = [&](int kt, f32x4 (&la)[2][2], f32x4 (&lb)[2][2], f32x4 (&ua)[2][2], f32x4 (&ub)[2][2]) {
-    // la / lb: free set, receives step kt + 2; ua / ub: holds step kt + 1 (requested one step ago), stored after the MFMAs
-#if NUDF_TN3_DIST2
-    if (kt + 2 < nk) {
-      load(pa, pa2, rowa, la, kt + 2);
-      load(pb, pb2, rowb, lb, kt + 2);
-    }
-#else      // A/B: requests one step ahead only (into the set that is stored after this step's MFMAs)
-    if (kt + 1 < nk && kt > 0) {
-      load(pa, pa2, rowa, ua, kt + 1);
-      load(pb, pb2, rowb, ub, kt + 1);
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
-    mma();
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                     // every wave is done reading the image
-    if (kt + 1 < nk) {
-      store(ua, kt + 1, As, do_bias);
-      store(ub, kt + 1, Bs, false);
-    }
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    kstep(kt, sa, sb, sa2, sb2);
-    if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb);
   }
 
-  if (g.dbg && tid == 0) {
-    long long* d = g.dbg + 4 * (size_t)blockIdx.x;
-    d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = 2 * 16 + 4;
-    d[3] = nk | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 16);
-  }
   if (g.flags & TNF_NO_EPILOGUE) return;
   float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
-  if (do_bias) {   // the loop's last barrier has passed: the operand image is free
+  if (do_bias) {   // the loop's last barrier has passed: the images are free
     float* red = reinterpret_cast<float*>(smem);
-    *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
-    *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
+    if (staging) {
+      *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
+      *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
+    }
     __syncthreads();
     if (tid < BM) {
       float sum = 0.0f;
@@ -1147,6 +1350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn3_group_kernel(TnPlan g) {
       else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
     }
   }
+  if (staging) return;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (slot) {   // accumulator register order, 64 contiguous bytes per lane (tn_reduce_kernel decodes it)
@@ -1294,8 +1498,11 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
     // exactly one resident wave of workgroups (2 per CU x 256 CUs; NUDF_TNG_BLOCKS: tuning hook), at least 8 k-steps
     // per workgroup.  Tile t costs cost[t] MFMA units per k-step: find the smallest per-workgroup budget T for which
     // sum_t ceil(cost[t] * nkt / T) fits, i.e. every workgroup does (nearly) the same number of MFMAs.
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
+    static int target0 = -1;
+    if (target0 < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target0 = e ? atoi(e) : 512; }
+    // (the wave-specialised bf16x3 kernel keeps ONE workgroup of eight waves per CU: half the resident workgroups)
+    const bool wspec = g.prec == 3 && (flags & TNF_WSPEC) && !(flags & TNF_NO_SPLIT_IMAGE);
+    const int target = wspec ? target0 / 2 : target0;
     const int max_chunks = nkt / 8 > 0 ? nkt / 8 : 1;
     auto count = [&](double T, bool store) {
       long total = 0;
@@ -1398,7 +1605,8 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   bool split3 = pl.prec == 3 && !(pl.flags & TNF_NO_SPLIT_IMAGE);
   for (int i = 0; i < args->n_problems && split3; ++i)
     if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;
-  if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  if (split3 && (pl.flags & TNF_WSPEC)) hipLaunchKernelGGL(gemm_tn3w_group_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, pl);
+  else if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");

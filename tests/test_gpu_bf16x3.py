@@ -133,7 +133,9 @@ def test_weight_gradient_gemm_against_float64(dev, M):
                                                                           for a, b, c in zip(e32, e3, e3g)], "x 1e-7")
     for (c32, b32), (c3, b3), (c3g, b3g) in zip(e32, e3, e3g):
         assert c3 <= 1.5 * c32 + 2e-7 and c3g <= 1.5 * c32 + 2e-7, (c32, c3, c3g)
-        assert b3 <= 1.5 * b32 + 2e-7 and b3g <= 1.5 * b32 + 2e-7       # bias sums: fp32 additions of the unsplit values
+        # bias sums: fp32 additions of the UNSPLIT values in every kernel, in each kernel's own association (the split-image
+        # kernel: a tree over a k-step's 16 rows, a running sum over the steps) -- fp32 summation noise, nowhere near 2^-9
+        assert b3 <= 3e-6 and b3g <= 3e-6 and b32 <= 3e-6, (b32, b3, b3g)
 
 
 def test_packed_weight_planes_sum_to_the_weight_bit_for_bit(dev):
