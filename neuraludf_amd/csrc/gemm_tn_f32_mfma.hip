@@ -44,7 +44,6 @@
 #define TNF_NO_XCD_MAP 64           // plain tile-major blockIdx (A/B of the XCD-aware order)
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 #define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
-#define TNF_WSPEC 1024              // bf16x3 mode: the wave-specialised kernel (one 8-wave workgroup per CU) instead of the default (A/B: slower)
 #define TNF_NO_SPLIT_IMAGE 512      // bf16x3 mode through the generic kernel (split on the way out of the fp32 image; A/B of gemm_tn3_group_kernel)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -959,22 +958,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
 // =======================================================================================================
 // bf16x3 mode (NudfGemmTNGroup.prec == 3): fp32 EMULATED on the bf16 matrix pipe, see NudfChainStep.prec.  Same tiles,
 // quadrant layout, workspace slots and reduce as above; both operands are fp32 row-major (the bf16x3 chains keep fp32
-// state).  The LDS image is the MFMA operand THREE TIMES: planes hi / mid / lo of the k-pair layout of
-// gemm_tn16_group_kernel, filled by splitting every element ONCE on its way in (x = hi + mid + lo exactly; 11 VALU
-// operations per pair of values), so the k loop holds no conversion at all: per 16 rows and sub-tile pair 3 + 3 operand
-// fragments of 4 ds_read_b32 and 6 MFMAs (hi lo, lo hi, mid mid, hi mid, mid hi, hi hi; fp32 accumulate).  k-steps of 32
-// rows, ONE LDS buffer of 50.7 KB (3 planes x 2 operands x 16 k-pair rows x 132 dwords): the global loads of step k + 1 are
-// in flight under step k's 48 MFMAs per wave, the split + LDS stores sit between two barriers, and the co-resident
-// workgroups of the CU (2-3) run their MFMA phases meanwhile.
+// state).  The LDS image is the MFMA operand THREE TIMES -- planes hi / mid / lo -- filled by splitting every element ONCE on
+// its way in (x = hi + mid + lo exactly; 11 VALU operations per pair of values), so the k loop holds no conversion at all:
+// per 16 rows and sub-tile pair 3 + 3 operand fragments (one ds_read_b128 each, layout in the kernel) and 6 MFMAs (hi lo,
+// lo hi, mid mid, hi mid, mid hi, hi hi; fp32 accumulate).  k-steps of 32 rows, ONE 48 KB buffer: the global loads of step
+// k + 2 are in flight under step k's 48 MFMAs per wave, the split + LDS stores sit between two barriers, and the other
+// workgroup of the CU runs its MFMA phase meanwhile.  A wave-specialised form (one 8-wave workgroup per CU: four matrix
+// waves, four staging waves, double-buffered image, one barrier per step) was built and measured slower in every variant
+// (1.30-1.51 ms against 1.01-1.15 ms per step; profiles/r04_bf16x3_experiments.txt item 7) and removed.
 // =======================================================================================================
 #ifndef NUDF_TN3_DIST2
 #define NUDF_TN3_DIST2 1
 #endif
 #ifndef NUDF_TN3_WGS
 #define NUDF_TN3_WGS 2       // workgroups per CU the split-image kernel is register-allocated for (3: 13 spilled registers)
-#endif
-#ifndef NUDF_TN3W_DEPTH
-#define NUDF_TN3W_DEPTH 4    // wave-specialised kernel: k-steps of operand rows in flight per staging wave
 #endif
 #define BK3 32
 #define LD3 132
@@ -1167,211 +1164,6 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
   }
 }
 
-// =======================================================================================================
-// bf16x3 mode, WAVE-SPECIALISED form (gemm_tn3w_group_kernel): one workgroup of EIGHT waves per CU -- waves 0..3 ("matrix
-// waves", one per SIMD) only read operand fragments from the split image and issue MFMAs, waves 4..7 ("staging waves", the
-// other wave slot of each SIMD) only load operand rows from HBM, split them and write the image.  The image is
-// double-buffered (2 x 50.7 KB), ONE barrier per 32-row k-step: while the matrix waves contract step k out of buffer k & 1
-// the staging waves fill buffer (k + 1) & 1 with step k + 1 (rows requested two steps ahead).  On every SIMD a matrix-pipe
-// wave sits beside a VALU / memory wave -- the complementary pairing -- instead of two workgroups whose split-and-store
-// phases stop their own MFMAs (gemm_tn3_group_kernel: 35 % of the bf16 peak; this form: see DESIGN 4.2).  Same tiles,
-// quadrant layout, workspace slots, reduce and arithmetic (bit-identical C and bias sums).
-// =======================================================================================================
-__global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
-  __shared__ __attribute__((aligned(16))) unsigned smem[2 * 6 * T3];
-
-  int t, chunk;
-  tn_decode(g, t, chunk);
-  const TnTile tl = g.tile[t];
-  const NudfGemmTNProblem& q = g.prob[tl.prob];
-  const int slot_id = tl.blk_start + chunk;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool staging = wave8 >= 4;
-  const int wave = wave8 & 3;
-  const int lt = tid & 255;
-  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
-  const int mbeg = chunk * tl.rows_per_block;
-  const int mend = min(mbeg + tl.rows_per_block, g.M);
-  const int nk = (mend - mbeg + BK3 - 1) / BK3;
-  const int pr = lt >> 4, pc = (lt & 15) * 8;
-  const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
-  f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
-
-  const int ca = i0 + pc, cb = j0 + pc;
-  const char* pa = reinterpret_cast<const char*>(q.A1) + (size_t)min(ca, q.lda1 - 4) * 4;
-  const char* pb = reinterpret_cast<const char*>(q.B1) + (size_t)min(cb, q.ldb1 - 4) * 4;
-  const int pa2 = (min(ca + 4, q.lda1 - 4) - min(ca, q.lda1 - 4)) * 4;
-  const int pb2 = (min(cb + 4, q.ldb1 - 4) - min(cb, q.ldb1 - 4)) * 4;
-  const size_t rowa = (size_t)q.lda1 * 4, rowb = (size_t)q.ldb1 * 4;
-  auto load = [&](const char* p, int p2, size_t rowbytes, f32x4 (&st)[2][2], int kt) {
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int row = min(mbeg + kt * BK3 + 2 * pr + rr, g.M - 1);
-      const char* src = p + (size_t)row * rowbytes;
-      st[rr][0] = *reinterpret_cast<const f32x4*>(src);
-      st[rr][1] = *reinterpret_cast<const f32x4*>(src + p2);
-    }
-  };
-  auto store = [&](const f32x4 (&st)[2][2], int kt, unsigned* tile, bool bias) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const int k0 = mbeg + kt * BK3 + 2 * pr;
-    const bool v0 = k0 < mend, v1 = k0 + 1 < mend;
-    const f32x4 r0l = v0 ? st[0][0] : z, r0h = v0 ? st[0][1] : z;
-    const f32x4 r1l = v1 ? st[1][0] : z, r1h = v1 ? st[1][1] : z;
-    u32x4 h0, m0, l0, h1, m1, l1;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      unsigned a, b, d;
-      tn_split3_pair(r0l[c], r1l[c], a, b, d);
-      h0[c] = a; m0[c] = b; l0[c] = d;
-      tn_split3_pair(r0h[c], r1h[c], a, b, d);
-      h1[c] = a; m1[c] = b; l1[c] = d;
-    }
-    if (bias) {
-      bias_lo += r0l + r1l;
-      bias_hi += r0h + r1h;
-    }
-    unsigned* dst = tile + pr * LD3 + pc;
-    *reinterpret_cast<u32x4*>(dst) = h0;
-    *reinterpret_cast<u32x4*>(dst + 4) = h1;
-    *reinterpret_cast<u32x4*>(dst + T3) = m0;
-    *reinterpret_cast<u32x4*>(dst + T3 + 4) = m1;
-    *reinterpret_cast<u32x4*>(dst + 2 * T3) = l0;
-    *reinterpret_cast<u32x4*>(dst + 2 * T3 + 4) = l1;
-  };
-  // matrix waves: fragments of one 16-row group = 2 + 2 sub-tiles x 3 planes x 4 dwords
-  struct Frag { u32x4 a[2][3], b[2][3]; };
-  auto rd = [&](Frag& f, const unsigned* img, int kk) {
-    const unsigned* as = img + (4 * (lane >> 5)) * LD3 + (wave >> 1) * 64 + (lane & 31);
-    const unsigned* bs = img + 3 * T3 + (4 * (lane >> 5)) * LD3 + (wave & 1) * 64 + (lane & 31);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f.a[s2][pl][e] = as[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
-          f.b[s2][pl][e] = bs[pl * T3 + (8 * kk + e) * LD3 + 32 * s2];
-        }
-  };
-  auto mfmas = [&](const Frag& f) {
-#pragma unroll
-    for (int tt = 0; tt < 6; ++tt) {
-      const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
-      const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i][qa]),
-                                                                   __builtin_bit_cast(bf16x8, f.b[j][qb]), acc[i * 2 + j], 0, 0, 0);
-    }
-  };
-
-  if (staging) {
-    // ring of D staging sets: the operand rows of step k + D are requested while step k + 1 is split and stored.  ONE
-    // workgroup per CU means this wave's requests are all the memory-level parallelism the CU has (D = 2: 64 KB in flight
-    // per CU, a third of what 10 B / cycle / CU of HBM need at ~2 us)
-    constexpr int D = NUDF_TN3W_DEPTH;
-    f32x4 sa[D][2][2], sb[D][2][2];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < nk) {
-        load(pa, pa2, rowa, sa[d], d);
-        load(pb, pb2, rowb, sb[d], d);
-      }
-    if (nk > 0) {
-      store(sa[0], 0, smem, do_bias);
-      store(sb[0], 0, smem + 3 * T3, false);
-    }
-    __syncthreads();                                   // image 0 holds step 0
-    for (int kt0 = 0; kt0 < nk; kt0 += D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int kt = kt0 + d;
-        if (kt < nk) {
-          if (kt + D < nk) {                             // slot d held step kt (stored one iteration ago): free
-            load(pa, pa2, rowa, sa[d], kt + D);
-            load(pb, pb2, rowb, sb[d], kt + D);
-          }
-          if (kt + 1 < nk) {
-            unsigned* img = smem + ((kt + 1) & 1) * 6 * T3;
-            store(sa[(d + 1) % D], kt + 1, img, do_bias);
-            store(sb[(d + 1) % D], kt + 1, img + 3 * T3, false);
-          }
-          __syncthreads();
-        }
-      }
-    }
-  } else {
-    // Fragment reads are always one 16-row group ahead of the MFMAs that use them, and the step's barrier sits BETWEEN its
-    // two groups: at barrier k the matrix waves hold both groups of image k in registers (the staging waves may overwrite
-    // it) and image k + 1 is complete (its first group is requested right behind the barrier, under group 1's MFMAs).
-    __builtin_amdgcn_s_setprio(1);
-    Frag f0, f1;
-    __syncthreads();                                   // image 0 holds step 0
-    if (nk > 0) rd(f0, smem, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned* img = smem + (kt & 1) * 6 * T3;
-      rd(f1, img, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(f0);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      if (kt + 1 < nk) rd(f0, smem + ((kt + 1) & 1) * 6 * T3, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(f1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  if (g.flags & TNF_NO_EPILOGUE) return;
-  float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
-  if (do_bias) {   // the loop's last barrier has passed: the images are free
-    float* red = reinterpret_cast<float*>(smem);
-    if (staging) {
-      *reinterpret_cast<f32x4*>(red + pr * BM + pc) = bias_lo;
-      *reinterpret_cast<f32x4*>(red + pr * BM + pc + 4) = bias_hi;
-    }
-    __syncthreads();
-    if (tid < BM) {
-      float sum = 0.0f;
-      for (int k = 0; k < 16; ++k) sum += red[k * BM + tid];
-      if (slot) slot[BM * BN + tid] = sum;
-      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
-    }
-  }
-  if (staging) return;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (slot) {   // accumulator register order, 64 contiguous bytes per lane (tn_reduce_kernel decodes it)
-      float* w = slot + ((wave * 4 + s) * 64 + lane) * 16;
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const f32x4 v = {acc[s][4 * qd], acc[s][4 * qd + 1], acc[s][4 * qd + 2], acc[s][4 * qd + 3]};
-        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
-      }
-    } else {
-      const int col = j0 + 32 * tn_jsub(2, wave, s) + (lane & 31);
-      if (col >= q.NB) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + 32 * tn_isub(2, wave, s) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s][r]);
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // host side: the plan (tiles, layouts, cost-weighted row chunks) and the C ABI
 // ---------------------------------------------------------------------------------------
@@ -1498,11 +1290,8 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
     // exactly one resident wave of workgroups (2 per CU x 256 CUs; NUDF_TNG_BLOCKS: tuning hook), at least 8 k-steps
     // per workgroup.  Tile t costs cost[t] MFMA units per k-step: find the smallest per-workgroup budget T for which
     // sum_t ceil(cost[t] * nkt / T) fits, i.e. every workgroup does (nearly) the same number of MFMAs.
-    static int target0 = -1;
-    if (target0 < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target0 = e ? atoi(e) : 512; }
-    // (the wave-specialised bf16x3 kernel keeps ONE workgroup of eight waves per CU: half the resident workgroups)
-    const bool wspec = g.prec == 3 && (flags & TNF_WSPEC) && !(flags & TNF_NO_SPLIT_IMAGE);
-    const int target = wspec ? target0 / 2 : target0;
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
     const int max_chunks = nkt / 8 > 0 ? nkt / 8 : 1;
     auto count = [&](double T, bool store) {
       long total = 0;
@@ -1605,8 +1394,7 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   bool split3 = pl.prec == 3 && !(pl.flags & TNF_NO_SPLIT_IMAGE);
   for (int i = 0; i < args->n_problems && split3; ++i)
     if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;
-  if (split3 && (pl.flags & TNF_WSPEC)) hipLaunchKernelGGL(gemm_tn3w_group_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, pl);
-  else if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
