@@ -227,6 +227,13 @@ typedef struct NudfUpsample {
                                                   section -- rows cos_val, vis_prob, alpha_plus, alpha_minus, alpha, weights
                                                   (before sample_pdf's + 1e-5), cdf -- for the stage-wise comparison with the
                                                   reference's tensors (scripts/upsample_first_diff.py); mode 0 only */
+  /* the PREVIOUS round's merge (nudf_merge) folded into this launch: merge_K > 0 -> the current samples are the sorted
+     merge of prev_z / prev_udf [N, M - merge_K] with add_z / add_udf [N, merge_K]; z / udf above are ignored, the merged
+     lists are also written to z_merged / udf_merged [N, M] (same values as nudf_merge writes: data movement only) */
+  const float* prev_z; const float* prev_udf;
+  const float* add_z; const float* add_udf;
+  float* z_merged; float* udf_merged;
+  int32_t merge_K;
 } NudfUpsample;
 #define NUDF_UP_DBG_ROWS 7
 #define NUDF_UP_THEORICAL 256
@@ -246,6 +253,14 @@ typedef struct NudfUpsample {
 int nudf_upsample(const NudfUpsample* args, void* stream);
 int nudf_merge(const float* z, const float* udf, const float* z_new, const float* udf_new, int N, int M,
                int K, float* z_out, float* udf_out, void* stream);
+/* the LAST merge of the schedule (z only, :278-288) + the section mid points the renderer evaluates next
+ * (nudf_ray_points mode 1, :352-357) in one launch: z_out [N, M + K], pts [N (M + K), 3].  xrows != NULL: the points are
+ * also written to columns 0..2 of the [N (M + K), ldx] row array at xrows and columns 3..xcols-1 are zeroed -- the
+ * [feat | pts | 0] input buffer of the colour network (what nudf_copy_cols + a pad fill did).  Same arithmetic as the
+ * separate launches. */
+int nudf_merge_points(const float* z, const float* z_new, int N, int M, int K, float* z_out, const float* rays_o,
+                      const float* rays_d, const float* sample_dist, float* pts, float* xrows, int ldx, int xcols,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pixel / patch blending and the SSIM patch loss (gradients reach the blending logits and the
@@ -328,6 +343,11 @@ int nudf_patch_metric(int type, const float* pred, const float* gt, const float*
  * ---------------------------------------------------------------------------------- */
 int nudf_coarse_z(const float* near, const float* far, int nf_stride, const float* t_rand, int N, int S,
                   float* z, float* sample_dist, void* stream);
+/* nudf_coarse_z + the points o + d z of those samples (nudf_ray_points mode 0) in ONE launch -- the start of the
+ * hierarchical sampling.  center != 0: t_rand holds the raw U[0, 1) draws and the - 0.5 of :618 is applied here
+ * (one rounded subtraction, as the separate torch op).  pts [N S, 3] or NULL. */
+int nudf_coarse_start(const float* near, const float* far, int nf_stride, const float* t_rand, int center, int N, int S,
+                      float* z, float* sample_dist, const float* rays_o, const float* rays_d, float* pts, void* stream);
 int nudf_outside_z(const float* far, int f_stride, const float* lin, int N, int n_out, int n_samples,
                    float* z_out, void* stream);
 int nudf_ray_points(const float* rays_o, const float* rays_d, const float* z, const float* sample_dist, int N,

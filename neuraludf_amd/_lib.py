@@ -82,7 +82,9 @@ class Upsample(C.Structure):
                 ("sample_dist", c_fp), ("gamma_dev", c_fp),
                 ("N", i32), ("M", i32), ("K", i32), ("mode", i32),
                 ("inv_s", f32), ("beta", f32), ("gamma", f32),
-                ("z_new", c_fp), ("pts_new", c_fp), ("dbg", c_fp)]
+                ("z_new", c_fp), ("pts_new", c_fp), ("dbg", c_fp),
+                ("prev_z", c_fp), ("prev_udf", c_fp), ("add_z", c_fp), ("add_udf", c_fp),
+                ("z_merged", c_fp), ("udf_merged", c_fp), ("merge_K", i32)]
 
 
 class PixelBlend(C.Structure):
@@ -185,7 +187,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_gemm_tn_grouped_plan", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
-    "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_coarse_z", "nudf_outside_z",
+    "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_merge_points", "nudf_coarse_z", "nudf_coarse_start", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
@@ -213,6 +215,8 @@ _ARGTYPES = {
     "nudf_upsample": [C.POINTER(Upsample), _P],
     "nudf_merge": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "nudf_coarse_z": [_P, _P, _I, _P, _I, _I, _P, _P, _P],
+    "nudf_coarse_start": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "nudf_merge_points": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "nudf_outside_z": [_P, _I, _P, _I, _I, _I, _P, _P],
     "nudf_ray_points": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
     "nudf_posenc": [_P, _I, _I, _P, _I, _I, _F, _I, _P, _I, _F, _P, _I, _F, _P],

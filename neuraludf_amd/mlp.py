@@ -779,9 +779,9 @@ class UDFEngine:
         skip_ok = len(self.skip) <= 1 and all(0 < s < self.L for s in self.skip)
         return USE_CHAIN and net.multires > 0 and net.d_in == 3 and widths_ok and skip_ok and self.L + 2 <= CH_MAX_STEPS
 
-    def forward(self, x, need_grad_state, feat_ld=0, udf_only=False):
+    def forward(self, x, need_grad_state, feat_ld=0, udf_only=False, feat_buf=None):
         if self._chain_ok():
-            return self._forward_chain(x, need_grad_state, feat_ld, udf_only)
+            return self._forward_chain(x, need_grad_state, feat_ld, udf_only, feat_buf)
         return self._forward_layers(x, need_grad_state, feat_ld, udf_only)
 
     def gradient(self, x, st):
@@ -816,8 +816,9 @@ class UDFEngine:
         """tile column where PE(x)/sqrt(2) starts in the input of skip layer l."""
         return self.layers[l].inp - self.E
 
-    def _forward_chain(self, x, need_grad_state, feat_ld=0, udf_only=False):
-        """one launch: posenc -> 8 softplus layers -> abs head, activations resident in LDS."""
+    def _forward_chain(self, x, need_grad_state, feat_ld=0, udf_only=False, feat_buf=None):
+        """one launch: posenc -> 8 softplus layers -> abs head, activations resident in LDS.
+        feat_buf: [pad_rows(P), max(feat_ld, F)] with [x | 0] already in columns F.. (nudf_merge_points), or None."""
         P, dev, L = x.shape[0], x.device, self.L
         net = self.net
         pack_group(self.layers, self._frag_kinds())
@@ -845,12 +846,15 @@ class UDFEngine:
         feat = None
         if not udf_only:
             ld = max(feat_ld, F)
-            feat = torch.empty((Pp, ld), device=dev)
-            if ld >= F + 3:
-                call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
-                _zero_cols(feat, F + 3)
+            if feat_buf is not None and tuple(feat_buf.shape) == (Pp, ld) and ld >= F + 3 and feat_buf.is_contiguous():
+                feat = feat_buf
             else:
-                _zero_cols(feat, F)
+                feat = torch.empty((Pp, ld), device=dev)
+                if ld >= F + 3:
+                    call("nudf_copy_cols", ptr(x), 3, 1, ptr(feat) + 4 * F, ld, 3, P, 1.0)
+                    _zero_cols(feat, F + 3)
+                else:
+                    _zero_cols(feat, F)
             cb.step("NONE", pl.frag(_kind("fwd_feat", "fwd")), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat,
                     act_write=0)
         cb.step("UDFHEAD", pl.frag("fwd_head0"), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,

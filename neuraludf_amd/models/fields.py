@@ -36,11 +36,11 @@ class _UDFEvalFn(torch.autograd.Function):
     colour network's base input ([feat F | pts 3 | zero pad], see mlp.ColorEngine)."""
 
     @staticmethod
-    def forward(ctx, engine, x, want_grad, feat_ld, normals_col, *params):
+    def forward(ctx, engine, x, want_grad, feat_ld, normals_col, feat_buf, *params):
         ctx.set_materialize_grads(False)     # unused outputs arrive as None, not as zero-filled tensors
         x = x.detach().contiguous()
         need_state = any(ctx.needs_input_grad)      # all False under no_grad (grad mode is off inside forward)
-        st = engine.forward(x, need_grad_state=(need_state or want_grad), feat_ld=feat_ld)
+        st = engine.forward(x, need_grad_state=(need_state or want_grad), feat_ld=feat_ld, feat_buf=feat_buf)
         g = DA = None
         if want_grad:
             g, DA = engine.gradient(x, st)
@@ -62,7 +62,7 @@ class _UDFEvalFn(torch.autograd.Function):
     def backward(ctx, d_udf, d_feat, d_g):
         engine, st = ctx.engine, ctx.st
         if d_udf is None and d_feat is None and (d_g is None or d_g.numel() == 0):
-            return (None, None, None, None, None) + (None,) * len(engine.params())
+            return (None, None, None, None, None, None) + (None,) * len(engine.params())
         if st is None:
             raise RuntimeError("UDF evaluation was run without gradient state")
         if d_g is not None and d_g.numel() == 0:
@@ -87,7 +87,7 @@ class _UDFEvalFn(torch.autograd.Function):
         grads = engine.backward(ctx.x, st, ctx.DA, d_udf.contiguous() if d_udf is not None else None,
                                 d_feat, ldf, d_g.contiguous() if d_g is not None else None)
         ctx.st = ctx.DA = None
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class UDFNetwork(nn.Module):
@@ -145,11 +145,13 @@ class UDFNetwork(nn.Module):
         if self._engine is not None:
             self._engine.invalidate()
 
-    def evaluate(self, x, want_grad=True, feat_ld=0, normals_col=-1):
+    def evaluate(self, x, want_grad=True, feat_ld=0, normals_col=-1, feat_buf=None):
         """fused value + spatial gradient: -> (udf [P], featbuf [P, max(feat_ld, F)], grad [P,3] or empty).
-        normals_col >= 0: also write the detached unit normal and its negative at these 6 columns of featbuf."""
+        normals_col >= 0: also write the detached unit normal and its negative at these 6 columns of featbuf.
+        feat_buf: a [pad_rows(P), feat_ld] buffer whose columns F.. already hold [x | 0] (nudf_merge_points wrote them):
+        used as featbuf, the copy of x and the pad fill are skipped."""
         eng = self.engine()
-        return _UDFEvalFn.apply(eng, x, want_grad, feat_ld, normals_col, *eng.params())
+        return _UDFEvalFn.apply(eng, x, want_grad, feat_ld, normals_col, feat_buf, *eng.params())
 
     @property
     def n_feature(self):

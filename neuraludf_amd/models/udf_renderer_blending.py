@@ -27,6 +27,7 @@ import os
 
 from .._lib import Composite, CompositeGrad, Upsample, call, ptr
 from .. import dist as nudf_dist
+from .. import mlp
 
 # Arithmetic of the up-sampling kernel (include/nudf.h), all four on by default -- together they reproduce the CPU
 # reference's new samples on EVERY ray of BASELINE config 2 when fed the reference's own (z, udf) (0 of 512 rays moved by
@@ -271,6 +272,7 @@ class UDFRendererBlending:
         from .patch_projector import PatchProjector
         self.patch_projector = PatchProjector(self.h_patch_size)
         self._u_cache = {}
+        self._mid = None        # (z_vals, mid points, colour-input buffer) left by _merge_last for render_core
 
     # ------------------------------------------------------------------------------------
     def _scalars(self, dev):
@@ -300,17 +302,30 @@ class UDFRendererBlending:
             self._u_cache[key] = torch.linspace(0. + 0.5 / k, 1. - 0.5 / k, steps=k).to(dev).contiguous()
         return self._u_cache[key]
 
-    def _udf_at(self, rays_o, rays_d, z, sample_dist):
+    def _udf_at(self, rays_o, rays_d, z, sample_dist, pts=None):
         N, M = z.shape
-        pts = torch.empty(N * M, 3, device=z.device)
-        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z), ptr(sample_dist), N, M, 0, ptr(pts))
+        if pts is None:
+            pts = torch.empty(N * M, 3, device=z.device)
+            call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z), ptr(sample_dist), N, M, 0, ptr(pts))
         return self.udf_network.udf_only(pts).reshape(N, M)
 
-    def _upsample(self, rays_o, rays_d, z, udf, sample_dist, k, mode, inv_s, beta, gamma, gamma_dev=None, dbg=None):
-        """`dbg`: optional [N, 7, M] device tensor for the kernel's per-section intermediates (include/nudf.h)."""
-        N, M = z.shape
-        dev = z.device
+    def _upsample(self, rays_o, rays_d, z, udf, sample_dist, k, mode, inv_s, beta, gamma, gamma_dev=None, dbg=None,
+                  pending=None):
+        """`dbg`: optional [N, 7, M] device tensor for the kernel's per-section intermediates (include/nudf.h).
+        `pending` = (z_prev, udf_prev, z_add, udf_add): the previous round's merge runs inside this launch (z, udf are
+        ignored) and the merged lists are returned as well: -> (z_new, pts_new, z_merged, udf_merged)."""
+        dev = rays_o.device
         a = Upsample()
+        keep = None
+        if pending is not None:
+            zp, up, za, ua = keep = [t.contiguous() for t in pending]
+            N, M = zp.shape[0], zp.shape[1] + za.shape[1]
+            z = torch.empty(N, M, device=dev)
+            udf = torch.empty(N, M, device=dev)
+            a.prev_z, a.prev_udf, a.add_z, a.add_udf = ptr(zp), ptr(up), ptr(za), ptr(ua)
+            a.z_merged, a.udf_merged, a.merge_K = ptr(z), ptr(udf), za.shape[1]
+        else:
+            N, M = z.shape
         a.rays_o, a.rays_d, a.z, a.udf = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf)
         a.u, a.sample_dist, a.gamma_dev = ptr(self._quantiles(k, dev)), ptr(sample_dist), ptr(gamma_dev)
         a.N, a.M, a.K, a.mode = N, M, k, mode | (256 if self.sdf2alpha_type == 'theorical' else 0) | UPSAMPLE_FLAGS
@@ -319,6 +334,8 @@ class UDFRendererBlending:
         pts_new = torch.empty(N * k, 3, device=dev)
         a.z_new, a.pts_new, a.dbg = ptr(z_new), ptr(pts_new), ptr(dbg)
         call("nudf_upsample", a)
+        if pending is not None:
+            return z_new, pts_new, z, udf
         return z_new, pts_new
 
     def _merge(self, z, udf, z_new, udf_new):
@@ -330,40 +347,73 @@ class UDFRendererBlending:
              ptr(uo))
         return zo, uo
 
+    def _merge_last(self, rays_o, rays_d, z, z_new, sample_dist):
+        """the schedule's last merge (z only) together with what render_core does first with its result: the interval mid
+        points, and their copy (+ zero pad) behind the feature columns of the colour network's input rows -- one launch
+        instead of merge, ray_points, copy_cols and a fill.  The by-products wait in `self._mid` for render_core."""
+        N, M = z.shape
+        K = z_new.shape[1]
+        S = M + K
+        dev = z.device
+        zo = torch.empty(N, S, device=dev)
+        pts = torch.empty(N * S, 3, device=dev)
+        ceng = self.color_network.engine()
+        F, ld = ceng.F, ceng.cin_ld
+        feat = None
+        if ld >= F + 3:
+            feat = torch.empty(mlp.pad_rows(N * S), ld, device=dev)
+        call("nudf_merge_points", ptr(z.contiguous()), ptr(z_new), N, M, K, ptr(zo), ptr(rays_o), ptr(rays_d),
+             ptr(sample_dist), ptr(pts), (ptr(feat) + 4 * F) if feat is not None else None, ld, ld - F)
+        self._mid = (zo, pts, feat)
+        return zo
+
     @torch.no_grad()
-    def importance_sample(self, rays_o, rays_d, z_vals, sample_dist):
-        """classical schedule (:723-755). `sample_dist` is a 1-element device tensor."""
+    def importance_sample(self, rays_o, rays_d, z_vals, sample_dist, pts0=None):
+        """classical schedule (:723-755). `sample_dist` is a 1-element device tensor; `pts0`: the points of `z_vals` if
+        the caller has them (nudf_coarse_start).  Each round's merge runs at the head of the next round's launch."""
         N = rays_o.shape[0]
-        udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist)
+        udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist, pts0)
         steps = self.up_sample_steps
         k = self.n_importance // steps
+        pend = None
         for i in range(steps):
             gamma = float(np.clip(20 * 2 ** (steps - i), 20, 320))
-            z_new, pts_new = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 0, 64 * 2 ** i,
-                                            64 * 2 ** (i + 1), gamma)
-            last = (i + 1 == steps)
-            udf_new = None if last else self.udf_network.udf_only(pts_new).reshape(N, k)
-            z_vals, udf = self._merge(z_vals, udf, z_new, udf_new)
+            if pend is None:
+                z_new, pts_new = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 0, 64 * 2 ** i,
+                                                64 * 2 ** (i + 1), gamma)
+            else:
+                z_new, pts_new, z_vals, udf = self._upsample(rays_o, rays_d, None, None, sample_dist, k, 0, 64 * 2 ** i,
+                                                             64 * 2 ** (i + 1), gamma, pending=pend)
+            if i + 1 == steps:
+                return self._merge_last(rays_o, rays_d, z_vals, z_new, sample_dist)
+            pend = (z_vals, udf, z_new, self.udf_network.udf_only(pts_new).reshape(N, k))
         return z_vals
 
     @torch.no_grad()
-    def importance_sample_mix(self, rays_o, rays_d, z_vals, sample_dist):
+    def importance_sample_mix(self, rays_o, rays_d, z_vals, sample_dist, pts0=None):
         """mix schedule (:762-832): `steps` not-occlusion-aware rounds + one unbiased round."""
         N = rays_o.shape[0]
-        udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist)
+        udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist, pts0)
         steps = self.up_sample_steps
         k = self.n_importance // (steps + 1)
         gamma_dev = self.beta_network.get_gamma().clip(1e-6, 1e6).detach().reshape(1).contiguous()
+        pend = None
         for i in range(steps):
-            z_new, pts_new = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 1, 64 * 2 ** i,
-                                            64 * 2 ** (i + 1), 0.0, gamma_dev)
-            udf_new = self.udf_network.udf_only(pts_new).reshape(N, k)
-            z_vals, udf = self._merge(z_vals, udf, z_new, udf_new)
+            if pend is None:
+                z_new, pts_new = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 1, 64 * 2 ** i,
+                                                64 * 2 ** (i + 1), 0.0, gamma_dev)
+            else:
+                z_new, pts_new, z_vals, udf = self._upsample(rays_o, rays_d, None, None, sample_dist, k, 1, 64 * 2 ** i,
+                                                             64 * 2 ** (i + 1), 0.0, gamma_dev, pending=pend)
+            pend = (z_vals, udf, z_new, self.udf_network.udf_only(pts_new).reshape(N, k))
         i = steps - 1
-        z_new, _ = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 0, 64 * 2 ** i, 64 * 2 ** (i + 1),
-                                  20 if i < 4 else 10)
-        z_vals, _ = self._merge(z_vals, udf, z_new, None)
-        return z_vals
+        if pend is None:
+            z_new, _ = self._upsample(rays_o, rays_d, z_vals, udf, sample_dist, k, 0, 64 * 2 ** i, 64 * 2 ** (i + 1),
+                                      20 if i < 4 else 10)
+        else:
+            z_new, _, z_vals, udf = self._upsample(rays_o, rays_d, None, None, sample_dist, k, 0, 64 * 2 ** i,
+                                                   64 * 2 ** (i + 1), 20 if i < 4 else 10, pending=pend)
+        return self._merge_last(rays_o, rays_d, z_vals, z_new, sample_dist)
 
     # ------------------------------------------------------------------------------------
     def render_core_outside(self, rays_o, rays_d, z_out, sample_dist, z_in=None):
@@ -391,12 +441,17 @@ class UDFRendererBlending:
         N, S = z_vals.shape
         dev = z_vals.device
         P = N * S
-        pts = torch.empty(P, 3, device=dev)
-        call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z_vals), ptr(sample_dist), N, S, 1, ptr(pts))
+        mid, self._mid = getattr(self, "_mid", None), None
+        feat_buf = None
+        if mid is not None and mid[0] is z_vals:           # nudf_merge_points already produced them (importance sampling)
+            pts, feat_buf = mid[1], mid[2]
+        else:
+            pts = torch.empty(P, 3, device=dev)
+            call("nudf_ray_points", ptr(rays_o), ptr(rays_d), ptr(z_vals), ptr(sample_dist), N, S, 1, ptr(pts))
         ceng = self.color_network.engine()
         # (colour-net modes that see the detached unit normal, :371, :425: it rides in the same buffer)
         udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld,
-                                                   normals_col=(ceng.F + 3) if ceng.nrm else -1)
+                                                   normals_col=(ceng.F + 3) if ceng.nrm else -1, feat_buf=feat_buf)
         cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
         scal, recip = self._scalars(dev)
         c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,
@@ -484,7 +539,7 @@ class UDFRendererBlending:
         if perturb > 0:
             # drawn on the rays' device: the reference draws on its default device, which the runner makes the GPU
             # (exp_runner_blending.py:872), so the draw order / shapes / generator are the same
-            t_rand = (torch.rand([N, 1], device=dev) - 0.5).contiguous()        # (:618)
+            t_rand = torch.rand([N, 1], device=dev)        # (:618); its - 0.5 is applied by the kernel (one launch less)
             if self.n_outside > 0:                                               # (:621-627) stratified jitter
                 mids = .5 * (lin[..., 1:] + lin[..., :-1])
                 upper = torch.cat([mids, lin[..., -1:]], -1)
@@ -492,8 +547,10 @@ class UDFRendererBlending:
                 lin = lower + (upper - lower) * torch.rand(lin.shape, device=dev)
         z_vals = torch.empty(N, self.n_samples, device=dev)
         sample_dist = torch.empty(1, device=dev)
-        call("nudf_coarse_z", ptr(near), ptr(far), nf_stride, ptr(t_rand), N, self.n_samples, ptr(z_vals),
-             ptr(sample_dist))
+        want_pts0 = z_vals_override is None and self.n_importance > 0 and self.upsampling_type in ('classical', 'mix')
+        pts0 = torch.empty(N * self.n_samples, 3, device=dev) if want_pts0 else None
+        call("nudf_coarse_start", ptr(near), ptr(far), nf_stride, ptr(t_rand), 1, N, self.n_samples, ptr(z_vals),
+             ptr(sample_dist), ptr(rays_o), ptr(rays_d), ptr(pts0))
         z_out = None
         if self.n_outside > 0:
             z_out = torch.empty(N, self.n_outside, device=dev)
@@ -509,9 +566,9 @@ class UDFRendererBlending:
             n_samples = z_vals.shape[1]
         elif self.n_importance > 0:
             if self.upsampling_type == 'classical':
-                z_vals = self.importance_sample(rays_o, rays_d, z_vals, sample_dist)
+                z_vals = self.importance_sample(rays_o, rays_d, z_vals, sample_dist, pts0)
             elif self.upsampling_type == 'mix':
-                z_vals = self.importance_sample_mix(rays_o, rays_d, z_vals, sample_dist)
+                z_vals = self.importance_sample_mix(rays_o, rays_d, z_vals, sample_dist, pts0)
             n_samples = self.n_samples + self.n_importance
 
         bg_sigma = bg_color = bg_color_in = None
