@@ -113,6 +113,10 @@ typedef struct NudfGemmTNGroup {
                                                    are refused with hipErrorInvalidValue); consecutive launches may
                                                    accumulate into the same C.                                       */
   int64_t workspace_floats;
+  int32_t assign;                               /* != 0 (workspace path only): the reduction ASSIGNS C and dbias (0 + the
+                                                   ordered sum) instead of adding to them -- the first launch into a
+                                                   gradient buffer then needs no zero fill.  Elements the group does not
+                                                   cover (rows >= NA, columns >= NB) are left untouched.               */
 } NudfGemmTNGroup;
 int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);
 /* floats of workspace this group needs (0 for an empty group, < 0 on an invalid one) */
@@ -178,6 +182,16 @@ typedef struct NudfComposite {
                                                   fields above, or NULL: lets a captured HIP graph of the train step (kernel
                                                   arguments frozen at capture) follow the per-iteration schedules
                                                   (exp_runner_blending.py:193-228); has_anneal stays by value            */
+  /* the renderer scalars formed in this launch instead of by nudf_scalars_fwd (one launch less each way):
+     p_variance != NULL -> `scal` is ignored; inv_s / beta / gamma come from the three 1-element parameters exactly as
+     nudf_scalars_fwd forms them (beta_hi = 1 / beta_min), and the forward writes them to scal_out [3] / recip_out [2]
+     (= 1 / inv_s, 1 / beta) when given */
+  const float* p_variance; const float* p_beta; const float* p_gamma;
+  float beta_hi;
+  int32_t defer_sums;                          /* != 0 (needs ws): the per-block partials stay in ws and `sums` is NOT
+                                                  written -- nudf_partial_sums(ws, ceil(N/4), 5, sums) or the ws argument
+                                                  of nudf_step_loss_fwd finishes the reduction in the consumer's launch */
+  float* scal_out; float* recip_out;
 } NudfComposite;
 
 typedef struct NudfCompositeGrad {
@@ -196,10 +210,15 @@ typedef struct NudfCompositeGrad {
   float* o_d_bg_color;                                /* [N,n_out,3] or NULL                */
   float* o_d_scal;                                    /* [3] d inv_s, d beta, d gamma: assigned when ws is given, += otherwise */
   float* ws;                                          /* scratch [3 * ceil(N/4)] or NULL (see NudfComposite.ws) */
+  float* o_d_param;                                   /* [3] d variance, d beta, d gamma (needs p_variance and ws): the
+                                                         reduction of the partials and nudf_scalars_bwd as one launch */
 } NudfCompositeGrad;
 
 int nudf_composite_fwd(const NudfComposite* args, void* stream);
 int nudf_composite_bwd(const NudfComposite* args, const NudfCompositeGrad* grads, void* stream);
+/* out[k] = sum over the nblk rows of ws [nblk, K] (K <= 8), fixed order: the second stage of the composite kernels'
+ * deterministic batch sums, for a caller that asked them to leave the partials (NudfComposite.defer_sums) */
+int nudf_partial_sums(const float* ws, int nblk, int K, float* out, void* stream);
 /* Layout of the FULL case (S = 128 / 256 / 512 inside samples, no outside samples, no diagnostics): 1 = lane l owns
  * S/64 consecutive samples (16-byte vector accesses), 0 (default) = sample i in lane i % 64 for every shape.  Same
  * arithmetic, different association of the two product scans; A-B switch (the two measure the same on MI355X). */
@@ -626,17 +645,22 @@ int nudf_color_loss_finish(const float* sums, int has_mask, float w_b, float w_c
  * nudf_sums_errors_fwd + total = ((cl + gens w_igr_ns) + sparse w_sparse) + ge w_igr in one launch, each product / sum
  * of the last line rounded on its own like the runner's scalar torch ops.  out[8] = {total, cl, Lb, Lc, ge, gens,
  * sparse, 0}; den_out[1].  bwd: upstream d_total (device scalar, NULL = 1) and optionally d_extra[8] for the other
- * outputs (indexed like out[], NULL = none) -> d_cb / d_c [n] and d_sums[5]. */
+ * outputs (indexed like out[], NULL = none) -> d_cb / d_c [n] and d_sums[5].
+ * sums_ws != NULL: the composite kernel left its per-block partial sums [sums_nblk, 5] there (NudfComposite.defer_sums);
+ * this launch reduces them first (nudf_partial_sums' order) and WRITES the five sums to `sums` as well. */
 int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
-                       const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns,
-                       float w_sparse, const float* w_dev, float* out, float* den_out, void* stream);
+                       float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns,
+                       float w_sparse, const float* w_dev, float* out, float* den_out, const float* sums_ws,
+                       int sums_nblk, void* stream);
 int nudf_step_loss_bwd(const float* cb, const float* c, const float* gt, int n, const float* den, const float* sums,
                        float n_rays, float w_b, float w_c, float w_px, float w_igr, float w_igr_ns, float w_sparse,
                        const float* w_dev, const float* d_total, const float* d_extra, float* d_cb, float* d_c, float* d_sums,
                        void* stream);
 /* out4 [P_pad, 4] (16-byte aligned): column 0 = sign[r] * d[r] * scale (d NULL: sign[r] * scale) for r < P, everything
  * else zero: the 4-wide column-0 operand of the UDF head's adjoint and second-order weight gradient (fields.py:184-231) */
-int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4, void* stream);
+/* out4_sign (NULL or like out4): column 0 = sign[r] * scale, written by the same launch */
+int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4, float* out4_sign,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------
  * GPU-resident ray / patch batch generation: Dataset.gen_random_rays_patches_at (dataset/dataset.py:228-294) and

@@ -46,7 +46,8 @@ class GemmTNProblem(C.Structure):
 
 class GemmTNGroup(C.Structure):
     _fields_ = [("n_problems", i32), ("M", i32), ("rows_per_block", i32), ("total_tiles", i32), ("prec", i32),
-                ("prob", GemmTNProblem * TN_MAX_PROBLEMS), ("workspace", c_fp), ("workspace_floats", C.c_int64)]
+                ("prob", GemmTNProblem * TN_MAX_PROBLEMS), ("workspace", c_fp), ("workspace_floats", C.c_int64),
+                ("assign", i32)]
 
 
 class RayBatch(C.Structure):
@@ -67,14 +68,16 @@ class Composite(C.Structure):
                 ("out_normals", c_fp), ("out_wsum", c_fp), ("out_wsum_all", c_fp), ("sums", c_fp), ("ws", c_fp),
                 ("o_alpha", c_fp), ("o_alpha_plus", c_fp), ("o_alpha_minus", c_fp), ("o_vis_prob", c_fp),
                 ("o_alpha_occ", c_fp), ("o_raw_occ", c_fp), ("o_true_cos", c_fp), ("o_grad_mag", c_fp),
-                ("o_mid_z", c_fp), ("o_dists", c_fp), ("o_inside", c_fp), ("o_flip", c_fp), ("sched", c_fp)]
+                ("o_mid_z", c_fp), ("o_dists", c_fp), ("o_inside", c_fp), ("o_flip", c_fp), ("sched", c_fp),
+                ("p_variance", c_fp), ("p_beta", c_fp), ("p_gamma", c_fp), ("beta_hi", f32), ("defer_sums", i32),
+                ("scal_out", c_fp), ("recip_out", c_fp)]
 
 
 class CompositeGrad(C.Structure):
     _fields_ = [("d_color", c_fp), ("d_color_base", c_fp), ("d_weights", c_fp), ("d_depth", c_fp),
                 ("d_normals", c_fp), ("d_wsum", c_fp), ("d_wsum_all", c_fp), ("d_sums", c_fp),
                 ("o_d_udf", c_fp), ("o_d_grad", c_fp), ("o_d_color", c_fp), ("o_d_color_base", c_fp),
-                ("o_d_bg_sigma", c_fp), ("o_d_bg_color", c_fp), ("o_d_scal", c_fp), ("ws", c_fp)]
+                ("o_d_bg_sigma", c_fp), ("o_d_bg_color", c_fp), ("o_d_scal", c_fp), ("ws", c_fp), ("o_d_param", c_fp)]
 
 
 class Upsample(C.Structure):
@@ -187,7 +190,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_gemm_tn_grouped_plan", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
-    "nudf_composite_bwd", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_merge_points", "nudf_coarse_z", "nudf_coarse_start", "nudf_outside_z",
+    "nudf_composite_bwd", "nudf_partial_sums", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_merge_points", "nudf_coarse_z", "nudf_coarse_start", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
@@ -212,6 +215,7 @@ _ARGTYPES = {
     "nudf_set_tn_debug": [_P],
     "nudf_composite_fwd": [C.POINTER(Composite), _P],
     "nudf_composite_bwd": [C.POINTER(Composite), C.POINTER(CompositeGrad), _P],
+    "nudf_partial_sums": [_P, _I, _I, _P, _P],
     "nudf_upsample": [C.POINTER(Upsample), _P],
     "nudf_merge": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "nudf_coarse_z": [_P, _P, _I, _P, _I, _I, _P, _P, _P],
@@ -255,9 +259,9 @@ _ARGTYPES = {
     "nudf_gen_ray_batch": [C.POINTER(RayBatch), _P],
     "nudf_color_loss_sums": [_P, _P, _P, _I, _P, _I, _P, _P],
     "nudf_color_loss_finish": [_P, _I, _F, _F, _F, _P, _P, _P, _P],
-    "nudf_step_loss_fwd": [_P, _P, _P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "nudf_step_loss_fwd": [_P, _P, _P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _P],
     "nudf_step_loss_bwd": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
-    "nudf_col0_seed4": [_P, _P, _F, _I, _I, _P, _P],
+    "nudf_col0_seed4": [_P, _P, _F, _I, _I, _P, _P, _P],
 }
 
 _lib = None

@@ -31,6 +31,26 @@ struct RayConst {
   float inv_s, beta, gamma, sdist;
 };
 
+// inv_s, beta, gamma of a launch: from the clipped device vector, or formed here from the three parameters with
+// scalars_fwd_kernel's expressions (rays_embed.hip; fields.py:654-655, 674-678 + the clips of :373-377)
+__device__ __forceinline__ void comp_scalars(const NudfComposite& p, float& inv_s, float& beta, float& gamma) {
+  if (p.p_variance) {
+    inv_s = fminf(fmaxf(expf(10.0f * p.p_variance[0]), 1e-6f), 1e6f);
+    beta = fminf(fmaxf(fminf(fmaxf(expf(10.0f * p.p_beta[0]), 0.0f), p.beta_hi), 1e-6f), 1e6f);
+    gamma = fminf(fmaxf(expf(10.0f * p.p_gamma[0]), 1e-6f), 1e6f);
+  } else {
+    inv_s = p.scal[0]; beta = p.scal[1]; gamma = p.scal[2];
+  }
+}
+__device__ __forceinline__ void comp_scalars_out(const NudfComposite& p) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && p.p_variance) {
+    float s, b, g;
+    comp_scalars(p, s, b, g);
+    if (p.scal_out) { p.scal_out[0] = s; p.scal_out[1] = b; p.scal_out[2] = g; }
+    if (p.recip_out) { p.recip_out[0] = 1.0f / s; p.recip_out[1] = 1.0f / b; }
+  }
+}
+
 __device__ __forceinline__ float iter_cos_of(float c, int has_r, float r) {
   // c = -|true_cos| <= 0 ; udf_renderer_blending.py:295-299
   if (!has_r) return c;
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     RayConst rc;
     rc.ox = p.rays_o[ray * 3 + 0]; rc.oy = p.rays_o[ray * 3 + 1]; rc.oz = p.rays_o[ray * 3 + 2];
     rc.dx = p.rays_d[ray * 3 + 0]; rc.dy = p.rays_d[ray * 3 + 1]; rc.dz = p.rays_d[ray * 3 + 2];
-    rc.inv_s = p.scal[0]; rc.beta = p.scal[1]; rc.gamma = p.scal[2]; rc.sdist = p.sample_dist[0];
+    comp_scalars(p, rc.inv_s, rc.beta, rc.gamma); rc.sdist = p.sample_dist[0];
 
     float tcv[NC], aocc[NC], alpha[NC], apv[NC], amv[NC], flipv[NC], midv[NC];
     float cr[NC], cg[NC], cb[NC], br[NC], bg[NC], bb[NC], nx[NC], ny[NC], nz[NC];
@@ -341,16 +361,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (p.ws) p.ws[(size_t)blockIdx.x * 5 + threadIdx.x] = t;   // summed by partial_sums_kernel
     else atomicAdd(p.sums + threadIdx.x, t);
-  }
+  }  comp_scalars_out(p);
 }
 
 // out[k] = sum_b ws[b * K + k]  (one block of 1024 threads; fixed order -> deterministic batch-global sums; ASSIGNS).
 // Thread t owns the block rows t, t + 1024, ... and keeps all K (<= 8) running sums, so the partials are read once,
 // coalesced; then one DPP wave reduction per k and a 16-entry LDS pass.  (The first version reduced one k at a time
 // with an LDS tree per k: 27 us for 8192 blocks, a quarter of the whole composite forward at 32768 rays.)
-__global__ __launch_bounds__(1024) void partial_sums_kernel(const float* __restrict__ ws, int nblk, int K,
-                                                            float* __restrict__ out) {
-  __shared__ float red[8][16];
+// the second stage's arithmetic (1024 threads): thread t owns rows t, t + 1024, ...; one wave reduction per k; 16 wave
+// results added in order.  res[k] valid in threads < K after the call.
+__device__ __forceinline__ float partial_sums_body(const float* __restrict__ ws, int nblk, int K, float (&red)[8][16]) {
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
@@ -369,11 +389,43 @@ __global__ __launch_bounds__(1024) void partial_sums_kernel(const float* __restr
     }
   }
   __syncthreads();
-  if (threadIdx.x < K) {
-    float t = 0.f;
+  float t = 0.f;
+  if (threadIdx.x < K)
     for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
-    out[threadIdx.x] = t;
+  return t;
+}
+
+// partial_sums + scalars_bwd_kernel (rays_embed.hip) as one launch: d inv_s / d beta / d gamma summed over the blocks, then
+// through the exp and the clips to the three parameters
+__global__ __launch_bounds__(1024) void partial_sums_scalars_kernel(const float* __restrict__ ws, int nblk,
+                                                                    const float* variance, const float* beta,
+                                                                    const float* gamma, float beta_hi,
+                                                                    float* __restrict__ d_scal_out,
+                                                                    float* __restrict__ d_param) {
+  __shared__ float red[8][16];
+  __shared__ float ds[3];
+  const float t = partial_sums_body(ws, nblk, 3, red);
+  if (threadIdx.x < 3) {
+    ds[threadIdx.x] = t;
+    if (d_scal_out) d_scal_out[threadIdx.x] = t;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = expf(10.0f * variance[0]);
+    d_param[0] = (s >= 1e-6f && s <= 1e6f) ? ds[0] * 10.0f * s : 0.0f;
+    const float b = expf(10.0f * beta[0]);
+    const float b1 = fminf(fmaxf(b, 0.0f), beta_hi);
+    d_param[1] = (b >= 0.0f && b <= beta_hi && b1 >= 1e-6f && b1 <= 1e6f) ? ds[1] * 10.0f * b : 0.0f;
+    const float g = expf(10.0f * gamma[0]);
+    d_param[2] = (g >= 1e-6f && g <= 1e6f) ? ds[2] * 10.0f * g : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void partial_sums_kernel(const float* __restrict__ ws, int nblk, int K,
+                                                            float* __restrict__ out) {
+  __shared__ float red[8][16];
+  const float t = partial_sums_body(ws, nblk, K, red);
+  if (threadIdx.x < K) out[threadIdx.x] = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -392,7 +444,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     RayConst rc;
     rc.ox = p.rays_o[ray * 3 + 0]; rc.oy = p.rays_o[ray * 3 + 1]; rc.oz = p.rays_o[ray * 3 + 2];
     rc.dx = p.rays_d[ray * 3 + 0]; rc.dy = p.rays_d[ray * 3 + 1]; rc.dz = p.rays_d[ray * 3 + 2];
-    rc.inv_s = p.scal[0]; rc.beta = p.scal[1]; rc.gamma = p.scal[2]; rc.sdist = p.sample_dist[0];
+    comp_scalars(p, rc.inv_s, rc.beta, rc.gamma); rc.sdist = p.sample_dist[0];
 
     // upstream gradients (per ray)
     const float dCr = g.d_color ? g.d_color[ray * 3 + 0] : 0.f, dCg = g.d_color ? g.d_color[ray * 3 + 1] : 0.f,
@@ -656,7 +708,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(NudfComposite p, Nud
     if (l == 0) { red[wave][0] = r[0]; red[wave][1] = r[1]; red[wave][2] = r[2]; }
   }
   __syncthreads();
-  if (threadIdx.x < 3 && g.o_d_scal) {
+  if (threadIdx.x < 3 && (g.o_d_scal || g.ws)) {
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (g.ws) g.ws[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
     else atomicAdd(g.o_d_scal + threadIdx.x, t);
@@ -746,7 +798,7 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p)
     RayConst rc;
     rc.ox = p.rays_o[ray * 3 + 0]; rc.oy = p.rays_o[ray * 3 + 1]; rc.oz = p.rays_o[ray * 3 + 2];
     rc.dx = p.rays_d[ray * 3 + 0]; rc.dy = p.rays_d[ray * 3 + 1]; rc.dz = p.rays_d[ray * 3 + 2];
-    rc.inv_s = p.scal[0]; rc.beta = p.scal[1]; rc.gamma = p.scal[2]; rc.sdist = p.sample_dist[0];
+    comp_scalars(p, rc.inv_s, rc.beta, rc.gamma); rc.sdist = p.sample_dist[0];
     const RayRows rr = ray_rows(p, ray);
     const unsigned o1 = (unsigned)l * PER, o3 = (unsigned)l * PER * 3u;
     float zv[PER], uv[PER], gv[3 * PER], cv[3 * PER], bv[3 * PER];
@@ -836,7 +888,7 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p)
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (p.ws) p.ws[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
     else atomicAdd(p.sums + threadIdx.x, t);
-  }
+  }  comp_scalars_out(p);
 }
 
 template <int PER>
@@ -851,7 +903,7 @@ __global__ __launch_bounds__(256) void composite_bwd_blk_kernel(NudfComposite p,
     RayConst rc;
     rc.ox = p.rays_o[ray * 3 + 0]; rc.oy = p.rays_o[ray * 3 + 1]; rc.oz = p.rays_o[ray * 3 + 2];
     rc.dx = p.rays_d[ray * 3 + 0]; rc.dy = p.rays_d[ray * 3 + 1]; rc.dz = p.rays_d[ray * 3 + 2];
-    rc.inv_s = p.scal[0]; rc.beta = p.scal[1]; rc.gamma = p.scal[2]; rc.sdist = p.sample_dist[0];
+    comp_scalars(p, rc.inv_s, rc.beta, rc.gamma); rc.sdist = p.sample_dist[0];
     const float dCr = g.d_color ? g.d_color[ray * 3 + 0] : 0.f, dCg = g.d_color ? g.d_color[ray * 3 + 1] : 0.f,
                 dCb = g.d_color ? g.d_color[ray * 3 + 2] : 0.f;
     const float dBr = g.d_color_base ? g.d_color_base[ray * 3 + 0] : 0.f,
@@ -1009,7 +1061,7 @@ __global__ __launch_bounds__(256) void composite_bwd_blk_kernel(NudfComposite p,
     if (l == 0) { red[wave][0] = r[0]; red[wave][1] = r[1]; red[wave][2] = r[2]; }
   }
   __syncthreads();
-  if (threadIdx.x < 3 && g.o_d_scal) {
+  if (threadIdx.x < 3 && (g.o_d_scal || g.ws)) {
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (g.ws) g.ws[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
     else atomicAdd(g.o_d_scal + threadIdx.x, t);
@@ -1043,6 +1095,10 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
     nudf_set_error("nudf_composite_fwd: 1 <= S, S + n_outside <= 512 required", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
+  if ((p.defer_sums && !p.ws) || (p.p_variance && (!p.p_beta || !p.p_gamma)) || (!p.p_variance && !p.scal)) {
+    nudf_set_error("nudf_composite_fwd: defer_sums needs ws; scalars need scal or all three parameters", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
   dim3 grid((p.N + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   // diagnostics (the 12 per-sample arrays of the full result dict) are a separate instantiation: the training path
@@ -1055,7 +1111,7 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
     if (nc == 2) hipLaunchKernelGGL(composite_fwd_blk_kernel<2>, grid, block, 0, st, p);
     else if (nc == 4) hipLaunchKernelGGL(composite_fwd_blk_kernel<4>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(composite_fwd_blk_kernel<8>, grid, block, 0, st, p);
-    if (p.ws) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, p.ws, (int)grid.x, 5, p.sums);
+    if (p.ws && !p.defer_sums) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, p.ws, (int)grid.x, 5, p.sums);
     NUDF_CHECK_LAUNCH("nudf_composite_fwd");
     return 0;
   }
@@ -1073,9 +1129,20 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
     default: NUDF_CF_LAUNCH(8); break;
   }
 #undef NUDF_CF_LAUNCH
-  if (p.ws) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, p.ws, (int)grid.x, 5, p.sums);
+  if (p.ws && !p.defer_sums) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, p.ws, (int)grid.x, 5, p.sums);
   NUDF_CHECK_LAUNCH("nudf_composite_fwd");
   return 0;
+}
+
+// second stage of the backward's d inv_s / d beta / d gamma: plain sums into o_d_scal, or (o_d_param) the sums taken on
+// through scalars_bwd's expressions to the three parameters in the same launch
+static void composite_bwd_reduce(const NudfComposite& p, const NudfCompositeGrad& g, int nblk, hipStream_t st) {
+  if (!g.ws) return;
+  if (g.o_d_param && p.p_variance)
+    hipLaunchKernelGGL(partial_sums_scalars_kernel, dim3(1), dim3(1024), 0, st, g.ws, nblk, p.p_variance, p.p_beta, p.p_gamma,
+                       p.beta_hi, g.o_d_scal, g.o_d_param);
+  else if (g.o_d_scal)
+    hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, g.ws, nblk, 3, g.o_d_scal);
 }
 
 extern "C" int nudf_composite_bwd(const NudfComposite* args, const NudfCompositeGrad* grads, void* stream) {
@@ -1096,8 +1163,7 @@ extern "C" int nudf_composite_bwd(const NudfComposite* args, const NudfComposite
     if (nc == 2) hipLaunchKernelGGL(composite_bwd_blk_kernel<2>, grid, block, 0, st, p, *grads);
     else if (nc == 4) hipLaunchKernelGGL(composite_bwd_blk_kernel<4>, grid, block, 0, st, p, *grads);
     else hipLaunchKernelGGL(composite_bwd_blk_kernel<8>, grid, block, 0, st, p, *grads);
-    if (grads->ws && grads->o_d_scal)
-      hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, grads->ws, (int)grid.x, 3, grads->o_d_scal);
+    composite_bwd_reduce(p, *grads, (int)grid.x, st);
     NUDF_CHECK_LAUNCH("nudf_composite_bwd");
     return 0;
   }
@@ -1114,8 +1180,17 @@ extern "C" int nudf_composite_bwd(const NudfComposite* args, const NudfComposite
     default: NUDF_CB_LAUNCH(8); break;
   }
 #undef NUDF_CB_LAUNCH
-  if (grads->ws && grads->o_d_scal)
-    hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, grads->ws, (int)grid.x, 3, grads->o_d_scal);
+  composite_bwd_reduce(p, *grads, (int)grid.x, st);
   NUDF_CHECK_LAUNCH("nudf_composite_bwd");
+  return 0;
+}
+
+extern "C" int nudf_partial_sums(const float* ws, int nblk, int K, float* out, void* stream) {
+  if (nblk < 0 || K < 1 || K > 8) {
+    nudf_set_error("nudf_partial_sums: 1 <= K <= 8 required", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ws, nblk, K, out);
+  NUDF_CHECK_LAUNCH("nudf_partial_sums");
   return 0;
 }

@@ -64,6 +64,7 @@ struct TnPlan {
   NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
   TnTile tile[TN_MAX_TILES + 1];   // tile[n_tiles].blk_start = total workgroups
   int n_tiles, M, prec, flags;
+  int assign;                      // reduce kernel: C = 0 + sum instead of C += sum
   float* ws;
   long long* dbg;                  // tuning: per workgroup {start, end} of wall_clock64 (100 MHz), layout, n
 };
@@ -650,7 +651,8 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnPlan g) {
     if (col >= BM || i0 + col >= q.NA) return;
     float s = 0.0f;
     for (int c = 0; c < chunks; ++c) s += ws[(size_t)c * TN_WS_TILE + BM * BN + col];
-    q.dbias[i0 + col] += s;
+    if (g.assign) q.dbias[i0 + col] = 0.0f + s;
+    else q.dbias[i0 + col] += s;
     return;
   }
   const int e = (slice * 256 + threadIdx.x) * 4;            // first of 4 accumulator registers
@@ -665,7 +667,10 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnPlan g) {
   for (int c = 0; c < chunks; ++c) sum += *reinterpret_cast<const f32x4*>(ws + (size_t)c * TN_WS_TILE + e);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (row + k < q.NA) q.C[(size_t)(row + k) * q.ldc + col] += sum[k];
+    if (row + k < q.NA) {
+      float* cp = q.C + (size_t)(row + k) * q.ldc + col;
+      *cp = (g.assign ? 0.0f : *cp) + sum[k];
+    }
 }
 
 
@@ -1363,6 +1368,11 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   if (blocks < 0) return (int)hipErrorInvalidValue;
   pl.ws = (pl.flags & TNF_ATOMICS) ? nullptr : args->workspace;
   pl.dbg = g_tn_dbg;
+  pl.assign = args->assign ? 1 : 0;
+  if (pl.assign && (!pl.ws || (pl.flags & TNF_NO_EPILOGUE))) {
+    nudf_set_error("nudf_gemm_tn_grouped: assign needs the workspace (two-pass) path", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
   if (pl.ws && ((((uintptr_t)pl.ws) & 15) || args->workspace_floats < (int64_t)blocks * TN_WS_TILE)) {
     nudf_set_error("nudf_gemm_tn_grouped: workspace too small or not 16-byte aligned "
                    "(nudf_gemm_tn_grouped_workspace gives the size)", hipErrorInvalidValue);

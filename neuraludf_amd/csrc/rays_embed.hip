@@ -819,12 +819,39 @@ extern "C" int nudf_color_loss_bwd(const float* cb, const float* c, const float*
 __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __restrict__ cb, const float* __restrict__ c,
                                                              const float* __restrict__ gt, int n,
                                                              const float* __restrict__ mask, int n_mask,
-                                                             const float* __restrict__ sums, float n_rays, float w_b,
+                                                             float* sums, float n_rays, float w_b,
                                                              float w_c, float w_px, float w_igr, float w_igr_ns,
                                                              float w_sparse, const float* __restrict__ w_dev, float* out,
-                                                             float* den_out) {
+                                                             float* den_out, const float* __restrict__ sums_ws,
+                                                             int sums_nblk) {
   __shared__ float red[3][16];
+  __shared__ float red5[5][16];
+  __shared__ float s5[5];
   NUDF_LOSS_WEIGHTS6(w_dev, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse);
+  if (sums_ws) {
+    // the composite kernel left its per-block partials (NudfComposite.defer_sums): partial_sums_kernel's reduction here,
+    // same thread layout and order (composite.hip), the five sums written out for the backward
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < sums_nblk; b += 1024) {
+      const float* row = sums_ws + (size_t)b * 5;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc[k] += row[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float t = wave_sum(acc[k]);
+      if ((threadIdx.x & 63) == 0) red5[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += red5[threadIdx.x][w];
+      sums[threadIdx.x] = t;
+      s5[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  const float* sv = sums_ws ? s5 : sums;
   float sb = 0.f, sc = 0.f, sm = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) {
     const float g = gt[i];
@@ -844,9 +871,9 @@ __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __rest
     const float den = mask ? (tm + 1e-4f) : (float)n;
     const float Lb = tb / den, Lc = tc / den;
     const float cl = (Lb * w_b + Lc * w_c) / (w_b + w_c + w_px);
-    const float ge = sums[0] / (sums[1] + 1e-5f);
-    const float gens = sums[2] / (sums[3] + 1e-5f);
-    const float sp = sums[4] / n_rays;
+    const float ge = sv[0] / (sv[1] + 1e-5f);
+    const float gens = sv[2] / (sv[3] + 1e-5f);
+    const float sp = sv[4] / n_rays;
     float total = __fadd_rn(cl, __fmul_rn(gens, w_igr_ns));
     total = __fadd_rn(total, __fmul_rn(sp, w_sparse));
     total = __fadd_rn(total, __fmul_rn(ge, w_igr));
@@ -855,11 +882,11 @@ __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __rest
   }
 }
 extern "C" int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
-                                  const float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr,
+                                  float* sums, float n_rays, float w_b, float w_c, float w_px, float w_igr,
                                   float w_igr_ns, float w_sparse, const float* w_dev, float* out, float* den_out,
-                                  void* stream) {
+                                  const float* sums_ws, int sums_nblk, void* stream) {
   hipLaunchKernelGGL(step_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, sums,
-                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, w_dev, out, den_out);
+                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, w_dev, out, den_out, sums_ws, sums_nblk);
   NUDF_CHECK_LAUNCH("nudf_step_loss_fwd");
   return 0;
 }
@@ -906,21 +933,27 @@ extern "C" int nudf_step_loss_bwd(const float* cb, const float* c, const float* 
   return 0;
 }
 
-// out4 [P_pad, 4]: column 0 = sign * d * scale (d = NULL: sign * scale), the rest (and rows >= P) zero -- the 4-wide
+// out4 [P_pad, 4]: column 0 = sign * d * scale (d = NULL: sign * scale), the rest (and rows >= P) zero; out4_sign (optional,
+// same shape): column 0 = sign * scale in the same launch (the second-order weight gradient's operand) -- the 4-wide
 // column-0 operand of the UDF head's adjoint / second-order weight gradient (mlp.UDFEngine.backward), in one launch
 // instead of a zero fill, two products and a strided copy.  (sign * d) * scale, each product rounded, as torch does.
 __global__ void col0_seed4_kernel(const float* __restrict__ sign, const float* __restrict__ d, float scale, int P, int P_pad,
-                                  float* __restrict__ out4) {
+                                  float* __restrict__ out4, float* __restrict__ out4_sign) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= P_pad) return;
-  float v = 0.0f;
-  if (r < P) v = d ? __fmul_rn(__fmul_rn(sign[r], d[r]), scale) : __fmul_rn(sign[r], scale);
+  float v = 0.0f, vs = 0.0f;
+  if (r < P) {
+    vs = __fmul_rn(sign[r], scale);
+    v = d ? __fmul_rn(__fmul_rn(sign[r], d[r]), scale) : vs;
+  }
   reinterpret_cast<float4*>(out4)[r] = make_float4(v, 0.0f, 0.0f, 0.0f);
+  if (out4_sign) reinterpret_cast<float4*>(out4_sign)[r] = make_float4(vs, 0.0f, 0.0f, 0.0f);
 }
-extern "C" int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4, void* stream) {
+extern "C" int nudf_col0_seed4(const float* sign, const float* d, float scale, int P, int P_pad, float* out4,
+                               float* out4_sign, void* stream) {
   if (P_pad <= 0) return 0;
   hipLaunchKernelGGL(col0_seed4_kernel, dim3(nblocks(P_pad, 256)), dim3(256), 0, (hipStream_t)stream, sign, d, scale, P,
-                     P_pad, out4);
+                     P_pad, out4, out4_sign);
   NUDF_CHECK_LAUNCH("nudf_col0_seed4");
   return 0;
 }

@@ -140,11 +140,18 @@ class _StepLossFn(torch.autograd.Function):
         w_dev = w_dev.detach()
         cb_, c_, gt_ = cb.detach().contiguous(), c.detach().contiguous(), gt.detach().contiguous()
         m_ = mask.detach().float().contiguous() if mask is not None else None
-        sums_ = sums.detach().contiguous()
+        # the composite launch may have left the five sums as per-block partials (NudfComposite.defer_sums): this launch
+        # finishes the reduction and fills `sums` (udf_renderer_blending.pending_sums)
+        pend = getattr(sums, "_nudf_ws", None)
+        if pend is not None:
+            del sums._nudf_ws
+        sums_ = sums.detach()
+        assert sums_.is_contiguous()
         out = torch.empty(8, device=cb_.device)
         den = torch.empty(1, device=cb_.device)
         call("nudf_step_loss_fwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(m_), m_.numel() if m_ is not None else 0,
-             ptr(sums_), float(n_rays), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(out), ptr(den))
+             ptr(sums_), float(n_rays), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(out), ptr(den),
+             ptr(pend[0]) if pend is not None else None, pend[1] if pend is not None else 0)
         ctx.save_for_backward(cb_, c_, gt_, den, sums_, w_dev)
         ctx.n_rays = float(n_rays)
         return tuple(out[i] for i in range(7))

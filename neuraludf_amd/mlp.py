@@ -117,10 +117,12 @@ def _zero_cols(t, c0):
     return t
 
 
-def alloc_grads(layers):
-    """one zero-filled flat buffer for the packed weight / bias gradients of `layers` -> [(dW, db), ...] views."""
+def alloc_grads(layers, zero=True):
+    """one flat buffer for the packed weight / bias gradients of `layers` -> [(dW, db), ...] views.  zero = False: the
+    first weight-gradient launch ASSIGNS every element the unpack kernel reads (`gemm_tn_grouped(..., assign=True)`), so
+    the fill (a 5 us launch per backward) is skipped; pad rows / columns then hold arbitrary values nobody reads."""
     sizes = [(pl.out_pad * pl.in_pad, pl.out_pad) for pl in layers]     # db padded to out_pad keeps 16-byte alignment
-    flat = torch.zeros(sum(a + b for a, b in sizes), device=layers[0].W.device)
+    flat = (torch.zeros if zero else torch.empty)(sum(a + b for a, b in sizes), device=layers[0].W.device)
     out, off = [], 0
     for pl, (a, b) in zip(layers, sizes):
         dW = flat[off:off + a].view(pl.out_pad, pl.in_pad)
@@ -365,8 +367,17 @@ def _tn_workspace(g, dev):
     return ws, ws.numel()
 
 
-def gemm_tn_grouped(jobs, M):
-    """jobs: [(A1 [M, lda], NA, B1 [M, ldb], NB, C [NA_pad, ldc], dbias | None)] -> one launch per <= 12 problems."""
+TN_ASSIGN = os.environ.get("NUDF_TN_ASSIGN", "1") == "1"     # A/B + tests: 0 = zero-filled gradient buffers, accumulate
+
+
+def tn_can_assign():
+    """the weight-gradient launches can ASSIGN their outputs (two-pass deterministic reduction; not the atomic A/B path)"""
+    return TN_ASSIGN and TN_DETERMINISTIC and not (int(os.environ.get("NUDF_TN_FLAGS", "0")) & (8 | 2))
+
+
+def gemm_tn_grouped(jobs, M, assign=False):
+    """jobs: [(A1 [M, lda], NA, B1 [M, ldb], NB, C [NA_pad, ldc], dbias | None)] -> one launch per <= 12 problems.
+    assign: C / dbias are assigned, not accumulated into (every C must then appear in ONE job; see `alloc_grads`)."""
     for base in range(0, len(jobs), _lib.TN_MAX_PROBLEMS):
         chunk = jobs[base:base + _lib.TN_MAX_PROBLEMS]
         g = _lib.GemmTNGroup()
@@ -384,6 +395,7 @@ def gemm_tn_grouped(jobs, M):
         if TN_DETERMINISTIC:
             ws, n = _tn_workspace(g, chunk[0][0].device)
             g.workspace, g.workspace_floats = ptr(ws), n
+        g.assign = 1 if assign else 0
         if PROFILE is not None:
             _timed("gemm_tn", flops, lambda: call("nudf_gemm_tn_grouped", g),
                    "gemm_tn_group_kernel %d problems M=%d (%.1f GFLOP)" % (len(chunk), M, flops / 1e9), nbytes)
@@ -899,7 +911,10 @@ class UDFEngine:
         X, sign = st["X"], st["sign"]
         layers = self.layers
         net = self.net
-        grads = alloc_grads(layers)
+        grouped = os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1"      # A/B switches (profiling)
+        head4_path = grouped and os.environ.get("NUDF_UDF_HEAD4", "1") == "1"
+        assign = head4_path and tn_can_assign()       # the first grouped launch writes every gradient element: no fill
+        grads = alloc_grads(layers, zero=not assign)
         second = d_g is not None and DA is not None
         R = EX = None
         if second:
@@ -919,8 +934,6 @@ class UDFEngine:
                         pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
                         pe_dst=R[l + 1] if nxt_skip else None)
             cb.launch()
-        grouped = os.environ.get("NUDF_UDF_TN_GROUPED", "1") == "1"      # A/B switches (profiling)
-        head4_path = grouped and os.environ.get("NUDF_UDF_HEAD4", "1") == "1"
         inv_scale = 1.0 / float(net.scale)
         if second and not head4_path:
             call("nudf_signed_colsum", ptr(sign), ptr(R[L]), R[L].shape[1], P, layers[L].inp, inv_scale, ptr(grads[L][0]))
@@ -931,11 +944,15 @@ class UDFEngine:
             # the head's adjoint is [sign * d udf / scale | d feat]: d feat is used where it lies (tile load, GEMM operand)
             # and column 0 travels as a 4-wide operand -- no [P, 257] copy (52 us), no separate column-sum kernel (36 us)
             head4 = torch.empty(pad_rows(P), 4, device=dev)
+            # (the second-order weight gradient's operand sign / scale comes out of the same launch)
+            sg4 = torch.empty(pad_rows(P), 4, device=dev) if second else None
             if d_udf is not None:      # column 0 = sign * d udf / scale, the rest zero: one launch
                 call("nudf_col0_seed4", ptr(sign), ptr(d_udf.reshape(-1).contiguous()), float(inv_scale), P, pad_rows(P),
-                     ptr(head4))
+                     ptr(head4), ptr(sg4))
             else:
                 head4.zero_()
+                if second:
+                    call("nudf_col0_seed4", ptr(sign), None, float(inv_scale), P, pad_rows(P), ptr(sg4), None)
             r1, ldr1 = head4, 4
         else:
             ABAR[L] = _buf(P, plL.out, dev, zero=False)
@@ -977,13 +994,11 @@ class UDFEngine:
                 jobs.append((head4, 1, X[L], plL.in_pad, dWL[:1], dbL[:1]))
             else:
                 jobs.append((ABAR[L], plL.out, X[L], plL.in_pad, dWL, dbL))
-            gemm_tn_grouped(jobs, P)
+            gemm_tn_grouped(jobs, P, assign=assign)
             if second:
                 jobs = [(DA[l], layers[l].out, R[l], layers[l].in_pad, grads[l][0], None) for l in range(L)]
                 if head4_path:
-                    sg4 = torch.empty(pad_rows(P), 4, device=dev)
                     # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
-                    call("nudf_col0_seed4", ptr(sign), None, float(inv_scale), P, pad_rows(P), ptr(sg4))
                     jobs.append((sg4, 1, R[L], plL.in_pad, dWL[:1], None))
                 gemm_tn_grouped(jobs, P)
             return unpack_group(layers, grads, claim_grad_slot(self, layers))
@@ -1237,7 +1252,8 @@ class ColorEngine:
         HB, HV = st["HB"], st["HV"]
         dev = color.device
         H, npe, dout = self.H, self.npe, self.dout
-        grads = alloc_grads(self.view + self.base)
+        assign = tn_can_assign()
+        grads = alloc_grads(self.view + self.base, zero=not assign)
         plv = self.view[n - 1]
         nb = plv.out - dout
         sd = HV[1].dtype        # adjoints of the hidden layers follow the saved activations (bf16 in the 16-bit mode)
@@ -1275,7 +1291,7 @@ class ColorEngine:
             jobs.append((Dv[i], pl.out, HV[i], pl.in_pad, grads[i][0], grads[i][1]))
         for i, pl in enumerate(self.base):
             jobs.append((Db[i], pl.out, HB[i], pl.in_pad, grads[n + i][0], grads[n + i][1]))
-        gemm_tn_grouped(jobs, P)
+        gemm_tn_grouped(jobs, P, assign=assign)
         return unpack_group(self.view + self.base, grads, claim_grad_slot(self, self.view + self.base)), dCIN[:P]
 
     def _forward_layers(self, CIN, rays_d, S, P, keep_state=True):
@@ -1537,7 +1553,8 @@ class NerfEngine:
         bw = _kind("bwd", "bwd")
         j = self._skip_layer()
         layers = self._all()
-        grads = alloc_grads(layers)
+        assign = tn_can_assign()
+        grads = alloc_grads(layers, zero=not assign)
         Pp = pad_rows(P)
         Drgb = torch.zeros(Pp, 32, device=dev)
         call("nudf_copy_cols", ptr(d_rgb), 3, 1, ptr(Drgb), 32, 3, P, 1.0)
@@ -1562,7 +1579,7 @@ class NerfEngine:
         jobs.append((dF, self.feature.out, h_last, self.feature.in_pad, grads[D + 1][0], grads[D + 1][1]))
         jobs.append((Dsig, 1, h_last, self.alpha.in_pad, grads[D + 2][0], grads[D + 2][1]))
         jobs.append((Drgb, 3, hv, self.rgb.in_pad, grads[D + 3][0], grads[D + 3][1]))
-        gemm_tn_grouped(jobs, P)
+        gemm_tn_grouped(jobs, P, assign=assign)
         return unpack_group(layers, grads, claim_grad_slot(self, layers))
 
     def _forward_layers(self, pts4, rays_d, S, P, keep_state=True):

@@ -42,6 +42,9 @@ from .. import mlp
 # Why any of it matters: such rays' pdf sits on sample_pdf's 1e-5 floor, where 1e-7 of noise is 1 %.  NUDF_UP_FLAGS=0
 # restores the wave-parallel fp32 scans and libm transcendentals of rounds 1-2 (what the same ops do on a GPU).
 UPSAMPLE_FLAGS = int(os.environ.get("NUDF_UP_FLAGS", str(512 | 1024 | 2048 | 4096)))
+# the renderer scalars (inv_s, beta, gamma) formed inside the composite launches instead of by nudf_scalars_fwd / _bwd
+# (same expressions; NUDF_FUSE_SCALARS=0 restores the separate launches: A/B and tests)
+FUSE_SCALARS = os.environ.get("NUDF_FUSE_SCALARS", "1") == "1"
 
 _DIAG = ["alpha", "alpha_plus", "alpha_minus", "vis_prob", "alpha_occ", "raw_occ", "true_cos", "grad_mag", "mid_z",
          "dists", "inside", "flip"]
@@ -63,7 +66,10 @@ class _CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, c, rays_o, rays_d, z, sample_dist, background_rgb, udf, grad, color, color_base, bg_z, bg_sigma,
-                bg_color, scal):
+                bg_color, scal, p_var=None, p_beta=None, p_gamma=None):
+        """`scal` [3] (clipped inv_s, beta, gamma), or None with the three 1-element parameters `p_var`, `p_beta`,
+        `p_gamma` (+ c["beta_hi"]): the kernels then form the scalars themselves and the two extra outputs at the END of
+        the result tuple are scal [3] and recip [2] (what nudf_scalars_fwd returned), not differentiable."""
         ctx.set_materialize_grads(False)     # unused outputs (depth, normals, diagnostics ...) arrive as None
         N, S = z.shape
         n_out = 0 if bg_z is None else bg_z.shape[1]
@@ -71,12 +77,18 @@ class _CompositeFn(torch.autograd.Function):
         t = lambda x: None if x is None else x.detach().contiguous()
         rays_o, rays_d, z, udf, grad, color, color_base = map(t, (rays_o, rays_d, z, udf, grad, color, color_base))
         bg_z, bg_sigma, bg_color, scal = map(t, (bg_z, bg_sigma, bg_color, scal))
+        p_var, p_beta, p_gamma = map(t, (p_var, p_beta, p_gamma))
         a = Composite()
         a.rays_o, a.rays_d, a.z, a.udf, a.grad = ptr(rays_o), ptr(rays_d), ptr(z), ptr(udf), ptr(grad)
         a.color, a.color_base = ptr(color), ptr(color_base)
         a.bg_z, a.bg_sigma, a.bg_color = ptr(bg_z), ptr(bg_sigma), ptr(bg_color)
         a.scal, a.sample_dist, a.background_rgb = ptr(scal), ptr(sample_dist), ptr(t(background_rgb))
         _fill_composite(a, c, N, S, n_out)
+        scal_out = recip = None
+        if p_var is not None:
+            scal_out, recip = torch.empty(3, device=dev), torch.empty(2, device=dev)
+            a.p_variance, a.p_beta, a.p_gamma, a.beta_hi = ptr(p_var), ptr(p_beta), ptr(p_gamma), float(c["beta_hi"])
+            a.scal_out, a.recip_out = ptr(scal_out), ptr(recip)
         weights = torch.empty(N, S + n_out, device=dev)
         out_color = torch.empty(N, 3, device=dev)
         out_cb = torch.empty(N, 3, device=dev)
@@ -96,17 +108,22 @@ class _CompositeFn(torch.autograd.Function):
                 d = torch.empty(N, S, device=dev)
                 setattr(a, "o_" + k, ptr(d))
                 diag.append(d)
+        if c.get("defer_sums"):
+            # the consumer's launch finishes the two-stage reduction (loss._StepLossFn, or `finish_sums`)
+            a.defer_sums = 1
+            sums._nudf_ws = (ws, (N + 3) // 4)
         call("nudf_composite_fwd", a)
         ctx.c = c
         ctx.save_for_backward(rays_o, rays_d, z, sample_dist, t(background_rgb), udf, grad, color, color_base, bg_z,
-                              bg_sigma, bg_color, scal)
-        ctx.mark_non_differentiable(*diag)
-        return (out_color, out_cb, weights, depth, normals, wsum, wsum_all, sums) + tuple(diag)
+                              bg_sigma, bg_color, scal, p_var, p_beta, p_gamma)
+        extra = () if p_var is None else (scal_out, recip)
+        ctx.mark_non_differentiable(*diag, *extra)
+        return (out_color, out_cb, weights, depth, normals, wsum, wsum_all, sums) + tuple(diag) + extra
 
     @staticmethod
     def backward(ctx, d_color, d_cb, d_weights, d_depth, d_normals, d_wsum, d_wsum_all, d_sums, *_):
         (rays_o, rays_d, z, sample_dist, background_rgb, udf, grad, color, color_base, bg_z, bg_sigma, bg_color,
-         scal) = ctx.saved_tensors
+         scal, p_var, p_beta, p_gamma) = ctx.saved_tensors
         c = ctx.c
         N, S = z.shape
         n_out = 0 if bg_z is None else bg_z.shape[1]
@@ -117,6 +134,8 @@ class _CompositeFn(torch.autograd.Function):
         a.bg_z, a.bg_sigma, a.bg_color = ptr(bg_z), ptr(bg_sigma), ptr(bg_color)
         a.scal, a.sample_dist, a.background_rgb = ptr(scal), ptr(sample_dist), ptr(background_rgb)
         _fill_composite(a, c, N, S, n_out)
+        if p_var is not None:
+            a.p_variance, a.p_beta, a.p_gamma, a.beta_hi = ptr(p_var), ptr(p_beta), ptr(p_gamma), float(c["beta_hi"])
         g = CompositeGrad()
         cg = lambda x: None if x is None else x.contiguous()
         keep = [cg(x) for x in (d_color, d_cb, d_weights, d_depth, d_normals, d_wsum, d_wsum_all, d_sums)]
@@ -128,13 +147,19 @@ class _CompositeFn(torch.autograd.Function):
         o_cb = torch.empty(N, S, 3, device=dev)
         o_sig = torch.empty(N, n_out, device=dev) if n_out else None
         o_bgc = torch.empty(N, n_out, 3, device=dev) if n_out else None
-        o_scal = torch.empty(3, device=dev)                   # assigned (ws given)
+        o_scal = o_par = None
+        if p_var is not None:
+            o_par = torch.empty(3, device=dev)                # d variance, d beta, d gamma: reduction + scalars_bwd, one launch
+        else:
+            o_scal = torch.empty(3, device=dev)               # assigned (ws given)
         ws = torch.empty(3 * ((N + 3) // 4), device=dev)
         g.ws = ptr(ws)
         g.o_d_udf, g.o_d_grad, g.o_d_color, g.o_d_color_base = ptr(o_udf), ptr(o_grad), ptr(o_col), ptr(o_cb)
-        g.o_d_bg_sigma, g.o_d_bg_color, g.o_d_scal = ptr(o_sig), ptr(o_bgc), ptr(o_scal)
+        g.o_d_bg_sigma, g.o_d_bg_color, g.o_d_scal, g.o_d_param = ptr(o_sig), ptr(o_bgc), ptr(o_scal), ptr(o_par)
         call("nudf_composite_bwd", a, g)
-        return (None, None, None, None, None, None, o_udf, o_grad, o_col, o_cb, None, o_sig, o_bgc, o_scal)
+        d_par = (None, None, None) if o_par is None else (o_par[0:1].reshape(p_var.shape), o_par[1:2].reshape(p_beta.shape),
+                                                         o_par[2:3].reshape(p_gamma.shape))
+        return (None, None, None, None, None, None, o_udf, o_grad, o_col, o_cb, None, o_sig, o_bgc, o_scal) + d_par
 
 
 class _ScalarsFn(torch.autograd.Function):
@@ -269,6 +294,8 @@ class UDFRendererBlending:
         self.defer_loss_sums = False       # hand the (local) sums to the caller (key '_loss_sums') instead of the three error
                                            # terms: the ray-sharded step packs them into its one all-reduce, the
                                            # single-process step finishes them inside its fused loss launch (train.Trainer)
+        self.defer_sums_reduce = False     # with defer_loss_sums, single process: '_loss_sums' arrives as per-block partials
+                                           # (tensor attribute _nudf_ws) that loss._StepLossFn / finish_sums reduce
         from .patch_projector import PatchProjector
         self.patch_projector = PatchProjector(self.h_patch_size)
         self._u_cache = {}
@@ -290,11 +317,32 @@ class UDFRendererBlending:
         scal = torch.cat([inv_s, beta, gamma])
         return scal, torch.stack([1.0 / inv_s[0], 1.0 / beta[0]]).detach()
 
+    def _scalar_params(self):
+        """the three 1-element parameters + 1 / beta_min when the scalar networks are the drop-in ones (the composite
+        launch then forms inv_s / beta / gamma itself: no nudf_scalars_fwd / _bwd launches), else None."""
+        dn, bn = self.deviation_network, self.beta_network
+        if (FUSE_SCALARS and isinstance(getattr(dn, "variance", None), torch.Tensor) and dn.variance.numel() == 1
+                and dn.variance.is_cuda and isinstance(getattr(bn, "beta", None), torch.Tensor) and bn.beta.numel() == 1
+                and isinstance(getattr(bn, "gamma", None), torch.Tensor) and bn.gamma.numel() == 1
+                and hasattr(bn, "beta_min")):
+            return dn.variance, bn.beta, bn.gamma, 1.0 / bn.beta_min
+        return None
+
+    @staticmethod
+    def finish_sums(sums):
+        """second stage of the composite sums when the launch left them as per-block partials (NudfComposite.defer_sums)
+        and the consumer is not the fused step loss (which reduces them in its own launch)."""
+        pend = getattr(sums, "_nudf_ws", None)
+        if pend is not None:
+            del sums._nudf_ws
+            call("nudf_partial_sums", ptr(pend[0]), pend[1], 5, ptr(sums))
+        return sums
+
     def errors_from_sums(self, sums, n_local):
         """[eik_num, eik_den, eikns_num, eikns_den, sparse_sum] (batch-global when data parallel) -> (gradient_error,
         gradient_error_near_surface, sparse_error); the sparsity mean runs over ALL rays of the batch."""
         n_rays = float(n_local) * (nudf_dist.world_size() if self.data_parallel else 1)
-        return _ErrorsFn.apply(sums, n_rays)
+        return _ErrorsFn.apply(self.finish_sums(sums), n_rays)
 
     def _quantiles(self, k, dev):
         key = (k, str(dev))
@@ -453,8 +501,15 @@ class UDFRendererBlending:
         udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld,
                                                    normals_col=(ceng.F + 3) if ceng.nrm else -1, feat_buf=feat_buf)
         cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
-        scal, recip = self._scalars(dev)
+        spar = self._scalar_params()
+        scal = recip = None
+        if spar is None:
+            scal, recip = self._scalars(dev)
+        defer = self.defer_loss_sums and (not self.data_parallel or nudf_dist.exchanging())
         c = dict(s_nominal=(s_nominal if s_nominal is not None else S), cos_anneal=cos_anneal_ratio,
+                 beta_hi=(spar[3] if spar is not None else 0.0),
+                 # the caller takes the LOCAL sums: single process -> leave the per-block partials to its fused loss launch
+                 defer_sums=bool(defer and not self.data_parallel and self.defer_sums_reduce),
                  flip_saturation=flip_saturation, use_norm_grad=self.use_norm_grad_for_cosine,
                  sparse_scale=self.sparse_scale_factor, diagnostics=self.diagnostics,
                  alpha_type=1 if self.sdf2alpha_type == 'theorical' else 0,
@@ -463,11 +518,13 @@ class UDFRendererBlending:
                  sched=getattr(self, "sched_scalars", None))
         outs = _CompositeFn.apply(c, rays_o, rays_d, z_vals, sample_dist, background_rgb, udf.reshape(N, S),
                                   grad.reshape(N, S, 3), col.reshape(N, S, 3), cb.reshape(N, S, 3), bg_z, bg_sigma,
-                                  bg_color, scal)
+                                  bg_color, scal, *(spar[:3] if spar is not None else ()))
         color, color_base, weights, depth, normals, wsum, wsum_all, sums = outs[:8]
-        diag = dict(zip(_DIAG, outs[8:])) if self.diagnostics else {}
+        if spar is not None:
+            scal, recip = outs[-2:]
+        diag = dict(zip(_DIAG, outs[8:8 + len(_DIAG)])) if self.diagnostics else {}
         local_sums = None
-        if self.defer_loss_sums and (not self.data_parallel or nudf_dist.exchanging()):
+        if defer:
             # ray-sharded step: the caller packs these five LOCAL sums with its other batch-global partial sums into ONE
             # all-reduce and finishes with `errors_from_sums` (train.Trainer.loss; dist.py (1))
             local_sums = sums

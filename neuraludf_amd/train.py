@@ -264,6 +264,8 @@ class Trainer:
         # sums instead of the three error terms -- requested per call inside `loss` only: a direct `renderer.render(...)`
         # (validation, debugging, the reference runner) keeps the reference's result dict
         self.fuse_loss = not data_parallel
+        self._one = {}
+        self.defer_sums_reduce = True      # (False: the composite launch is followed by its own reduction launch -- A/B, tests)
         if data_parallel:
             self.renderer.data_parallel = True
             self.renderer.defer_loss_sums = True
@@ -307,15 +309,16 @@ class Trainer:
                       rays_uv=batch["rays_uv"].clone() if lc["color_patch_weight"] > 0 else None)
             if "ref_cam" in blend:        # patch-camera constants computed by the caller (GraphedStep: outside the capture)
                 kw["patch_cams"] = (blend["ref_cam"], blend["src_cam"])
-        defer = self.renderer.defer_loss_sums
+        defer, defer_r = self.renderer.defer_loss_sums, self.renderer.defer_sums_reduce
         if self.fuse_loss:
             self.renderer.defer_loss_sums = True
+            self.renderer.defer_sums_reduce = self.defer_sums_reduce   # the fused loss launch finishes the composite's sums
         try:
             out = self.renderer.render(batch["rays_o"], batch["rays_d"], batch["near"], batch["far"],
                                        flip_saturation=flip_saturation, cos_anneal_ratio=cos_anneal_ratio,
                                        perturb_overwrite=perturb_overwrite, **kw)
         finally:
-            self.renderer.defer_loss_sums = defer
+            self.renderer.defer_loss_sums, self.renderer.defer_sums_reduce = defer, defer_r
         weight_sum = out["weight_sum"]
         patch_mask = None
         if out["patch_mask"] is not None:
@@ -376,7 +379,11 @@ class Trainer:
     def step(self, batch, **kw):
         loss, out = self.loss(batch, **kw)
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        # the seed of the backward pass: a resident 1.0 instead of the ones_like(loss) fill autograd would launch
+        one = self._one.get(loss.device)
+        if one is None or one.dtype != loss.dtype:
+            one = self._one[loss.device] = torch.ones((), device=loss.device, dtype=loss.dtype)
+        loss.backward(gradient=one)
         if self.data_parallel:
             self.bucket.all_reduce()
         self.optimizer.step()

@@ -56,10 +56,12 @@ def test_col0_seed4_kernel():
     sign = torch.sign(torch.randn(P, generator=g)).to(dev)
     d = torch.randn(P, generator=g).to(dev)
     out = torch.full((Pp, 4), 7.0, device=dev)
-    call("nudf_col0_seed4", ptr(sign), ptr(d), 0.37, P, Pp, ptr(out))
+    both = torch.full((Pp, 4), 7.0, device=dev)
+    call("nudf_col0_seed4", ptr(sign), ptr(d), 0.37, P, Pp, ptr(out), ptr(both))
     ref = torch.zeros(Pp, 4, device=dev)
     ref[:P, 0] = sign * d * 0.37
     assert torch.equal(out, ref)
-    call("nudf_col0_seed4", ptr(sign), None, 0.37, P, Pp, ptr(out))
+    call("nudf_col0_seed4", ptr(sign), None, 0.37, P, Pp, ptr(out), None)
     ref[:P, 0] = sign * 0.37
     assert torch.equal(out, ref)
+    assert torch.equal(both, ref)          # the second output of the first launch: sign * scale
