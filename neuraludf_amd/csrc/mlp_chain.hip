@@ -282,6 +282,11 @@ __device__ __forceinline__ void ch_split3(const f32x4& lo4, const f32x4& hi4, bf
   p1 = __builtin_bit_cast(bf16x8, b);
   p2 = __builtin_bit_cast(bf16x8, c);
 }
+#ifndef NUDF_X3_BDIST
+#define NUDF_X3_BDIST 1     // A/B build switch: k steps the weight fragments are requested ahead.  2 (three register sets, one
+                            // set of split activations; 5 spilled registers in the 64-point tile) measured the same as 1:
+                            // the fetch is not latency-bound (profiles/r04_bf16x3_experiments.txt item 9)
+#endif
 #ifndef NUDF_X3_PIPE
 #define NUDF_X3_PIPE 0      // A/B build switch: 1 = the next step's split interleaved with this step's MFMAs (measured slower:
                             // 4.63 vs 4.44 ms per step -- two in-phase waves per SIMD already cover each other's split)
@@ -306,6 +311,9 @@ __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const
     }
   };
   auto ldb = [&](uint4 (&bb)[NCT][3], int g) {
+#ifdef NUDF_X3_PROBE_B0      // timing probe only (wrong results): every k step re-reads step 0's fragments -- L1 hits
+    g = 0;
+#endif
     const uint4* bq = bptr + (size_t)g * bstride3;
 #pragma unroll
     for (int j = 0; j < NCT; ++j)
@@ -341,6 +349,43 @@ __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const
 #endif
   };
   const int gl = G16 - 1;
+#if NUDF_X3_BDIST == 2
+  // Weight fragments requested TWO k steps ahead (three register sets in rotation), one set of split activations: the
+  // split of step g + 1 runs after step g's MFMAs have been issued and have read their operands, so it may overwrite them.
+  // (Built because a probe with every k step re-reading step 0's fragments -- L1 hits, NUDF_X3_PROBE_B0 -- runs every chain
+  // launch 12-17 % faster; the distance turned out not to be the reason.)
+  {
+    uint4 b3[3][NCT][3];
+    lda(0);
+    ldb(b3[0], 0);
+    ldb(b3[1], min(1, gl));
+    split(pa[0]);
+    int g3 = 0;
+#define CH_X3_STEP(cur, nxt2, gg)                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    lda(min((gg) + 1, gl));                                         \
+    ldb(b3[nxt2], min((gg) + 2, gl));                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    mfmas(pa[0], b3[cur]);                                          \
+    split(pa[0]);
+#pragma unroll 1
+    for (; g3 + 3 <= G16; g3 += 3) {
+      CH_X3_STEP(0, 2, g3)
+      CH_X3_STEP(1, 0, g3 + 1)
+      CH_X3_STEP(2, 1, g3 + 2)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (g3 + 2 <= G16) {          // two steps left: sets 0 and 1 hold them
+      CH_X3_STEP(0, 2, g3)
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(pa[0], b3[1]);
+    } else if (g3 < G16) {
+      mfmas(pa[0], b3[0]);
+    }
+#undef CH_X3_STEP
+    return;
+  }
+#endif
   lda(0);
   ldb(b[0], 0);
   split(pa[0]);
