@@ -507,32 +507,124 @@ __device__ __forceinline__ void frag_store(const NudfPackFrag& f, int o, int c, 
   }
 }
 
-__global__ __launch_bounds__(256) void wn_pack_multi_kernel(NudfPackMulti a) {
-  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (grow >= a.total_rows) return;
-  int li = 0;
-  while (li + 1 < a.n_layers && a.layer[li + 1].row_start <= grow) ++li;
-  const NudfPackLayer& L = a.layer[li];
-  const int row = grow - L.row_start;
-  const int l = threadIdx.x & 63;
-  float sc = 1.0f;
-  if (L.g) {
-    float ss = 0.f;
-    for (int i = l; i < L.in; i += 64) {
-      const float t = L.v[(size_t)row * L.in + i];
-      ss += t * t;
-    }
-    ss = wave_sum(ss);
-    const float inv = 1.0f / sqrtf(ss);
-    if (l == 0 && L.inv_norm) L.inv_norm[row] = inv;
-    sc = L.g[row] * inv;
+// One workgroup per (layer, panel of 32 output rows).  Phase 1: a wave per row forms the weight_norm scale (same sums,
+// same order as wn_pack_kernel) and stages the scaled row in LDS (packed column order) while writing W.  Phase 2 writes
+// W^T and the fragment copies FROM the panel: a bf16x3 fragment slot holds 8 consecutive k of one column = 16 bytes per
+// plane, so a thread builds whole slots (three 16-byte stores, consecutive threads = consecutive slots) instead of 24
+// two-byte stores scattered over as many cache lines.  Slots whose 8 rows straddle two panels (row offsets that are not
+// a multiple of 8: the abs head's feature rows) and the fp32 / 16-bit fragment kinds keep the per-element stores.
+// Measured (scripts/pack_bench.py under rocprofv3, the nine UDF layers alone): 18.4 us with every fragment kind of a train
+// step, 9.7 us with none (W, W^T, norms; an empty launch is 4.5), 1.5-2 us per slot-built kind, 5.7 us for the kind that
+// still goes element by element; inside the step 25.0 + 16 us (the wave-per-row form it replaces: 25.5 + 18.1) -- the
+// launch is not where the step's time is.  All 197 chain outputs bit-identical to the previous form.
+#define WNP_ROWS 32
+#define WNP_THREADS 1024
+__device__ __forceinline__ void wnp_split8(const float (&w)[8], uint4& hi, uint4& mid, uint4& lo) {
+  unsigned short h[8], m[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {          // the same three roundings as frag_store's dtype 3
+    const __bf16 a = (__bf16)w[j];
+    const float r1 = w[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    h[j] = __builtin_bit_cast(unsigned short, a);
+    m[j] = __builtin_bit_cast(unsigned short, b);
+    q[j] = __builtin_bit_cast(unsigned short, c);
   }
-  for (int i = l; i < L.in; i += 64) {
-    const int c = L.perm ? L.perm[i] : i;
-    const float w = L.v[(size_t)row * L.in + i] * sc;
-    if (L.W) L.W[(size_t)row * L.ldw + c] = w;
-    if (L.Wt) L.Wt[(size_t)c * L.ldwt + row] = w;
-    for (int f = 0; f < L.nfrag; ++f) frag_store(L.frag[f], row, c, w);
+  hi = uint4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+             (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+  mid = uint4{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16),
+              (unsigned)m[4] | ((unsigned)m[5] << 16), (unsigned)m[6] | ((unsigned)m[7] << 16)};
+  lo = uint4{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
+             (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+}
+
+__global__ __launch_bounds__(WNP_THREADS) void wn_pack_multi_kernel(NudfPackMulti a, int pw) {
+  extern __shared__ float panel[];             // [WNP_ROWS][pw], pw = max in rounded up to 32, + 4
+  int li = 0, b = blockIdx.x;
+  for (; li < a.n_layers; ++li) {
+    const int nb = (a.layer[li].out + WNP_ROWS - 1) / WNP_ROWS;
+    if (b < nb) break;
+    b -= nb;
+  }
+  if (li >= a.n_layers) return;
+  const NudfPackLayer& L = a.layer[li];
+  const int row0 = b * WNP_ROWS;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, tid = threadIdx.x;
+  for (int e = tid; e < WNP_ROWS * pw; e += WNP_THREADS) panel[e] = 0.0f;      // rows >= out, columns >= in: zeros
+  __syncthreads();
+  for (int r = wave; r < WNP_ROWS; r += WNP_THREADS / 64) {   // two rows per wave: the row loads are latency, not bandwidth
+    const int row = row0 + r;
+    if (row >= L.out) break;
+    float sc = 1.0f;
+    if (L.g) {
+      float ss = 0.f;
+      for (int i = l; i < L.in; i += 64) {
+        const float t = L.v[(size_t)row * L.in + i];
+        ss += t * t;
+      }
+      ss = wave_sum(ss);
+      const float inv = 1.0f / sqrtf(ss);
+      if (l == 0 && L.inv_norm) L.inv_norm[row] = inv;
+      sc = L.g[row] * inv;
+    }
+    for (int i = l; i < L.in; i += 64) {
+      const int c = L.perm ? L.perm[i] : i;
+      const float w = L.v[(size_t)row * L.in + i] * sc;
+      if (L.W) L.W[(size_t)row * L.ldw + c] = w;
+      panel[r * pw + c] = w;
+    }
+  }
+  __syncthreads();
+  const int nrows = min(WNP_ROWS, L.out - row0);
+  if (L.Wt) {
+    for (int e = tid; e < L.in * WNP_ROWS; e += WNP_THREADS) {      // lanes = consecutive rows of one column: 128-byte runs
+      const int c = e >> 5, r = e & 31;
+      if (r < nrows) L.Wt[(size_t)c * L.ldwt + row0 + r] = panel[r * pw + c];
+    }
+  }
+  for (int fi = 0; fi < L.nfrag; ++fi) {
+    const NudfPackFrag& f = L.frag[fi];
+    const int NT = (f.N + 31) >> 5;
+    uint4* d4 = reinterpret_cast<uint4*>(f.dst);
+    if (f.dtype == 3 && f.transpose) {
+      // k = c - i0 (8 consecutive columns of a row), n = row - o0
+      const int Q = (f.K + 7) >> 3;
+      for (int e = tid; e < WNP_ROWS * Q; e += WNP_THREADS) {
+        const int r = e & 31, q = e >> 5;
+        const int n = row0 + r - f.o0;
+        if (r >= nrows || n < 0 || n >= f.N) continue;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * q + j;
+          w[j] = (k < f.K) ? panel[r * pw + f.i0 + k] : 0.0f;
+        }
+        uint4 hi, mid, lo;
+        wnp_split8(w, hi, mid, lo);
+        const size_t slot = ((size_t)((q >> 1) * NT + (n >> 5)) * 3) * 64 + 32 * (q & 1) + (n & 31);
+        d4[slot] = hi; d4[slot + 64] = mid; d4[slot + 128] = lo;
+      }
+    } else if (f.dtype == 3 && (f.o0 & 7) == 0) {
+      // k = row - o0 (8 consecutive rows of a column: row0 and o0 are multiples of 8), n = c - i0
+      for (int e = tid; e < 4 * f.N; e += WNP_THREADS) {
+        const int t = e / f.N, n = e - t * f.N;
+        const int k0 = row0 - f.o0 + 8 * t;
+        if (k0 < 0 || k0 >= f.K) continue;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (k0 + j < f.K) ? panel[(8 * t + j) * pw + f.i0 + n] : 0.0f;
+        uint4 hi, mid, lo;
+        wnp_split8(w, hi, mid, lo);
+        const size_t slot = ((size_t)((k0 >> 4) * NT + (n >> 5)) * 3) * 64 + 32 * ((k0 >> 3) & 1) + (n & 31);
+        d4[slot] = hi; d4[slot + 64] = mid; d4[slot + 128] = lo;
+      }
+    } else {
+      for (int e = tid; e < nrows * L.in; e += WNP_THREADS) {
+        const int r = e / L.in, c = e - r * L.in;
+        frag_store(f, row0 + r, c, panel[r * pw + c]);
+      }
+    }
   }
 }
 extern "C" int nudf_weightnorm_pack_multi(const NudfPackMulti* args, void* stream) {
@@ -541,7 +633,23 @@ extern "C" int nudf_weightnorm_pack_multi(const NudfPackMulti* args, void* strea
     nudf_set_error("nudf_weightnorm_pack_multi: too many layers", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(wn_pack_multi_kernel, dim3((args->total_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *args);
+  int blocks = 0, in_max = 0;
+  for (int i = 0; i < args->n_layers; ++i) {
+    blocks += (args->layer[i].out + WNP_ROWS - 1) / WNP_ROWS;
+    in_max = max(in_max, args->layer[i].in);
+    for (int f = 0; f < args->layer[i].nfrag; ++f)      // (the panel is addressed up to i0 + K - 1 <= in - 1)
+      if (args->layer[i].frag[f].dtype == 3 && (((uintptr_t)args->layer[i].frag[f].dst) & 15)) {
+        nudf_set_error("nudf_weightnorm_pack_multi: bf16x3 fragment buffers must be 16-byte aligned", hipErrorInvalidValue);
+        return (int)hipErrorInvalidValue;
+      }
+  }
+  const int pw = (in_max + 31) / 32 * 32 + 4;
+  const size_t lds = (size_t)WNP_ROWS * pw * sizeof(float);
+  if (lds > 64 * 1024) {
+    nudf_set_error("nudf_weightnorm_pack_multi: layer wider than 508 inputs", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(wn_pack_multi_kernel, dim3(blocks), dim3(WNP_THREADS), lds, (hipStream_t)stream, *args, pw);
   NUDF_CHECK_LAUNCH("nudf_weightnorm_pack_multi");
   return 0;
 }
