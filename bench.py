@@ -607,11 +607,30 @@ def composite_roofline(dev, N, S, reps=50):
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
+            # the weights-first form of no-grad rendering: the same launch without the two colour arrays
+            # -- their compositing sums are taken inside the colour network's epilogues (NudfChainStep.row_w)
+            a.color = a.color_base = None
+            for _ in range(3):
+                call("nudf_composite_fwd", a)
+            e0.record()
+            for _ in range(reps):
+                call("nudf_composite_fwd", a)
+            e1.record()
+            torch.cuda.synchronize()
+            us_w = e0.elapsed_time(e1) / reps * 1e3
         bytes_fwd = 48.0 * n * s + 68.0 * n
         level = "hbm" if bytes_fwd > 256e6 else ("mall (256 MB Infinity Cache resident)" if bytes_fwd > 32e6 else "l2 / launch latency")
         out[f"fwd_{n}x{s}"] = {"bound": level, "achieved": bytes_fwd / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_fwd / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                "avg_launch_us": us, "algorithmic_bytes": bytes_fwd}
+        bytes_w = 24.0 * n * s + 44.0 * n          # z, udf, grad in; weights out; per ray: o, d in, depth / normals / sums out
+        out[f"fwd_weights_first_{n}x{s}"] = {
+            "bound": "hbm" if bytes_w > 256e6 else ("mall (256 MB Infinity Cache resident)" if bytes_w > 32e6 else "l2 / launch latency"),
+            "achieved": bytes_w / (us_w * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_w / (us_w * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": us_w, "algorithmic_bytes": bytes_w,
+            "what": "nudf_composite_fwd with color = color_base = NULL: 24 B/sample instead of 48; the colour sums ride in the "
+                    "colour network's sigmoid-head epilogues (12 B/sample + 68 B/ray of the fused pair against 72 B/sample + "
+                    "68 B/ray with the colours written and read back)"}
     return out
 
 

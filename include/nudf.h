@@ -219,6 +219,12 @@ int nudf_composite_bwd(const NudfComposite* args, const NudfCompositeGrad* grads
 /* out[k] = sum over the nblk rows of ws [nblk, K] (K <= 8), fixed order: the second stage of the composite kernels'
  * deterministic batch sums, for a caller that asked them to leave the partials (NudfComposite.defer_sums) */
 int nudf_partial_sums(const float* ws, int nblk, int K, float* out, void* stream);
+/* per-ray colours from the per-32-point partial sums a colour chain left (NudfChainStep.row_sums [N S / 32, 4]):
+ * out[ray][c] = sum of the ray's S / 32 blocks (+ background_rgb[c] (1 - wsum_all[ray]) for `out_color`, :527-528).
+ * NudfComposite.color == NULL makes nudf_composite_fwd compute everything BUT the two colour sums (weights first). */
+int nudf_composite_colour_finish(const float* sums_color, const float* sums_color_base, int N, int S,
+                                 const float* background_rgb, const float* wsum_all, float* out_color,
+                                 float* out_color_base, void* stream);
 /* Layout of the FULL case (S = 128 / 256 / 512 inside samples, no outside samples, no diagnostics): 1 = lane l owns
  * S/64 consecutive samples (16-byte vector accesses), 0 (default) = sample i in lane i % 64 for every shape.  Same
  * arithmetic, different association of the two product scans; A-B switch (the two measure the same on MI355X). */
@@ -485,6 +491,14 @@ typedef struct NudfChainStep {
   float pe_tail_scale;
   float scale, xscale;
   int32_t layout;                  /* NUDF_CH_BLK_* bits: which of this step's [P, ld] buffers use the BLOCKED layout */
+  /* SIGMOIDN steps of the workgroup-shared kernel only -- the compositing sum of a colour head taken inside its epilogue
+     (udf_renderer_blending.py:508-526: (colour * weights[..., None]).sum(dim=1)), so that the per-sample colours need not
+     go to memory: row_w [rows padded to 64, zero tail] = the compositing weight of every point; row_sums [ceil(P / 32), 4]:
+     row_sums[b][c] = sum over the 32 points of block b of row_w[r] * sigmoid(v[r][c]), c < min(iparam, 4) (fixed order).
+     With rays of S % 32 == 0 samples the blocks of a ray are consecutive: nudf_composite_colour_finish adds them up.
+     C1 / C2 may be NULL then. */
+  const float* row_w;
+  float* row_sums;
 } NudfChainStep;
 /* Blocked layout of a [P, ld] buffer (P padded to 32 rows, ld % 4 == 0): element (r, c) lives at
  *   (r / 32) * 32 * ld + (c / 4) * 128 + (r % 32) * 4 + (c % 4)

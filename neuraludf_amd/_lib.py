@@ -143,7 +143,7 @@ class ChainStep(C.Structure):
                 ("r1_row", c_fp), ("r1_col", c_fp), ("K", i32), ("N", i32), ("epi", i32), ("iparam", i32),
                 ("ldx1", i32), ("ldx2", i32), ("ldc1", i32), ("ldc2", i32), ("ldr1", i32), ("prec", i32), ("act_write", i32),
                 ("act_col0", i32), ("pe_tail_col", i32), ("ld_pe", i32), ("pe_dst", c_fp), ("pe_tail_scale", f32),
-                ("scale", f32), ("xscale", f32), ("layout", i32)]
+                ("scale", f32), ("xscale", f32), ("layout", i32), ("row_w", c_fp), ("row_sums", c_fp)]
 
 
 class Chain(C.Structure):
@@ -190,7 +190,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_gemm_tn_grouped_plan", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
-    "nudf_composite_bwd", "nudf_partial_sums", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_merge_points", "nudf_coarse_z", "nudf_coarse_start", "nudf_outside_z",
+    "nudf_composite_bwd", "nudf_partial_sums", "nudf_composite_colour_finish", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_merge_points", "nudf_coarse_z", "nudf_coarse_start", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
@@ -216,6 +216,7 @@ _ARGTYPES = {
     "nudf_composite_fwd": [C.POINTER(Composite), _P],
     "nudf_composite_bwd": [C.POINTER(Composite), C.POINTER(CompositeGrad), _P],
     "nudf_partial_sums": [_P, _I, _I, _P, _P],
+    "nudf_composite_colour_finish": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     "nudf_upsample": [C.POINTER(Upsample), _P],
     "nudf_merge": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "nudf_coarse_z": [_P, _P, _I, _P, _I, _I, _P, _P, _P],

@@ -195,14 +195,19 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
     RawSample raw[NC];
     float bgz[NC], bgzn[NC], bgs[NC];
     const RayRows rr = ray_rows(p, ray);
+    const bool has_col = p.color != nullptr;
     float* __restrict__ wrow = p.weights + (size_t)ray * ST;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int i = c * 64 + l;
       load_raw(rr, S, i, raw[c]);
       const unsigned b = min((unsigned)i, (unsigned)(S - 1));
-      cr[c] = rr.color[b * 3u + 0u]; cg[c] = rr.color[b * 3u + 1u]; cb[c] = rr.color[b * 3u + 2u];
-      br[c] = rr.color_base[b * 3u + 0u]; bg[c] = rr.color_base[b * 3u + 1u]; bb[c] = rr.color_base[b * 3u + 2u];
+      if (has_col) {   // (uniform; weights-first launches leave the colour sums to the colour network's epilogue)
+        cr[c] = rr.color[b * 3u + 0u]; cg[c] = rr.color[b * 3u + 1u]; cb[c] = rr.color[b * 3u + 2u];
+        br[c] = rr.color_base[b * 3u + 0u]; bg[c] = rr.color_base[b * 3u + 1u]; bb[c] = rr.color_base[b * 3u + 2u];
+      } else {
+        cr[c] = cg[c] = cb[c] = br[c] = bg[c] = bb[c] = 0.f;
+      }
       bgz[c] = bgzn[c] = bgs[c] = 0.f;
     }
     if (!FULL && NO > 0) {  // uniform
@@ -339,8 +344,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
         bgg = p.background_rgb[1] * (1.0f - a_wall);
         bgb = p.background_rgb[2] * (1.0f - a_wall);
       }
-      p.out_color[ray * 3 + 0] = a_cr + bgr; p.out_color[ray * 3 + 1] = a_cg + bgg; p.out_color[ray * 3 + 2] = a_cb + bgb;
-      p.out_color_base[ray * 3 + 0] = a_br; p.out_color_base[ray * 3 + 1] = a_bg; p.out_color_base[ray * 3 + 2] = a_bb;
+      if (has_col) {
+        p.out_color[ray * 3 + 0] = a_cr + bgr; p.out_color[ray * 3 + 1] = a_cg + bgg; p.out_color[ray * 3 + 2] = a_cb + bgb;
+        p.out_color_base[ray * 3 + 0] = a_br; p.out_color_base[ray * 3 + 1] = a_bg; p.out_color_base[ray * 3 + 2] = a_bb;
+      }
       p.out_depth[ray] = a_depth;
       p.out_normals[ray * 3 + 0] = a_nx; p.out_normals[ray * 3 + 1] = a_ny; p.out_normals[ray * 3 + 2] = a_nz;
       p.out_wsum[ray] = a_ws;
@@ -1095,6 +1102,11 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
     nudf_set_error("nudf_composite_fwd: 1 <= S, S + n_outside <= 512 required", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
+  if ((p.color == nullptr) != (p.color_base == nullptr) || (!p.color && (p.n_out > 0 || p.bg_color))) {
+    nudf_set_error("nudf_composite_fwd: color and color_base are given together; the weights-first form (both NULL) has no "
+                   "outside samples", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
   if ((p.defer_sums && !p.ws) || (p.p_variance && (!p.p_beta || !p.p_gamma)) || (!p.p_variance && !p.scal)) {
     nudf_set_error("nudf_composite_fwd: defer_sums needs ws; scalars need scal or all three parameters", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
@@ -1106,7 +1118,7 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
   const bool diag = p.o_alpha_occ || p.o_raw_occ || p.o_true_cos || p.o_grad_mag || p.o_mid_z || p.o_dists ||
                     p.o_inside || p.o_flip || p.o_vis_prob || p.o_alpha || p.o_alpha_plus || p.o_alpha_minus;
   const bool full = (p.S == 64 * nc) && p.n_out == 0 && p.s_nominal >= p.S;
-  if (full && !diag && (nc == 2 || nc == 4 || nc == 8) && composite_blocked_enabled() && ptr16(p.z) && ptr16(p.udf) &&
+  if (full && !diag && p.color && (nc == 2 || nc == 4 || nc == 8) && composite_blocked_enabled() && ptr16(p.z) && ptr16(p.udf) &&
       ptr16(p.grad) && ptr16(p.color) && ptr16(p.color_base) && ptr16(p.weights)) {
     if (nc == 2) hipLaunchKernelGGL(composite_fwd_blk_kernel<2>, grid, block, 0, st, p);
     else if (nc == 4) hipLaunchKernelGGL(composite_fwd_blk_kernel<4>, grid, block, 0, st, p);
@@ -1182,6 +1194,37 @@ extern "C" int nudf_composite_bwd(const NudfComposite* args, const NudfComposite
 #undef NUDF_CB_LAUNCH
   composite_bwd_reduce(p, *grads, (int)grid.x, st);
   NUDF_CHECK_LAUNCH("nudf_composite_bwd");
+  return 0;
+}
+
+// per-ray colours from the 32-point partial sums the colour chain's SIGMOIDN epilogues left (NudfChainStep.row_sums)
+__global__ void colour_finish_kernel(const float* __restrict__ sc, const float* __restrict__ sb, int N, int nb,
+                                     const float* __restrict__ background_rgb, const float* __restrict__ wsum_all,
+                                     float* __restrict__ out_c, float* __restrict__ out_b) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * 3) return;
+  const int ray = idx / 3, c = idx - ray * 3;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nb; ++k) {
+    a += sc[((size_t)ray * nb + k) * 4 + c];
+    if (sb) b += sb[((size_t)ray * nb + k) * 4 + c];
+  }
+  if (background_rgb) a += background_rgb[c] * (1.0f - wsum_all[ray]);
+  out_c[idx] = a;
+  if (out_b) out_b[idx] = b;
+}
+extern "C" int nudf_composite_colour_finish(const float* sums_color, const float* sums_color_base, int N, int S,
+                                            const float* background_rgb, const float* wsum_all, float* out_color,
+                                            float* out_color_base, void* stream) {
+  if (N <= 0) return 0;
+  if (S < 32 || (S & 31) || !sums_color || !out_color || (background_rgb && !wsum_all) || (!sums_color_base != !out_color_base)) {
+    nudf_set_error("nudf_composite_colour_finish: S a positive multiple of 32 (rays = whole 32-point blocks) required",
+                   hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(colour_finish_kernel, dim3((N * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums_color,
+                     sums_color_base, N, S / 32, background_rgb, wsum_all, out_color, out_color_base);
+  NUDF_CHECK_LAUNCH("nudf_composite_colour_finish");
   return 0;
 }
 

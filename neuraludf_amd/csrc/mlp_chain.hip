@@ -549,6 +549,15 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       }
     }
   }
+  if (EPI == NUDF_CH_SIGMOIDN && st.row_w) {
+    // compositing sum of this 32-point block inside the epilogue: lane (ln, h) holds 16 rows of column `col`
+    const float* wr = st.row_w + grow0;
+    float sacc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc += wr[CH_KOFF(r)] * out[r];
+    sacc += __shfl_xor(sacc, 32);
+    if (h == 0 && col < st.iparam && col < 4) st.row_sums[(size_t)(grow0 >> 5) * 4 + col] = sacc;
+  }
   // ---- stores ----
   if (EPI == NUDF_CH_UDFHEAD) {
     if (col == 0) {
@@ -1085,7 +1094,17 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of
   // that kernel is 1024 waves = 32 768 points, so it is chosen when the last round is at least ~80 % full; the
   // up-sampling rounds (5-8 k points) and awkward sizes keep the workgroup-shared tiles below.
-  bool rows_ok = p.tile_rows == 128 || p.tile_rows == 0;
+  bool roww = false;
+  for (int i = 0; i < p.n_steps; ++i) {
+    const NudfChainStep& s = p.step[i];
+    if (!s.row_w) continue;
+    roww = true;
+    if (s.epi != NUDF_CH_SIGMOIDN || !s.row_sums || p.tile_rows == 66 || p.tile_rows == 128 || p.tile_rows == 130) {
+      nudf_set_error("nudf_mlp_chain: row_w / row_sums belong to SIGMOIDN steps of the workgroup-shared kernel", hipErrorInvalidValue);
+      return (int)hipErrorInvalidValue;
+    }
+  }
+  bool rows_ok = !roww && (p.tile_rows == 128 || p.tile_rows == 0);
   if (rows_ok && p.tile_rows == 0) {
     const long long round = 1024LL * 32, rounds = (p.P + round - 1) / round;
     rows_ok = nudf_chain_rows_auto() && p.P >= 24576 && (double)p.P >= 0.8 * (double)(rounds * round);
@@ -1110,13 +1129,13 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0) return nudf_mlp_chain_tq_launch(p, cls, st, 1);
   }
-  if (p.tile_rows == 66 || (p.tile_rows == 0 && p.P > 256 * 64 && nudf_chain_quad_mode() > 0)) {
+  if (!roww && (p.tile_rows == 66 || (p.tile_rows == 0 && p.P > 256 * 64 && nudf_chain_quad_mode() > 0))) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0 && (p.tile_rows == 66 || cls <= 1 || nudf_chain_quad_mode() >= 2)) return nudf_mlp_chain_tq_launch(p, cls, st);
   }
   // NUDF_CHAIN_PAIR=2: paired tiles (mlp_chain_pair_kernel, reached through the transposed-product launcher) for every
   // fp32 launch of at least 32 768 points that meets that kernel's contract -- a measured counter-example, off by default
-  if (p.tile_rows == 0 && p.P >= 32768 && !any16 && !any3 && nudf_chain_pair_mode() >= 2) {
+  if (!roww && p.tile_rows == 0 && p.P >= 32768 && !any16 && !any3 && nudf_chain_pair_mode() >= 2) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0) return nudf_mlp_chain_tq_launch(p, cls, st);
   }

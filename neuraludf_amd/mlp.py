@@ -271,7 +271,7 @@ class ChainBuilder:
 
     def step(self, epi, Bp, K, N, bias=None, bias_off=0, X1=None, X2=None, C1=None, C2=None, ldc1=0, ldc2=0, r1_row=None,
              ldr1=1, r1_col=None, iparam=0, act_write=1, act_col0=0, pe_tail_col=-1, pe_tail_scale=0.0, pe_dst=None,
-             scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x2_off=0):
+             scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x2_off=0, row_w=None, row_sums=None):
         if self.n >= CH_MAX_STEPS:
             raise _lib.NudfError("too many chain steps")
         s = self.c.step[self.n]
@@ -283,6 +283,7 @@ class ChainBuilder:
         s.ldc1 = ldc1 or (C1.shape[1] if (C1 is not None and C1.dim() == 2) else 0)
         s.ldc2 = ldc2 or (C2.shape[1] if (C2 is not None and C2.dim() == 2) else 0)
         s.r1_row, s.ldr1, s.r1_col = self._p(r1_row), ldr1, self._p(r1_col)
+        s.row_w, s.row_sums = self._p(row_w), self._p(row_sums)      # SIGMOIDN: compositing sum inside the epilogue
         s.K, s.N, s.epi, s.iparam = K, N, CH[epi], iparam
         s.prec = getattr(Bp, "prec", 0)
         # 16-bit stored state (config-5 mode): X1, X2, C1, the TANGENT mirror C2 and pe_dst of a step are bf16 TOGETHER
@@ -1199,9 +1200,11 @@ class ColorEngine:
         kinds += [(fw, bw)] * self.n
         return kinds
 
-    def forward(self, CIN, rays_d, S, P, keep_state=True):
+    def forward(self, CIN, rays_d, S, P, keep_state=True, row_w=None):
         if self._chain_ok():
-            return self._forward_chain(CIN, rays_d, S, P, keep_state)
+            return self._forward_chain(CIN, rays_d, S, P, keep_state, row_w)
+        if row_w is not None:
+            raise _lib.NudfError("the compositing sum inside the colour heads needs the fused chain launch")
         return self._forward_layers(CIN, rays_d, S, P, keep_state)
 
     def backward(self, st, color_base, color, d_cb, d_color, d_logits):
@@ -1209,10 +1212,15 @@ class ColorEngine:
             return self._backward_chain(st, color_base, color, d_cb, d_color, d_logits)
         return self._backward_layers(st, color_base, color, d_cb, d_color, d_logits)
 
-    def _forward_chain(self, CIN, rays_d, S, P, keep_state=True):
+    def _forward_chain(self, CIN, rays_d, S, P, keep_state=True, row_w=None):
         """one launch: base branch (ReLU x4, sigmoid head) -> [hidden | PE(dir) | color_base] assembled in the LDS
-        tile -> view branch (ReLU x4, sigmoid + logits head)   (fields.py:452-495)."""
+        tile -> view branch (ReLU x4, sigmoid + logits head)   (fields.py:452-495).
+        row_w [pad_rows(P)] (no-grad rendering, `keep_state` False): the compositing weight of every point -- the two
+        sigmoid heads then return the per-32-point sums of weight x colour ([ceil(P / 32), 4] each) INSTEAD of the
+        per-point colours, which never leave the chip (udf_renderer_blending.py:508-526 taken into the epilogue)."""
         dev, n = CIN.device, self.n
+        fused = row_w is not None
+        assert not (fused and keep_state)
         H, npe, dout = self.H, self.npe, self.dout
         pack_group(self.base + self.view, self._kinds())
         Pp = pad_rows(P)
@@ -1229,20 +1237,24 @@ class ColorEngine:
             cb.step("RELU", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=HB[l + 1] if keep_state else None,
                     C2=VIN if (tap and keep_state) else None, pe_tail_col=H if tap else -1, pe_tail_scale=1.0,
                     pe_dst=VIN if (tap and keep_state) else None)
-        color_base = torch.empty(Pp, dout, device=dev)
+        color_base = None if fused else torch.empty(Pp, dout, device=dev)
+        sums_b = torch.empty(Pp // 32, 4, device=dev) if fused else None
+        sums_c = torch.empty(Pp // 32, 4, device=dev) if fused else None
         pl = self.base[n - 1]
         cb.step("SIGMOIDN", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=color_base, C2=VIN if keep_state else None,
-                c2_off=H + npe, iparam=dout, act_write=1, act_col0=H + npe)
+                c2_off=H + npe, iparam=dout, act_write=1, act_col0=H + npe, row_w=row_w, row_sums=sums_b)
         for l in range(n - 1):
             pl = self.view[l]
             cb.step("RELU", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=HV[l + 1] if keep_state else None)
         pl = self.view[n - 1]
         nb = pl.out - dout
-        color = torch.empty(Pp, dout, device=dev)
+        color = None if fused else torch.empty(Pp, dout, device=dev)
         logits = torch.empty(Pp, max(nb, 1), device=dev)
         cb.step("SIGMOIDN", pl.frag(_kind("fwd", "fwd")), k8(pl.inp), pl.out, bias=pl.bias, C1=color, C2=logits if nb > 0 else None,
-                iparam=dout, act_write=0)
+                iparam=dout, act_write=0, row_w=row_w, row_sums=sums_c)
         cb.launch()
+        if fused:
+            return sums_b, sums_c, (logits[:P] if nb > 0 else None), None
         st = dict(HB=HB, HV=HV, P=P, chain=True) if keep_state else None
         return color_base[:P], color[:P], (logits[:P] if nb > 0 else None), st
 

@@ -45,6 +45,9 @@ UPSAMPLE_FLAGS = int(os.environ.get("NUDF_UP_FLAGS", str(512 | 1024 | 2048 | 409
 # the renderer scalars (inv_s, beta, gamma) formed inside the composite launches instead of by nudf_scalars_fwd / _bwd
 # (same expressions; NUDF_FUSE_SCALARS=0 restores the separate launches: A/B and tests)
 FUSE_SCALARS = os.environ.get("NUDF_FUSE_SCALARS", "1") == "1"
+# no-grad rendering: composite weights first, colour sums inside the colour network's epilogues (render_core); 0 = the
+# per-sample colours through memory as in a training step (A/B, tests)
+FUSE_COLOUR = os.environ.get("NUDF_FUSE_COLOUR", "1") == "1"
 
 _DIAG = ["alpha", "alpha_plus", "alpha_minus", "vis_prob", "alpha_occ", "raw_occ", "true_cos", "grad_mag", "mid_z",
          "dists", "inside", "flip"]
@@ -500,7 +503,16 @@ class UDFRendererBlending:
         # (colour-net modes that see the detached unit normal, :371, :425: it rides in the same buffer)
         udf, CIN, grad = self.udf_network.evaluate(pts, want_grad=True, feat_ld=ceng.cin_ld,
                                                    normals_col=(ceng.F + 3) if ceng.nrm else -1, feat_buf=feat_buf)
-        cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
+        # No-grad rendering (validation images, forward-only throughput) without outside samples and blending: the
+        # compositing WEIGHTS first (everything of the composite launch but its two colour sums), then the colour network
+        # with those weights -- its two sigmoid heads sum weight x colour per 32 points inside their epilogues, so the
+        # per-sample colours [P, 3] x 2 are never written or read (:425-429 -> :508-526).  A training
+        # step keeps them: its backward reads them (sigmoid', d weights), as the reference's autograd does.
+        fuse_colour = (FUSE_COLOUR and not torch.is_grad_enabled() and bg_z is None and color_maps is None and S % 32 == 0
+                       and S >= 32 and hasattr(ceng, "_forward_chain") and ceng._chain_ok() and not self.data_parallel)
+        cb = col = logits = None
+        if not fuse_colour:
+            cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
         spar = self._scalar_params()
         scal = recip = None
         if spar is None:
@@ -517,9 +529,20 @@ class UDFRendererBlending:
                  # cos_anneal_ratio = None the kernel still takes flip_saturation from it (has_anneal stays by value)
                  sched=getattr(self, "sched_scalars", None))
         outs = _CompositeFn.apply(c, rays_o, rays_d, z_vals, sample_dist, background_rgb, udf.reshape(N, S),
-                                  grad.reshape(N, S, 3), col.reshape(N, S, 3), cb.reshape(N, S, 3), bg_z, bg_sigma,
+                                  grad.reshape(N, S, 3), None if fuse_colour else col.reshape(N, S, 3),
+                                  None if fuse_colour else cb.reshape(N, S, 3), bg_z, bg_sigma,
                                   bg_color, scal, *(spar[:3] if spar is not None else ()))
         color, color_base, weights, depth, normals, wsum, wsum_all, sums = outs[:8]
+        if fuse_colour:
+            Pp = mlp.pad_rows(P)
+            row_w = weights.reshape(-1)
+            if Pp != P:                                       # the chain's last tile reads weights of its pad rows: zeros
+                row_w = torch.zeros(Pp, device=dev)
+                row_w[:P] = weights.reshape(-1)
+            sums_b, sums_c, logits, _ = ceng.forward(CIN.detach(), rays_d, S, P, keep_state=False, row_w=row_w)
+            color, color_base = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+            call("nudf_composite_colour_finish", ptr(sums_c), ptr(sums_b), N, S, ptr(background_rgb), ptr(wsum_all), ptr(color),
+                 ptr(color_base))
         if spar is not None:
             scal, recip = outs[-2:]
         diag = dict(zip(_DIAG, outs[8:8 + len(_DIAG)])) if self.diagnostics else {}

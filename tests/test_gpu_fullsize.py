@@ -73,12 +73,17 @@ def test_full_size_render_invariants_and_gradients(dev, name, rconf, n_rays):
             assert p.grad is not None, (mod_name, n)
             assert bool(torch.isfinite(p.grad).all()), (mod_name, n)
     assert float(sum(p.grad.abs().sum() for p in tr.udf.parameters())) > 0
-    # forward is run-to-run identical (no atomics on the forward path)
+    # forward is run-to-run identical (no atomics on the forward path).  Under no_grad the two colour sums are taken inside
+    # the colour network's epilogues (32-point partial sums) instead of by the composite launch: the same
+    # products in another association -- everything else is the training forward bit for bit
     with torch.no_grad():
         _, out2 = tr.loss(batch, cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
+        _, out3 = tr.loss(batch, cos_anneal_ratio=1.0, flip_saturation=1.0, perturb_overwrite=0)
     assert torch.equal(out["z_vals"], out2["z_vals"])
-    assert torch.equal(out["color"].detach(), out2["color"])
     assert torch.equal(out["weights"].detach(), out2["weights"])
+    assert torch.equal(out2["color"], out3["color"]) and torch.equal(out2["color_base"], out3["color_base"])
+    assert float((out["color"].detach() - out2["color"]).abs().max()) <= 2e-6
+    assert float((out["color_base"].detach() - out2["color_base"]).abs().max()) <= 2e-6
 
 
 def test_cfg3_blending_full_size(dev):

@@ -175,3 +175,77 @@ def test_step_loss_reduces_the_partials_it_is_handed(dev):
          ptr(out_b), ptr(den_b), ptr(ws), nblk)
     assert torch.equal(sums_a, sums_b) and torch.equal(out_a, out_b) and torch.equal(den_a, den_b)
     assert torch.allclose(sums_a, ws.double().sum(0).float(), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the colour network's epilogue takes the compositing sum (no-grad rendering)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,S,bg", [(64, 128, False), (37, 64, True), (5, 32, False), (130, 96, True)])
+def test_no_grad_render_with_the_colour_sums_inside_the_colour_heads(dev, N, S, bg):
+    """render() under no_grad: weights first, then the colour chain with row_w / row_sums and nudf_composite_colour_finish,
+    against the same render with the per-sample colours through memory (NUDF_FUSE_COLOUR=0): everything that does not
+    involve the colours bit for bit, the two colours to fp32 summation noise (32-point partial sums instead of the
+    composite kernel's wave reduction)."""
+    from common import build_modules, perturb_
+    from neuraludf_amd.models import fields, udf_renderer_blending as R
+    mods = perturb_(build_modules(fields, seed=0))
+    for m in mods.values():
+        m.to(dev)
+    g = torch.Generator().manual_seed(N)
+    o = (torch.randn(N, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -2.5])).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1).to(dev)
+    near, far = torch.full((N, 1), 1.5, device=dev), torch.full((N, 1), 3.5, device=dev)
+    rend = R.UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], n_samples=S // 2,
+                                 n_importance=S // 2, n_outside=0, up_sample_steps=2, perturb=0.0)
+    kw = dict(cos_anneal_ratio=0.8, background_rgb=(torch.tensor([1.0, 0.5, 0.25]) if bg else None))
+    old = R.FUSE_COLOUR
+    try:
+        outs = []
+        for fused in (True, False):
+            R.FUSE_COLOUR = fused
+            with torch.no_grad():
+                outs.append(rend.render(o, d, near, far, **kw))
+    finally:
+        R.FUSE_COLOUR = old
+    a, b = outs
+    for k in ("weights", "z_vals", "depth", "normals", "weight_sum", "gradients", "udf", "gradient_error"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("color", "color_base"):
+        err = float((a[k] - b[k]).abs().max())
+        assert err <= 2e-6, (k, err)
+        assert float(b[k].abs().max()) > 1e-3
+    # with autograd on, the per-sample colours go through memory (the backward reads them): the unfused result, bit for bit
+    out_g = rend.render(o, d, near, far, **kw)
+    assert torch.equal(out_g["color"], b["color"]) and out_g["color"].requires_grad
+
+
+def test_sigmoid_head_row_sums_are_the_weighted_block_sums(dev):
+    """NudfChainStep.row_w / row_sums on the colour engine's chain: per-32-point sums of weight x colour against the same
+    launch's per-point colours (float64 sums), and the launch is refused outside the SIGMOIDN steps' kernel."""
+    from common import build_modules, perturb_
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = perturb_(build_modules(fields, seed=0))
+    eng = mods["color"].to(dev).engine()
+    P, S = 64 * 37 + 32, 32
+    g = torch.Generator().manual_seed(1)
+    CIN = torch.zeros(mlp.pad_rows(P), eng.cin_ld, device=dev)
+    CIN[:P, :eng.F + 3] = torch.randn(P, eng.F + 3, generator=g).to(dev) * 0.5
+    rays_d = torch.nn.functional.normalize(torch.randn(P // S, 3, generator=g), dim=-1).to(dev)
+    w = torch.zeros(mlp.pad_rows(P), device=dev)
+    w[:P] = torch.rand(P, generator=g).to(dev)
+    with torch.no_grad():
+        cb, col, _, _ = eng.forward(CIN[:P], rays_d, S, P, keep_state=False)
+        sb, sc, _, _ = eng.forward(CIN[:P], rays_d, S, P, keep_state=False, row_w=w)
+    for sums, colours in ((sb, cb), (sc, col)):
+        ref = (colours.double() * w[:P, None].double()).reshape(P // 32, 32, 3).sum(1)
+        assert float((sums[:P // 32, :3].double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+def test_colour_finish_arguments_are_checked(dev):
+    s = torch.zeros(8, 4, device=dev)
+    out = torch.zeros(2, 3, device=dev)
+    with pytest.raises(RuntimeError):
+        call("nudf_composite_colour_finish", ptr(s), ptr(s), 2, 48, None, None, ptr(out), ptr(out))      # S % 32 != 0
+    with pytest.raises(RuntimeError):
+        call("nudf_composite_colour_finish", ptr(s), None, 2, 64, None, None, ptr(out), ptr(out))        # one of a pair missing
