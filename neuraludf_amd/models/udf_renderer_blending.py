@@ -398,10 +398,12 @@ class UDFRendererBlending:
              ptr(uo))
         return zo, uo
 
-    def _merge_last(self, rays_o, rays_d, z, z_new, sample_dist):
+    def _merge_last(self, rays_o, rays_d, z, z_new, sample_dist, for_render=False):
         """the schedule's last merge (z only) together with what render_core does first with its result: the interval mid
         points, and their copy (+ zero pad) behind the feature columns of the colour network's input rows -- one launch
         instead of merge, ray_points, copy_cols and a fill.  The by-products wait in `self._mid` for render_core."""
+        if not for_render:              # a direct call of the sampling schedule: the plain merge, nothing kept
+            return self._merge(z, None, z_new, None)[0]
         N, M = z.shape
         K = z_new.shape[1]
         S = M + K
@@ -419,7 +421,7 @@ class UDFRendererBlending:
         return zo
 
     @torch.no_grad()
-    def importance_sample(self, rays_o, rays_d, z_vals, sample_dist, pts0=None):
+    def importance_sample(self, rays_o, rays_d, z_vals, sample_dist, pts0=None, for_render=False):
         """classical schedule (:723-755). `sample_dist` is a 1-element device tensor; `pts0`: the points of `z_vals` if
         the caller has them (nudf_coarse_start).  Each round's merge runs at the head of the next round's launch."""
         N = rays_o.shape[0]
@@ -436,12 +438,12 @@ class UDFRendererBlending:
                 z_new, pts_new, z_vals, udf = self._upsample(rays_o, rays_d, None, None, sample_dist, k, 0, 64 * 2 ** i,
                                                              64 * 2 ** (i + 1), gamma, pending=pend)
             if i + 1 == steps:
-                return self._merge_last(rays_o, rays_d, z_vals, z_new, sample_dist)
+                return self._merge_last(rays_o, rays_d, z_vals, z_new, sample_dist, for_render)
             pend = (z_vals, udf, z_new, self.udf_network.udf_only(pts_new).reshape(N, k))
         return z_vals
 
     @torch.no_grad()
-    def importance_sample_mix(self, rays_o, rays_d, z_vals, sample_dist, pts0=None):
+    def importance_sample_mix(self, rays_o, rays_d, z_vals, sample_dist, pts0=None, for_render=False):
         """mix schedule (:762-832): `steps` not-occlusion-aware rounds + one unbiased round."""
         N = rays_o.shape[0]
         udf = self._udf_at(rays_o, rays_d, z_vals, sample_dist, pts0)
@@ -464,7 +466,7 @@ class UDFRendererBlending:
         else:
             z_new, _, z_vals, udf = self._upsample(rays_o, rays_d, None, None, sample_dist, k, 0, 64 * 2 ** i,
                                                    64 * 2 ** (i + 1), 20 if i < 4 else 10, pending=pend)
-        return self._merge_last(rays_o, rays_d, z_vals, z_new, sample_dist)
+        return self._merge_last(rays_o, rays_d, z_vals, z_new, sample_dist, for_render)
 
     # ------------------------------------------------------------------------------------
     def render_core_outside(self, rays_o, rays_d, z_out, sample_dist, z_in=None):
@@ -646,9 +648,9 @@ class UDFRendererBlending:
             n_samples = z_vals.shape[1]
         elif self.n_importance > 0:
             if self.upsampling_type == 'classical':
-                z_vals = self.importance_sample(rays_o, rays_d, z_vals, sample_dist, pts0)
+                z_vals = self.importance_sample(rays_o, rays_d, z_vals, sample_dist, pts0, for_render=True)
             elif self.upsampling_type == 'mix':
-                z_vals = self.importance_sample_mix(rays_o, rays_d, z_vals, sample_dist, pts0)
+                z_vals = self.importance_sample_mix(rays_o, rays_d, z_vals, sample_dist, pts0, for_render=True)
             n_samples = self.n_samples + self.n_importance
 
         bg_sigma = bg_color = bg_color_in = None
