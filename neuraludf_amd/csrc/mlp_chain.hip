@@ -288,10 +288,12 @@ __device__ __forceinline__ void ch_split3(const f32x4& lo4, const f32x4& hi4, bf
                             // the fetch is not latency-bound (profiles/r04_bf16x3_experiments.txt item 9)
 #endif
 #ifndef NUDF_X3_PIPE
-#define NUDF_X3_PIPE 0      // A/B build switch: 1 = the next step's split interleaved with this step's MFMAs (measured slower:
-                            // 4.63 vs 4.44 ms per step -- two in-phase waves per SIMD already cover each other's split)
+#define NUDF_X3_PIPE 2      // the next step's split interleaved with this step's MFMAs (sched_group_barrier pattern): 0 = never,
+                            // 1 = always (measured slower on the 64-point tiles: 4.63 vs 4.44 ms per step -- two in-phase waves
+                            // per SIMD already cover each other's split), 2 = only where a wave has its SIMD to itself: the
+                            // 32-point tiles of the 8 192-point launches (81 -> 77 us per launch, experiments item 9)
 #endif
-template <int NRT, int NCT>
+template <int NRT, int NCT, bool PIPE>
 __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride3,
                                            int G16, f32x16 (&acc)[2][2]) {
   // bptr: this lane's uint4 of plane 0 of column tile ct0 in k step 0; planes 64 uint4 apart, column tiles 192, k steps
@@ -338,15 +340,15 @@ __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const
         }
   };
   auto pattern = [&]() {
-#if NUDF_X3_PIPE
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRT, 0);     // the next step's LDS reads ...
-    __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCT, 0);     // ... and weight loads first
+    if constexpr (PIPE) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRT, 0);     // the next step's LDS reads ...
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCT, 0);     // ... and weight loads first
 #pragma unroll
-    for (int m = 0; m < 6 * NRT * NCT; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, (44 * NRT + 6 * NRT * NCT - 1) / (6 * NRT * NCT), 0);
+      for (int m = 0; m < 6 * NRT * NCT; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (44 * NRT + 6 * NRT * NCT - 1) / (6 * NRT * NCT), 0);
+      }
     }
-#endif
   };
   const int gl = G16 - 1;
 #if NUDF_X3_BDIST == 2
@@ -395,18 +397,14 @@ __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const
     __builtin_amdgcn_sched_barrier(0);
     lda(min(g + 1, gl));
     ldb(b[1], min(g + 1, gl));
-#if !NUDF_X3_PIPE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);
     mfmas(pa[0], b[0]);
     split(pa[1]);
     pattern();
     __builtin_amdgcn_sched_barrier(0);
     lda(min(g + 2, gl));
     ldb(b[0], min(g + 2, gl));
-#if !NUDF_X3_PIPE
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);
     mfmas(pa[1], b[1]);
     split(pa[0]);
     pattern();
@@ -972,10 +970,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
         const uint4* bp3 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 192 + lane;
         const size_t bstride3 = (size_t)NT * 192;
         const int G16 = st.K >> 4;
-        if (nrt == 2 && nct == 2) ch_mma16x3<2, 2>(arow16, bp3, bstride3, G16, acc);
-        else if (nrt == 2) ch_mma16x3<2, 1>(arow16, bp3, bstride3, G16, acc);
-        else if (nct == 2) ch_mma16x3<1, 2>(arow16, bp3, bstride3, G16, acc);
-        else ch_mma16x3<1, 1>(arow16, bp3, bstride3, G16, acc);
+        constexpr bool PIPE3 = (NUDF_X3_PIPE == 1) || (NUDF_X3_PIPE == 2 && TM == 32);
+        if (nrt == 2 && nct == 2) ch_mma16x3<2, 2, PIPE3>(arow16, bp3, bstride3, G16, acc);
+        else if (nrt == 2) ch_mma16x3<2, 1, PIPE3>(arow16, bp3, bstride3, G16, acc);
+        else if (nct == 2) ch_mma16x3<1, 2, PIPE3>(arow16, bp3, bstride3, G16, acc);
+        else ch_mma16x3<1, 1, PIPE3>(arow16, bp3, bstride3, G16, acc);
       } else if (ANY16 && st.prec != 0) {
         const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
         const uint4* bp16 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 64 + lane;

@@ -511,7 +511,7 @@ class UDFRendererBlending:
         # per-sample colours [P, 3] x 2 are never written or read (:425-429 -> :508-526).  A training
         # step keeps them: its backward reads them (sigmoid', d weights), as the reference's autograd does.
         fuse_colour = (FUSE_COLOUR and not torch.is_grad_enabled() and bg_z is None and color_maps is None and S % 32 == 0
-                       and S >= 32 and hasattr(ceng, "_forward_chain") and ceng._chain_ok() and not self.data_parallel)
+                       and S >= 32 and isinstance(ceng, mlp.ColorEngine) and ceng._chain_ok() and not self.data_parallel)
         cb = col = logits = None
         if not fuse_colour:
             cb, col, logits = self.color_network.evaluate(CIN, rays_d, S)
