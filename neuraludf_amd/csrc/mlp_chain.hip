@@ -291,7 +291,7 @@ __device__ __forceinline__ void ch_split3(const f32x4& lo4, const f32x4& hi4, bf
 #define NUDF_X3_PIPE 2      // the next step's split interleaved with this step's MFMAs (sched_group_barrier pattern): 0 = never,
                             // 1 = always (measured slower on the 64-point tiles: 4.63 vs 4.44 ms per step -- two in-phase waves
                             // per SIMD already cover each other's split), 2 = only where a wave has its SIMD to itself: the
-                            // 32-point tiles of the 8 192-point launches (81 -> 77 us per launch, experiments item 9)
+                            // 32-point tiles of the 8 192-point launches (81-85 -> 70-75 us per launch, experiments item 10)
 #endif
 template <int NRT, int NCT, bool PIPE>
 __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride3,
