@@ -21,6 +21,25 @@ int nudf_version(void);
 const char* nudf_last_error(void);
 
 /* ------------------------------------------------------------------------------------
+ * Non-finite status word.  The reference stops on the host when a NaN appears -- sample_pdf's new samples
+ * (models/udf_renderer_blending.py:97-101), up_sample_unbias / up_sample_no_occ_aware's (:265-269, :860-864), the eikonal
+ * term of render_core (:543-544) -- each a `.cpu()` sync in the middle of a step.  Here the caller hands the library ONE
+ * int32 of device memory (zeroed by the caller); nudf_upsample ORs NUDF_STATUS_NONFINITE_SAMPLES into it when a new sample
+ * is not finite, nudf_composite_fwd NUDF_STATUS_NONFINITE_WEIGHTS when a ray's compositing weights are not, and
+ * nudf_step_loss_fwd NUDF_STATUS_NONFINITE_LOSS when the step's total loss is not.  Nothing on the device reads the word
+ * and no call waits for it: the caller polls it when it likes (UDFRendererBlending.status(), Trainer.iteration every
+ * `status_every` iterations).  NULL (the default) switches the checks off.  The pointer is per process (one process per
+ * GPU); it is passed to the kernels as an argument, so launches captured in a HIP graph keep the word they were captured with.
+ * ---------------------------------------------------------------------------------- */
+enum {
+  NUDF_STATUS_NONFINITE_WEIGHTS = 1,
+  NUDF_STATUS_NONFINITE_SAMPLES = 2,
+  NUDF_STATUS_NONFINITE_LOSS = 4
+};
+int nudf_set_status_flag(int32_t* device_word);
+int32_t* nudf_status_flag(void);
+
+/* ------------------------------------------------------------------------------------
  * Dense layer GEMMs (fp32 MFMA).  Replace F.linear + weight_norm + Softplus/ReLU and their
  * autograd (double-)backward:  models/fields.py:192-231 (UDFNetwork.forward/.gradient),
  * :452-495 (ResidualRenderingNetwork.forward), :599-628 (NeRF.forward).

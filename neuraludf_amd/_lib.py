@@ -189,7 +189,7 @@ EPI = dict(NONE=0, SOFTPLUS=1, RELU=2, MUL=3, MULMASK=4, TANGENT=5, BWD=6, SIGMO
 
 # every symbol include/nudf.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "nudf_version", "nudf_last_error", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_gemm_tn_grouped_plan", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
+    "nudf_version", "nudf_last_error", "nudf_set_status_flag", "nudf_status_flag", "nudf_gemm_nn", "nudf_set_gemm_variant", "nudf_gemm_tn", "nudf_gemm_tn_grouped", "nudf_gemm_tn_grouped_workspace", "nudf_gemm_tn_grouped_plan", "nudf_set_tn_flags", "nudf_patch_metric", "nudf_set_tn_debug", "nudf_composite_fwd",
     "nudf_composite_bwd", "nudf_partial_sums", "nudf_composite_colour_finish", "nudf_set_composite_blocked", "nudf_upsample", "nudf_merge", "nudf_merge_points", "nudf_coarse_z", "nudf_coarse_start", "nudf_outside_z",
     "nudf_ray_points", "nudf_posenc", "nudf_posenc_vjp", "nudf_copy_cols", "nudf_add_cols",
     "nudf_udf_grad_seed", "nudf_udf_head_bwd", "nudf_signed_colsum", "nudf_sigmoid_head_bwd",
@@ -292,7 +292,51 @@ def lib():
         _lib.nudf_adam_chunk.restype = C.c_int
         _bind(_lib)
         _lib.nudf_gemm_tn_grouped_workspace.restype = C.c_int64
+        _lib.nudf_set_status_flag.argtypes = [C.c_void_p]
+        _lib.nudf_set_status_flag.restype = C.c_int
+        _lib.nudf_status_flag.argtypes = []
+        _lib.nudf_status_flag.restype = C.c_void_p
     return _lib
+
+
+# ---- the non-finite status word (include/nudf.h: nudf_set_status_flag) -----------------------------------------------
+STATUS_NONFINITE_WEIGHTS, STATUS_NONFINITE_SAMPLES, STATUS_NONFINITE_LOSS = 1, 2, 4
+_STATUS_WORDS = {}        # device index -> the int32 tensor the kernels OR their bits into
+_STATUS_BOUND = None      # device index the library currently points at
+
+
+def bind_status(dev):
+    """make the kernels' status word the one of `dev` (allocated and zeroed on first use).  One python compare per call
+    once bound; the library keeps one pointer per process (one process per GPU)."""
+    global _STATUS_BOUND
+    if dev.type != "cuda":
+        raise NudfError("libnudf kernels need device tensors (got a CPU tensor): run on an MI355X")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if _STATUS_BOUND == idx:
+        return _STATUS_WORDS[idx]
+    w = _STATUS_WORDS.get(idx)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        _STATUS_WORDS[idx] = w
+    check(lib().nudf_set_status_flag(C.c_void_p(w.data_ptr())), "nudf_set_status_flag")
+    _STATUS_BOUND = idx
+    return w
+
+
+def read_status(dev, clear=False):
+    """the status bits seen so far on `dev` (synchronises: one 4-byte D2H copy)."""
+    w = bind_status(dev)
+    v = int(w.item())
+    if clear and v:
+        w.zero_()
+    return v
+
+
+def status_text(bits):
+    names = [(STATUS_NONFINITE_SAMPLES, "non-finite new samples in the hierarchical re-sampling (nudf_upsample)"),
+             (STATUS_NONFINITE_WEIGHTS, "non-finite compositing weights (nudf_composite_fwd)"),
+             (STATUS_NONFINITE_LOSS, "non-finite loss (nudf_step_loss_fwd)")]
+    return "; ".join(t for b, t in names if bits & b) or "finite"
 
 
 def ptr(t):

@@ -26,8 +26,16 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def _flag_stamp() -> str:
+    return LIB + ".flags"
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
+        return True
+    # the extra compiler flags the library was built with (NUDF_HIPCC_FLAGS) are part of its identity
+    stamp = open(_flag_stamp()).read() if os.path.exists(_flag_stamp()) else ""
+    if stamp != os.environ.get("NUDF_HIPCC_FLAGS", ""):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "nudf.h"), __file__]
@@ -63,20 +71,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
         flags = " ".join(cmd)
         if not force and not _obj_stale(o, d, flags):
             continue
-        with open(o + ".flags", "w") as f:
-            f.write(flags)
+        for stale in (o, o + ".flags"):       # an interrupted / failed compile must not leave an object that looks current
+            if os.path.exists(stale):
+                os.remove(stale)
         cmd += ["-MD", "-MF", d]
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, pr in procs:
+        procs.append((cmd, flags, o, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = None
+    for cmd, flags, o, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+            failed = failed or RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+            continue
+        with open(o + ".flags", "w") as f:    # the stamp is written only once the object exists
+            f.write(flags)
         if verbose and out:
             print(out.decode())
+    if failed is not None:
+        raise failed
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())
+    with open(_flag_stamp(), "w") as f:
+        f.write(os.environ.get("NUDF_HIPCC_FLAGS", ""))
     return LIB
 
 

@@ -174,7 +174,7 @@ __device__ __forceinline__ void eval_sample(const NudfComposite& p, const RayCon
   }
 
 template <int NC, bool DIAG, bool FULL>
-__global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
+__global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p, int32_t* status) {
   NUDF_COMPOSITE_SCHED(p)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
@@ -352,6 +352,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p) {
       p.out_normals[ray * 3 + 0] = a_nx; p.out_normals[ray * 3 + 1] = a_ny; p.out_normals[ray * 3 + 2] = a_nz;
       p.out_wsum[ray] = a_ws;
       p.out_wsum_all[ray] = a_wall;
+      // a non-finite weight anywhere on the ray makes this sum non-finite (inf - inf = NaN): the value is in a register,
+      // the check is one compare per ray, the atomic only fires when something is wrong (nudf_set_status_flag)
+      if (status && !(fabsf(a_wall) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_WEIGHTS);
     }
   }
 
@@ -794,7 +797,7 @@ __device__ __forceinline__ void blk_excl_rsum(const float (&v)[PER], float (&out
 }
 
 template <int PER>
-__global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p) {
+__global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p, int32_t* status) {
   NUDF_COMPOSITE_SCHED(p)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int ray = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
@@ -881,6 +884,7 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p)
       p.out_normals[ray * 3 + 0] = a[7]; p.out_normals[ray * 3 + 1] = a[8]; p.out_normals[ray * 3 + 2] = a[9];
       p.out_wsum[ray] = a[10];
       p.out_wsum_all[ray] = a[11];
+      if (status && !(fabsf(a[11]) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_WEIGHTS);
     }
   }
   {
@@ -1113,6 +1117,7 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
   }
   dim3 grid((p.N + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  int32_t* status = nudf_status_flag();
   // diagnostics (the 12 per-sample arrays of the full result dict) are a separate instantiation: the training path
   // carries no stores, branches or address arithmetic for them
   const bool diag = p.o_alpha_occ || p.o_raw_occ || p.o_true_cos || p.o_grad_mag || p.o_mid_z || p.o_dists ||
@@ -1120,17 +1125,17 @@ extern "C" int nudf_composite_fwd(const NudfComposite* args, void* stream) {
   const bool full = (p.S == 64 * nc) && p.n_out == 0 && p.s_nominal >= p.S;
   if (full && !diag && p.color && (nc == 2 || nc == 4 || nc == 8) && composite_blocked_enabled() && ptr16(p.z) && ptr16(p.udf) &&
       ptr16(p.grad) && ptr16(p.color) && ptr16(p.color_base) && ptr16(p.weights)) {
-    if (nc == 2) hipLaunchKernelGGL(composite_fwd_blk_kernel<2>, grid, block, 0, st, p);
-    else if (nc == 4) hipLaunchKernelGGL(composite_fwd_blk_kernel<4>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(composite_fwd_blk_kernel<8>, grid, block, 0, st, p);
+    if (nc == 2) hipLaunchKernelGGL(composite_fwd_blk_kernel<2>, grid, block, 0, st, p, status);
+    else if (nc == 4) hipLaunchKernelGGL(composite_fwd_blk_kernel<4>, grid, block, 0, st, p, status);
+    else hipLaunchKernelGGL(composite_fwd_blk_kernel<8>, grid, block, 0, st, p, status);
     if (p.ws && !p.defer_sums) hipLaunchKernelGGL(partial_sums_kernel, dim3(1), dim3(1024), 0, st, p.ws, (int)grid.x, 5, p.sums);
     NUDF_CHECK_LAUNCH("nudf_composite_fwd");
     return 0;
   }
 #define NUDF_CF_LAUNCH(NCV)                                                                                   \
-  if (diag) hipLaunchKernelGGL((composite_fwd_kernel<NCV, true, false>), grid, block, 0, st, p);              \
-  else if (full) hipLaunchKernelGGL((composite_fwd_kernel<NCV, false, true>), grid, block, 0, st, p);        \
-  else hipLaunchKernelGGL((composite_fwd_kernel<NCV, false, false>), grid, block, 0, st, p)
+  if (diag) hipLaunchKernelGGL((composite_fwd_kernel<NCV, true, false>), grid, block, 0, st, p, status);      \
+  else if (full) hipLaunchKernelGGL((composite_fwd_kernel<NCV, false, true>), grid, block, 0, st, p, status); \
+  else hipLaunchKernelGGL((composite_fwd_kernel<NCV, false, false>), grid, block, 0, st, p, status)
   switch (nc) {
     case 1: NUDF_CF_LAUNCH(1); break;
     case 2: NUDF_CF_LAUNCH(2); break;

@@ -9,6 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern "C" void nudf_set_error(const char* where, hipError_t e);
+extern "C" int32_t* nudf_status_flag(void);     // nudf_api.hip: the caller's non-finite status word (or NULL)
 
 #define NUDF_CHECK_LAUNCH(where)                         \
   do {                                                   \

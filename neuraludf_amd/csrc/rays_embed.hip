@@ -931,7 +931,7 @@ __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __rest
                                                              float w_c, float w_px, float w_igr, float w_igr_ns,
                                                              float w_sparse, const float* __restrict__ w_dev, float* out,
                                                              float* den_out, const float* __restrict__ sums_ws,
-                                                             int sums_nblk) {
+                                                             int sums_nblk, int32_t* status) {
   __shared__ float red[3][16];
   __shared__ float red5[5][16];
   __shared__ float s5[5];
@@ -987,6 +987,8 @@ __global__ __launch_bounds__(1024) void step_loss_fwd_kernel(const float* __rest
     total = __fadd_rn(total, __fmul_rn(ge, w_igr));
     out[0] = total; out[1] = cl; out[2] = Lb; out[3] = Lc; out[4] = ge; out[5] = gens; out[6] = sp; out[7] = 0.f;
     den_out[0] = den;
+    // (udf_renderer_blending.py:543-544 stops on a NaN eikonal term; every term of the step's loss ends in `total`)
+    if (status && !(fabsf(total) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_LOSS);
   }
 }
 extern "C" int nudf_step_loss_fwd(const float* cb, const float* c, const float* gt, int n, const float* mask, int n_mask,
@@ -994,7 +996,7 @@ extern "C" int nudf_step_loss_fwd(const float* cb, const float* c, const float* 
                                   float w_igr_ns, float w_sparse, const float* w_dev, float* out, float* den_out,
                                   const float* sums_ws, int sums_nblk, void* stream) {
   hipLaunchKernelGGL(step_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cb, c, gt, n, mask, n_mask, sums,
-                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, w_dev, out, den_out, sums_ws, sums_nblk);
+                     n_rays, w_b, w_c, w_px, w_igr, w_igr_ns, w_sparse, w_dev, out, den_out, sums_ws, sums_nblk, nudf_status_flag());
   NUDF_CHECK_LAUNCH("nudf_step_loss_fwd");
   return 0;
 }

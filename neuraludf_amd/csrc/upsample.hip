@@ -38,21 +38,22 @@ extern "C" int nudf_upsample(const NudfUpsample* args, void* stream) {
   dim3 grid((p.N + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int nc = (p.M + 63) / 64;
+  int32_t* status = nudf_status_flag();
   if (p.mode & NUDF_UP_NOCONTRACT) {
     switch (nc) {
-      case 1: hipLaunchKernelGGL(up_exact::upsample_kernel<1>, grid, block, 0, st, p); break;
-      case 2: hipLaunchKernelGGL(up_exact::upsample_kernel<2>, grid, block, 0, st, p); break;
-      case 3: hipLaunchKernelGGL(up_exact::upsample_kernel<3>, grid, block, 0, st, p); break;
-      case 4: hipLaunchKernelGGL(up_exact::upsample_kernel<4>, grid, block, 0, st, p); break;
-      default: hipLaunchKernelGGL(up_exact::upsample_kernel<8>, grid, block, 0, st, p); break;
+      case 1: hipLaunchKernelGGL(up_exact::upsample_kernel<1>, grid, block, 0, st, p, status); break;
+      case 2: hipLaunchKernelGGL(up_exact::upsample_kernel<2>, grid, block, 0, st, p, status); break;
+      case 3: hipLaunchKernelGGL(up_exact::upsample_kernel<3>, grid, block, 0, st, p, status); break;
+      case 4: hipLaunchKernelGGL(up_exact::upsample_kernel<4>, grid, block, 0, st, p, status); break;
+      default: hipLaunchKernelGGL(up_exact::upsample_kernel<8>, grid, block, 0, st, p, status); break;
     }
   } else {
     switch (nc) {
-      case 1: hipLaunchKernelGGL(up_fast::upsample_kernel<1>, grid, block, 0, st, p); break;
-      case 2: hipLaunchKernelGGL(up_fast::upsample_kernel<2>, grid, block, 0, st, p); break;
-      case 3: hipLaunchKernelGGL(up_fast::upsample_kernel<3>, grid, block, 0, st, p); break;
-      case 4: hipLaunchKernelGGL(up_fast::upsample_kernel<4>, grid, block, 0, st, p); break;
-      default: hipLaunchKernelGGL(up_fast::upsample_kernel<8>, grid, block, 0, st, p); break;
+      case 1: hipLaunchKernelGGL(up_fast::upsample_kernel<1>, grid, block, 0, st, p, status); break;
+      case 2: hipLaunchKernelGGL(up_fast::upsample_kernel<2>, grid, block, 0, st, p, status); break;
+      case 3: hipLaunchKernelGGL(up_fast::upsample_kernel<3>, grid, block, 0, st, p, status); break;
+      case 4: hipLaunchKernelGGL(up_fast::upsample_kernel<4>, grid, block, 0, st, p, status); break;
+      default: hipLaunchKernelGGL(up_fast::upsample_kernel<8>, grid, block, 0, st, p, status); break;
     }
   }
   NUDF_CHECK_LAUNCH("nudf_upsample");

@@ -55,11 +55,18 @@ class LossWeights:
         if self._bound is not None:
             return self._bound
         vals = self.values()
-        if self._own is None or self._own.device != torch.device(device):
-            self._own, self._own_vals = torch.empty(LW_COUNT, device=device), None
-        if vals != self._own_vals:
-            self._own.copy_(torch.tensor(vals, dtype=torch.float32))
-            self._own_vals = vals
+        if self._own is not None and self._own.device == torch.device(device) and vals == self._own_vals:
+            return self._own
+        # a NEW small device tensor per change (a colour-weight ramp changes the values every iteration): autograd nodes
+        # of a loss that has not run its backward yet may still hold views of the previous vector, so it is never
+        # overwritten in place; staged through pinned host memory, so the copy does not stall the host-ahead pipeline
+        import torch as _t
+        h = _t.tensor(vals, dtype=_t.float32)
+        if _t.device(device).type == "cuda":
+            h = h.pin_memory()
+        self._own = h.to(device, non_blocking=True)
+        self._own_host = h            # (keeps the pinned source alive until the copy has run)
+        self._own_vals = vals
         return self._own
 
 

@@ -14,7 +14,10 @@ Notes on value-preserving deviations (all verified against the oracle):
   * render_core evaluates the UDF MLP once (the reference runs the identical forward twice, :364/:368);
   * the NeRF is evaluated on the `n_outside` samples only when `color_maps is None` (the
     reference evaluates all S+n_outside points and discards the inside ones, :493-501);
-  * NaN guards that block on the host (:97, :265, :543, :860) are dropped;
+  * NaN guards that block on the host (:97, :265, :543, :860) are a status word in device memory instead: the up-sampling,
+    composite and step-loss kernels OR a bit into it when they produce a non-finite sample / weight / loss
+    (include/nudf.h: nudf_set_status_flag); `renderer.status()` reads it, `renderer.check_finite()` raises -- when the
+    caller chooses to look (Trainer.iteration: every `status_every` iterations), not in the middle of every step;
   * `sparse_random_error` (:681-686, never consumed by the runner) is 0.0 unless
     `renderer.compute_sparse_random = True`.
 """
@@ -25,6 +28,7 @@ import torch
 
 import os
 
+from .. import _lib
 from .._lib import Composite, CompositeGrad, Upsample, call, ptr
 from .. import dist as nudf_dist
 from .. import mlp
@@ -112,8 +116,12 @@ class _CompositeFn(torch.autograd.Function):
                 setattr(a, "o_" + k, ptr(d))
                 diag.append(d)
         if c.get("defer_sums"):
-            # the consumer's launch finishes the two-stage reduction (loss._StepLossFn, or `finish_sums`)
+            # the consumer's launch finishes the two-stage reduction (loss._StepLossFn, or `finish_sums`), found through a
+            # python attribute of the tensor.  A consumer that loses the attribute on the way (detach / clone / .to) must
+            # not read uninitialised memory silently: the five sums start as NaN, which the loss kernels' non-finite
+            # status bit and any reader then make loud
             a.defer_sums = 1
+            sums.fill_(float("nan"))
             sums._nudf_ws = (ws, (N + 3) // 4)
         call("nudf_composite_fwd", a)
         ctx.c = c
@@ -324,10 +332,15 @@ class UDFRendererBlending:
         """the three 1-element parameters + 1 / beta_min when the scalar networks are the drop-in ones (the composite
         launch then forms inv_s / beta / gamma itself: no nudf_scalars_fwd / _bwd launches), else None."""
         dn, bn = self.deviation_network, self.beta_network
-        if (FUSE_SCALARS and isinstance(getattr(dn, "variance", None), torch.Tensor) and dn.variance.numel() == 1
-                and dn.variance.is_cuda and isinstance(getattr(bn, "beta", None), torch.Tensor) and bn.beta.numel() == 1
-                and isinstance(getattr(bn, "gamma", None), torch.Tensor) and bn.gamma.numel() == 1
-                and hasattr(bn, "beta_min")):
+        # exactly the drop-in classes: the kernel restates THEIR forward / get_beta / get_gamma (exp(10 p), the clips) --
+        # a subclass or look-alike with other expressions goes through its own methods (`_scalars`)
+        from . import fields as _fields
+        if not (FUSE_SCALARS and type(dn) is _fields.SingleVarianceNetwork and type(bn) is _fields.BetaNetwork):
+            return None
+        ps = (dn.variance, bn.beta, bn.gamma)
+        dev = ps[0].device
+        if all(isinstance(t, torch.Tensor) and t.numel() == 1 and t.is_cuda and t.device == dev and t.dtype == torch.float32
+               and t.is_contiguous() for t in ps):
             return dn.variance, bn.beta, bn.gamma, 1.0 / bn.beta_min
         return None
 
@@ -597,6 +610,25 @@ class UDFRendererBlending:
         return ret
 
     # ------------------------------------------------------------------------------------
+    # ---- the non-finite status word (replaces the reference's host-side NaN stops, :97-101, 265-269, 543-544, 860-864) ----
+    def _device(self):
+        return next(self.udf_network.parameters()).device
+
+    def status(self, clear=False):
+        """bits seen since the last clear: 1 = non-finite compositing weights, 2 = non-finite new samples, 4 = non-finite
+        loss (_lib.STATUS_*).  Reads 4 bytes from the device, i.e. waits for the work enqueued so far."""
+        return _lib.read_status(self._device(), clear=clear)
+
+    def clear_status(self):
+        _lib.read_status(self._device(), clear=True)
+
+    def check_finite(self):
+        """raise FloatingPointError if a kernel has reported a non-finite value since the last clear (the reference drops
+        into pdb at that point); clears the word."""
+        bits = self.status(clear=True)
+        if bits:
+            raise FloatingPointError("NeuralUDF renderer: " + _lib.status_text(bits))
+
     def render(self, rays_o, rays_d, near, far, cos_anneal_ratio=None, perturb_overwrite=-1, background_rgb=None,
                flip_saturation=0, color_maps=None, w2cs=None, intrinsics=None, query_c2w=None, img_index=None,
                rays_uv=None, z_vals_override=None, patch_cams=None):
@@ -604,6 +636,7 @@ class UDFRendererBlending:
         N = len(rays_o)
         if N == 0:
             return self._empty_result(dev, color_maps is not None, rays_uv is not None)
+        _lib.bind_status(dev)          # (one python compare once bound)
         rays_o = rays_o.detach().float().contiguous()
         rays_d = rays_d.detach().float().contiguous()
         if not isinstance(near, torch.Tensor):
@@ -638,6 +671,7 @@ class UDFRendererBlending:
             z_out = torch.empty(N, self.n_outside, device=dev)
             call("nudf_outside_z", ptr(far), nf_stride, ptr(lin.float().contiguous()), N, self.n_outside,
                  self.n_samples, ptr(z_out))
+        self._z_vals_outside = z_out      # not in the result dict (the reference's has no such key): read by the jitter parity test
 
         n_samples = self.n_samples
         if z_vals_override is not None:

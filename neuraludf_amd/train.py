@@ -259,6 +259,7 @@ class Trainer:
         with contextlib.redirect_stdout(io.StringIO()):
             self.color_loss = loss_cls(**lc)
         self.data_parallel = data_parallel
+        self.status_every = 100        # iterations between looks at the non-finite status word (the runner's report_freq)
         self._beta_flag = True
         # single process: the step's loss assembly is fused (see `loss`), so the renderer hands over the composite kernel's
         # sums instead of the three error terms -- requested per call inside `loss` only: a direct `renderer.render(...)`
@@ -417,6 +418,12 @@ class Trainer:
         loss, out = stepper(batch, cos_anneal_ratio=a["cos_anneal_ratio"], flip_saturation=a["flip_saturation"],
                             blend=blend)
         self._trainability_toggles(out, iter_step)
+        # the reference stops on the host the moment a NaN appears (udf_renderer_blending.py:97, 265, 543, 860); here the
+        # kernels leave a bit in a device word and the loop looks at it every `status_every` iterations (one 4-byte read,
+        # the only sync of the loop) -- a run that went non-finite stops within that many iterations instead of silently
+        # writing black images
+        if self.status_every and iter_step % self.status_every == 0:
+            self.renderer.check_finite()
         return loss, out, s
 
     def _trainability_toggles(self, out, iter_step):

@@ -89,3 +89,44 @@ def smooth_images(v, h, w, seed=0):
             f = torch.rand(4, generator=g) * 6 + 1
             imgs[i, c] = 0.5 + 0.25 * torch.sin(f[0] * xx + f[1] * yy + i) + 0.2 * torch.cos(f[2] * xx - f[3] * yy + c)
     return imgs
+
+
+def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, tol=1e-4, tie=2e-5, max_rays=3):
+    """Compositing weights of ALL rays against the reference's, where the reference's own arithmetic is discontinuous:
+    `vis_mask = (true_cos < 0.01)` (/root/reference/models/udf_renderer_blending.py:399-405) is a hard selection that
+    switches a factor of the running visibility product between `1 - alpha_occ` and 1, i.e. the alpha of every LATER
+    sample of that ray; where true_cos ties with the threshold to an ulp two fp32 implementations may select differently.
+
+    Contract checked here (instead of exempting such rays wholesale): at most `max_rays` rays contain a weight that differs
+    by more than `tol`; on each of them every weight BEFORE the first sample whose true_cos lies within `tie` of the
+    threshold agrees to `tol`, i.e. the first difference sits at or behind a tie.  `render_again()` re-renders with
+    `rend.diagnostics = True` and returns the result dict (only called when a ray differs).  Returns the [N] bool mask
+    of rays without a difference (per-ray outputs downstream of the weights are compared on those) and the tie list."""
+    import torch
+    w_hip = torch.as_tensor(w_hip).detach().float().cpu()
+    w_ref = torch.as_tensor(w_ref).detach().float().cpu()
+    bad = (w_hip - w_ref).abs() > tol
+    rays = bad.any(dim=1)
+    n = int(rays.sum())
+    assert n <= max_rays, f"{n} rays differ from the reference's weights by > {tol}"
+    ties = []
+    if n:
+        old = rend.diagnostics
+        rend.diagnostics = True
+        try:
+            with torch.no_grad():
+                tc = render_again()["true_cos"].detach().float().cpu().reshape(w_hip.shape[0], -1)
+        finally:
+            rend.diagnostics = old
+        for r in rays.nonzero().flatten().tolist():
+            k = int(bad[r].float().argmax())                       # first differing weight
+            upto = min(k, n_core - 1)
+            near = ((tc[r, :upto + 1] - 0.01).abs() < tie).nonzero().flatten().tolist()
+            assert near, (f"ray {r}: weights differ from sample {k} on (max {float((w_hip[r] - w_ref[r]).abs().max()):.2e}) but no "
+                          f"true_cos within {tie} of the 0.01 threshold at or before it: "
+                          f"{[round(float(x), 6) for x in tc[r, max(0, upto - 3):upto + 1]]}")
+            m = near[0]
+            # everything in front of the tie agrees (by definition of k >= m this is every sample < m)
+            assert float((w_hip[r, :m] - w_ref[r, :m]).abs().max()) <= tol if m > 0 else True
+            ties.append((r, m, k, float(tc[r, m])))
+    return ~rays, ties

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import build_modules, perturb_, state_dicts, checksum, oracle_nets
+from common import build_modules, perturb_, state_dicts, checksum, oracle_nets, weights_vs_reference_up_to_ties
 from oracle import udf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -86,6 +86,8 @@ def test_cfg2_render_core_and_all_parameter_gradients_vs_reference(dev, setup, t
               "gradient_error_near_surface", "sparse_error"]:
         # sparse_error = mean sum exp(-25000 udf) amplifies an fp32 ulp of udf to ~1e-3 relative
         assert rel(out[k], fx["out_" + k]) < (2e-3 if k == "sparse_error" else VTOL), k
+    # ... which is why its INPUT is held to an absolute bound beside it (measured 1.6e-6 = a few fp32 ulp of a udf ~ 1)
+    assert float((out["udf"].detach().cpu() - torch.from_numpy(fx["out_udf"])).abs().max()) < 4e-6
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
     worst, n = ("", 0.0), 0
     for net in ("udf", "color", "var", "beta"):
@@ -131,6 +133,7 @@ def test_shipped_dtu_sampling_with_background_nerf_vs_reference(dev):
     for k in ["color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum", "gradient_error",
               "gradient_error_near_surface", "sparse_error"]:
         assert rel(out[k], fx["out_" + k]) < (2e-3 if k == "sparse_error" else VTOL), k
+    assert float((out["udf"].detach().cpu() - torch.from_numpy(fx["out_udf"])).abs().max()) < 4e-6   # sparse_error's input
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
     worst, n, floats = ("", 0.0), 0, 0
     for net in ("udf", "color", "var", "beta", "nerf"):
@@ -172,16 +175,15 @@ def test_cfg5_shape_fp32_vs_reference(dev):
     loss = _loss(out, rays["true_rgb"])
     loss.backward()
     torch.cuda.synchronize()
-    # The alpha of a sample is a hard selection between two candidates (udf_renderer_blending.py:414-423): where they tie
-    # to an ulp -- here one sample of one ray whose neighbours are 1.7e-6 apart -- fp32 implementations may select
-    # differently and that ray's later weights shift by 1e-3 (its colour by 5e-6).  Such rays are counted, not compared.
-    wd = (out["weights"].detach().cpu() - torch.from_numpy(fx["out_weights"])).abs().max(dim=1)[0]
-    ok = wd < 1e-4
-    assert int((~ok).sum()) <= 3, int((~ok).sum())
+    # `vis_mask = true_cos < 0.01` (udf_renderer_blending.py:399-405) is a hard selection: where true_cos ties with the
+    # threshold to an ulp fp32 implementations may select differently, and that ray's LATER weights shift by 1e-3 (its
+    # colour by 5e-6).  At most 3 rays may hold such a tie, and their weights in front of it are compared like all others.
+    again = lambda: rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                                perturb_overwrite=0, flip_saturation=0.9, z_vals_override=z_ref)
+    ok, ties = weights_vs_reference_up_to_ties(rend, again, out["weights"], fx["out_weights"], 256)
     for k in ["color", "color_base", "weight_sum", "gradient_error", "gradient_error_near_surface", "sparse_error"]:
         assert rel(out[k], fx["out_" + k]) < (2e-3 if k == "sparse_error" else VTOL), k
-    for k in ["weights", "depth"]:
-        assert rel(out[k].detach().cpu()[ok], torch.from_numpy(fx["out_" + k])[ok]) < VTOL, k
+    assert rel(out["depth"].detach().cpu()[ok], torch.from_numpy(fx["out_depth"])[ok]) < VTOL
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
     worst, n = ("", 0.0), 0
     for net in ("udf", "color", "var", "beta"):
@@ -195,7 +197,7 @@ def test_cfg5_shape_fp32_vs_reference(dev):
                 worst = (key, r)
             assert r < GTOL, (key, r)
     assert n >= 50
-    print(f"cfg5 shape (fp32, P = 262 144): rays with a flipped alpha selection {int((~ok).sum())} of 1024; {n} parameter "
+    print(f"cfg5 shape (fp32, P = 262 144): rays with a true_cos tie (ray, tie sample, first differing weight, true_cos) {ties} of 1024; {n} parameter "
           f"gradients vs the reference, worst {worst[0]} {worst[1]:.2e}")
 
 
@@ -236,10 +238,10 @@ def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays):
     # The alpha of a sample is a hard selection between two candidates (udf_renderer_blending.py:414-423): where they tie to
     # an ulp, fp32 implementations may select differently and that ray's later weights shift by ~1e-3 (its colour by
     # ~1e-5) -- see test_cfg5_shape_fp32_vs_reference.  Such rays are counted (<= 3), per-sample arrays compared on the rest.
-    wd = (out["weights"].detach().cpu() - torch.from_numpy(fx["out_weights"])).abs().max(dim=1)[0]
-    ok = wd < 1e-4
+    again = lambda: rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                                perturb_overwrite=0, flip_saturation=0.9, z_vals_override=z_ref)
+    ok, ties = weights_vs_reference_up_to_ties(rend, again, out["weights"], fx["out_weights"], z_ref.shape[1])
     n_flip = int((~ok).sum())
-    assert n_flip <= 3, (n_flip, float(wd.max()))
     worst_v = ("", 0.0)
     for k in ["color", "color_base", "weights", "depth", "udf", "gradients", "normals", "weight_sum", "gradient_error",
               "gradient_error_near_surface", "color_pixel", "patch_colors"]:
@@ -251,7 +253,7 @@ def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays):
         r = rel(a, b)
         if r > worst_v[1]:
             worst_v = (k, r)
-        assert r < (3e-4 if k in ("color_pixel", "patch_colors") else VTOL), (k, r)
+        assert r < (1.5e-4 if k in ("color_pixel", "patch_colors") else VTOL), (k, r)     # worst measured 7e-5
     for k in ("loss", "color_base_loss", "color_loss", "color_pixel_loss", "color_patch_loss"):
         assert abs(float(cl[k]) - float(fx["closs_" + k])) < 2e-4 * max(1.0, abs(float(fx["closs_" + k]))), k
     worst, n = ("", 0.0), 0
@@ -365,8 +367,10 @@ def test_cfg2_end_to_end_matching_rays_and_first_divergence(dev, setup):
             f.write("\n".join(report) + "\n")
     except OSError:
         pass
-    assert frac > 0.7, frac
-    assert psnr > 60.0, psnr
+    # measured (round 4, the reference's transcendentals in the up-sampling kernel): 467-477 / 512 rays, 93.0 dB; the bounds
+    # leave a 2x margin on the number of moved rays / 5 dB so that a regression of the sampling chain fails here
+    assert frac > 0.88, frac
+    assert psnr > 88.0, psnr
 
 
 def _psnr(a, b):
@@ -488,13 +492,12 @@ def test_bench_inputs_vs_reference_fixture(dev):
     loss = _loss(out, rays["true_rgb"])
     loss.backward()
     torch.cuda.synchronize()
-    wd = (out["weights"].detach().cpu() - torch.from_numpy(fx["out_weights"])).abs().max(dim=1)[0]
-    ok = wd < 1e-4
-    assert int((~ok).sum()) <= 3, int((~ok).sum())          # rays with a flipped hard alpha selection (see the cfg5 test)
+    again = lambda: rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0,
+                                perturb_overwrite=0, flip_saturation=1.0, z_vals_override=z_ref)
+    ok, ties = weights_vs_reference_up_to_ties(rend, again, out["weights"], fx["out_weights"], 128)   # see the cfg5 test
     for k in ["color", "color_base", "weight_sum"]:
         assert rel(out[k], fx["out_" + k]) < VTOL, k
-    for k in ["weights", "depth"]:
-        assert rel(out[k].detach().cpu()[ok], torch.from_numpy(fx["out_" + k])[ok]) < VTOL, k
+    assert rel(out["depth"].detach().cpu()[ok], torch.from_numpy(fx["out_depth"])[ok]) < VTOL
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
     worst, n = ("", 0.0), 0
     for net in ("udf", "color", "var", "beta"):
@@ -513,14 +516,14 @@ def test_bench_inputs_vs_reference_fixture(dev):
                           flip_saturation=1.0)
     zerr = (e2e["z_vals"].cpu() - torch.from_numpy(fx["out_z_vals"])).abs().max(dim=1)[0]
     good, close = zerr < 1e-4, zerr < 1e-5
-    assert float(good.float().mean()) > 0.75, int(good.sum())
-    assert float(close.float().mean()) > 0.5, int(close.sum())
+    assert float(good.float().mean()) > 0.88, int(good.sum())          # measured 477 / 512
+    assert float(close.float().mean()) > 0.75, int(close.sum())        # measured 419 / 512
     # seed-0 weights are the geometric initialisation, a sharp sphere: 1e-4 of sample position is 1.4e-4 of colour there, so
-    # the 1e-4 colour bound is held on the rays whose samples agree to 1e-5 (and 3x looser on those within 1e-4)
+    # the 1e-4 colour bound is held on the rays whose samples agree to 1e-5 (and 1.5x looser on those within 1e-4)
     c_close = rel(e2e["color"][close.to(dev)], torch.from_numpy(fx["out_color"])[close])
     c_good = rel(e2e["color"][good.to(dev)], torch.from_numpy(fx["out_color"])[good])
     assert c_close < VTOL, c_close
-    assert c_good < 3 * VTOL, c_good
-    print(f"bench inputs vs the reference: {n} parameter gradients, worst {worst[0]} {worst[1]:.2e}; rays with a flipped alpha "
-          f"selection {int((~ok).sum())}; end to end {int(close.sum())} / 512 rays with samples within 1e-5 (colour {c_close:.1e}), "
+    assert c_good < 1.5 * VTOL, c_good
+    print(f"bench inputs vs the reference: {n} parameter gradients, worst {worst[0]} {worst[1]:.2e}; rays with a true_cos "
+          f"tie {ties}; end to end {int(close.sum())} / 512 rays with samples within 1e-5 (colour {c_close:.1e}), "
           f"{int(good.sum())} within 1e-4 (colour {c_good:.1e})")

@@ -1,0 +1,110 @@
+"""The jittered sampling every training step -- and bench.py's timed step -- runs (perturb = 1): the coarse z are shifted by
+`(rand[N, 1] - 0.5) * 2 / n_samples` and the outside samples drawn stratified, `lower + (upper - lower) * rand[n_outside]`
+(/root/reference/models/udf_renderer_blending.py:617-629).  The drop-in draws with the same calls, shapes and order on the
+rays' device; here the CUDA generator is seeded, the render runs with `perturb_overwrite = -1`, the generator is seeded
+again and the SAME draws are replayed on the host into the oracle's `t_rand` / `t_rand_out` inputs (the oracle's jitter path
+is pinned against the reference code by tests/test_oracle_vs_reference.py::test_jittered_sampling_matches_reference).
+
+  * coarse z and outside z: bit for bit, or 1 ulp where the device's division rounds differently;
+  * the whole jittered render (hierarchical sampling on both sides): rays keeping the oracle's samples, colours / weights
+    on them <= 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import build_modules, perturb_, state_dicts, oracle_nets
+from oracle import udf_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    # BASELINE config 2 (the headline workload): no outside samples
+    "cfg2": (dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0), "ref_cfg2_full.npz", 256),
+    # the shipped DTU conf: 32 stratified outside samples through the background NeRF
+    "dtu_shipped": (dict(n_samples=64, n_importance=50, n_outside=32, up_sample_steps=5, perturb=1.0),
+                    "ref_dtu_shipped_full.npz", 192),
+}
+
+
+def _ulps(a, b):
+    """distance in units of the last place of b (fp32)"""
+    a, b = a.double(), b.double()
+    ulp = torch.from_numpy(np.spacing(np.abs(b.float().numpy()))).double()
+    return ((a - b).abs() / ulp)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_jittered_render_replayed_into_the_oracle(case):
+    from neuraludf_amd.models import fields
+    from neuraludf_amd.models.udf_renderer_blending import UDFRendererBlending
+    dev = torch.device("cuda:0")
+    kw, fixture, N = CASES[case]
+    fx = dict(np.load(os.path.join(HERE, "golden", fixture)))
+    mods = perturb_(build_modules(fields, seed=0))
+    sds = state_dicts(mods)
+    for m in mods.values():
+        m.to(dev)
+    rays = {k[4:]: torch.from_numpy(v)[:N].contiguous() for k, v in fx.items() if k.startswith("ray_")}
+    drays = {k: v.to(dev) for k, v in rays.items()}
+    rend = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"], **kw)
+    coarse = UDFRendererBlending(mods["nerf"], mods["udf"], mods["var"], mods["color"], mods["beta"],
+                                 **{**kw, "n_importance": 0})
+    SEED = 4242
+
+    def hip(r):
+        torch.manual_seed(SEED)                       # seeds the CUDA generator the renderer draws from
+        with torch.no_grad():
+            return r.render(drays["rays_o"], drays["rays_d"], drays["near"], drays["far"], cos_anneal_ratio=0.7,
+                            perturb_overwrite=-1, flip_saturation=0.9)
+
+    out = hip(rend)
+    z_out_hip = rend._z_vals_outside.cpu() if kw["n_outside"] > 0 else None
+    z0_hip = hip(coarse)["z_vals"].cpu()              # n_importance = 0: z_vals ARE the jittered coarse samples
+
+    torch.manual_seed(SEED)                           # the renderer's draws again (udf_renderer_blending.py:618, 626)
+    t_rand = torch.rand([N, 1], device=dev).cpu() - 0.5
+    t_out = torch.rand([kw["n_outside"]], device=dev).cpu() if kw["n_outside"] > 0 else None
+    assert float(t_rand.abs().max()) <= 0.5 and float(t_rand.std()) > 0.2
+
+    cfg = O.RenderCfg(**{k: v for k, v in kw.items() if k != "perturb"})
+    z0, z_out, sd = O.coarse_z(cfg, rays["near"], rays["far"], N, t_rand, t_out)
+    plain0, plain_out, _ = O.coarse_z(cfg, rays["near"], rays["far"], N)
+    assert float((z0 - plain0).abs().max()) > 1e-3    # the jitter is really on
+    u0 = _ulps(z0_hip, z0)
+    assert float(u0.max()) <= 1.0, float(u0.max())
+    exact0 = float((u0 == 0).float().mean())
+    msg = f"{case}: coarse z bit-identical on {100 * exact0:.2f} % of {z0.numel()} samples (worst {float(u0.max()):.0f} ulp)"
+    if z_out is not None:
+        assert float((z_out - plain_out).abs().max()) > 1e-3
+        z_out_full = z_out if z_out.shape[0] == N else z_out.expand(N, -1)
+        uo = _ulps(z_out_hip, z_out_full)
+        assert float(uo.max()) <= 1.0, float(uo.max())
+        msg += f"; outside z bit-identical on {100 * float((uo == 0).float().mean()):.2f} % (worst {float(uo.max()):.0f} ulp)"
+
+    nets = oracle_nets(sds)
+    ref = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                   flip_saturation=0.9, t_rand=t_rand, t_rand_out=t_out)
+    ref = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in ref.items()}
+    dz = (out["z_vals"].cpu() - ref["z_vals"]).abs().max(dim=1)[0]
+    good = dz < 1e-4
+    frac = float(good.float().mean())
+    # the up-sampling is discontinuous (quantile bins): rays whose bins flipped are counted, the others compared
+    assert frac > 0.85, frac
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp(min=1.0))
+
+    worst = ("", 0.0)
+    for k in ["color", "color_base", "weights", "depth", "weight_sum", "weight_sum_fg_bg"]:
+        r = rel(out[k].cpu()[good], ref[k][good])
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < 1e-4, (k, r)
+    mse = float(((out["color"].cpu() - ref["color"]) ** 2).mean())
+    psnr = 10.0 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 80.0, psnr
+    print(msg + f"; jittered render: {int(good.sum())} / {N} rays keep the oracle's samples, worst value on them {worst[0]} "
+          f"{worst[1]:.2e}, colour PSNR over ALL rays {psnr:.1f} dB")

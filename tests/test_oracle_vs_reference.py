@@ -73,6 +73,40 @@ def test_render_matches_reference(ref, case):
             assert _maxrel(nets.nerf[n].grad, p.grad) < 5e-5, n
 
 
+@pytest.mark.parametrize("case", ["classical_bg", "flat"])
+def test_jittered_sampling_matches_reference(ref, case):
+    """perturb = 1 (what every training step -- and bench.py's timed step -- runs): the reference draws `t_rand - 0.5`
+    for the coarse z and a stratified `lower + (upper - lower) * rand` for the outside samples from the default generator
+    (udf_renderer_blending.py:617-627).  Replaying the same draws into the oracle's `t_rand` / `t_rand_out` inputs must give
+    the reference's samples and colours."""
+    rf, rr, rl, mods = ref
+    scene = synth.make_scene("tiny")
+    rays = synth.make_rays(scene, 0, 48, seed=5)
+    if case == "classical_bg":
+        kw = dict(n_samples=32, n_importance=20, n_outside=8, up_sample_steps=5, perturb=1.0)
+    else:
+        kw = dict(n_samples=32, n_importance=0, n_outside=0, up_sample_steps=1, perturb=1.0)
+    r = _renderer(rr, mods, **kw)
+    torch.manual_seed(77)
+    out_ref = r.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                       perturb_overwrite=-1, flip_saturation=0.9)
+    torch.manual_seed(77)                      # the same draws, in the reference's order and shapes
+    t_rand = torch.rand([48, 1]) - 0.5
+    t_out = torch.rand([kw["n_outside"]]) if kw["n_outside"] > 0 else None
+    cfg = O.RenderCfg(n_samples=kw["n_samples"], n_importance=kw["n_importance"], n_outside=kw["n_outside"],
+                      up_sample_steps=kw["up_sample_steps"])
+    nets = oracle_nets(state_dicts(mods))
+    with torch.no_grad():
+        out = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                       flip_saturation=0.9, t_rand=t_rand, t_rand_out=t_out)
+        # and it is a different render from the unperturbed one (the test would otherwise pass vacuously)
+        plain = O.render(nets, cfg, rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=0.7,
+                         flip_saturation=0.9)
+    assert float((plain["z_vals"] - out["z_vals"]).abs().max()) > 1e-3
+    for k in ["z_vals", "color", "color_base", "weights", "depth", "udf", "weight_sum", "weight_sum_fg_bg"]:
+        assert _maxrel(out[k].detach(), out_ref[k].detach()) < 2e-6, k
+
+
 def test_analytic_gradient(ref):
     rf, rr, rl, mods = ref
     x = torch.randn(257, 3) * 0.6
