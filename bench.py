@@ -7,8 +7,12 @@ path (render + colour/eikonal loss + backward + Adam) on synthetic DTU-scan24-sh
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): 512 rays x 128 samples per GPU (64 coarse + 64 hierarchical in
-4 rounds, no outside samples), fp32.  With N GPUs the global batch is 512*N rays, ray-sharded, one
-packed loss all-reduce + one gradient all-reduce per step (weak scaling).
+4 rounds, no outside samples); arithmetic: fp32 EMULATED on the bf16 matrix pipe (`--precision bf16x3`, the default; `fp32`
+= the exact v_mfma_f32_32x32x2_f32 kernels, also timed here as the secondary `fp32_exact` leg).  With N GPUs the global
+batch is 512*N rays, ray-sharded, one packed loss all-reduce + one gradient all-reduce per step (weak scaling);
+`--scaling strong --global-rays 4096` (BASELINE configs[3]) fixes the global batch and gives every rank 4096 / N rays.
+The timed region is `--windows` (5) windows of `--steps` steps each, every window bracketed by barrier + synchronize and
+reduced with MAX over ranks; `ms_per_step` is the MEDIAN window, `window_ms` lists them all.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel class of the step (the fused layer-chain kernel `mlp_chain_kernel`): flops its
@@ -62,6 +66,10 @@ WORKLOADS = {
                                "garment"),
 }
 BLEND_WORKLOADS = {"garment_blend_1024x128": dict(color_pixel_weight=0.5, color_patch_weight=0.1)}
+# BASELINE configs[3]: 4096 GLOBAL rays x (64 + 64), ray-sharded over the ranks (strong scaling: 4096 / N rays per GPU)
+WORKLOADS["dtu_scan118_4096x128"] = (4096, dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0),
+                                     "dtu")
+STRONG_WORKLOADS = {"dtu_scan118_4096x128"}
 
 
 def _cpu_info():
@@ -116,6 +124,7 @@ def _vs_reference_fixture(workload, n_rays, rays, rend, dev):
             "max_abs_diff_on_rays_with_samples_within_1e-5": float((got["color"] - col)[exact].abs().max()) if bool(exact.any()) else None,
             "max_abs_diff_on_rays_with_identical_samples": float((got["color"] - col)[same].abs().max()) if bool(same.any()) else None,
             "weights_max_abs_diff_on_rays_with_identical_samples": float((got["weights"] - w)[same].abs().max()) if bool(same.any()) else None,
+            "weights_max_abs_diff_on_rays_with_samples_within_1e-5": float((got["weights"] - w)[exact].abs().max()) if bool(exact.any()) else None,
             "ray_ulp_diff": ray_diff,
             "fixture": "tests/golden/ref_bench_cfg2_full.npz (the reference's own CPU run on these rays and weights)"}
 
@@ -165,6 +174,7 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
         mse = float(((got["color"] - ref["color"]) ** 2).mean())          # exp_runner_blending.py:341-342 with mask = 1
         dz = (got["z_vals"] - ref["z_vals"]).abs()
         same = dz.max(dim=1)[0] < 1e-4
+        exact = dz.max(dim=1)[0] < 1e-5
         dw = (got["weights"] - ref["weights"]).abs()
         moved = dz >= 1e-4                                                 # individual samples at other positions
         wsum = float(ref["weights"].sum())
@@ -172,6 +182,8 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
                 "max_abs_diff": float((got["color"] - ref["color"]).abs().max()),
                 "max_abs_diff_on_rays_with_identical_samples": float((got["color"] - ref["color"])[same].abs().max()) if bool(same.any()) else None,
                 "weights_max_abs_diff_on_rays_with_identical_samples": float(dw[same].max()) if bool(same.any()) else None,
+                "weights_max_abs_diff_on_rays_with_samples_within_1e-5": float(dw[exact].max()) if bool(exact.any()) else None,
+                "rays_with_samples_within_1e-5": int(exact.sum()),
                 "weights_max_abs_diff": float(dw.max()),
                 "weight_mass_on_moved_samples": (float(ref["weights"][:, :moved.shape[1]][moved].sum()) / wsum) if wsum > 0 else None,
                 "rays": n_rays, "rays_with_identical_samples": int(same.sum()), "samples_per_ray": s_core, "precision": precision,
@@ -283,6 +295,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="dtu_scan24_512x128", choices=list(WORKLOADS))
     ap.add_argument("--rays-per-gpu", type=int, default=0)
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak (default): --rays-per-gpu rays on every rank; strong: --global-rays rays in total, "
+                         "global / N per rank (default for the dtu_scan118_4096x128 workload, BASELINE configs[3])")
+    ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: rays of the whole job (default: the workload's)")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="timed windows of --steps steps each; ms_per_step is the median window (box-to-box and "
+                         "window-to-window spread of a 0.1 s region is ~3 %%)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary exact-fp32 timing leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the extra forward-only timing (profiling runs)")
@@ -291,8 +311,10 @@ def main():
                     help="1: the timed steps are replays of the train step captured in a HIP graph (train.GraphedStep: "
                          "bit-identical to eager steps, one graph launch per step); 0: eager launches")
     ap.add_argument("--precision", default=os.environ.get("NUDF_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "mixed16"],
-                    help="fp32 = the parity path and the headline; mixed16 = BASELINE config 5 (16-bit MFMA operands, "
-                         "fp32 accumulate) -- reported for reference only, never the headline number")
+                    help="bf16x3 (default, the headline) = fp32 products EMULATED on the bf16 matrix pipe (exact 3-way operand "
+                         "split, 6 bf16 MFMA products, fp32 accumulate: fp32-level accuracy, not bit-comparable with fp32 "
+                         "MFMA); fp32 = the exact v_mfma_f32_32x32x2_f32 kernels (also timed as the `fp32_exact` leg); "
+                         "mixed16 = BASELINE config 5 (16-bit MFMA operands, fp32 accumulate) -- never the headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -321,8 +343,17 @@ def main():
 
     mlp.set_precision(args.precision)
     rays_per_gpu, rconf, scene_kind = WORKLOADS[args.workload]
-    if args.rays_per_gpu:
+    scaling = args.scaling or ("strong" if args.workload in STRONG_WORKLOADS else "weak")
+    if scaling == "strong":
+        global_rays = args.global_rays or (rays_per_gpu if args.workload in STRONG_WORKLOADS else rays_per_gpu * 8)
+        if global_rays % world:
+            print(json.dumps({"error": "strong scaling: %d global rays do not divide over %d ranks" % (global_rays, world)}))
+            sys.exit(1)
+        rays_per_gpu = global_rays // world
+    elif args.rays_per_gpu:
         rays_per_gpu = args.rays_per_gpu
+    elif args.workload in STRONG_WORKLOADS:
+        rays_per_gpu = rays_per_gpu // 8          # the workload's per-GPU share on the 8-GPU node it is quoted on
     fused = bool(args.fused_adam)
     try:
         import neuraludf_amd.optim  # noqa: F401
@@ -347,13 +378,20 @@ def main():
             dist.barrier()
 
     from neuraludf_amd.train import GraphedStep
-    # a ray-sharded step (world > 1) is captured only on request (NUDF_DP_GRAPH=1): its two RCCL all-reduces capture and
-    # replay on this image (tests/test_gpu_dist.py), but no 2-GPU run has confirmed it yet -- eager is the multi-GPU default
-    gstep = GraphedStep(tr, eager_steps=2, capture_collectives=os.environ.get("NUDF_DP_GRAPH", "0") == "1") if args.graph else None
+    # a ray-sharded step (world > 1) is captured WITH its two RCCL all-reduces (they capture and replay on this image,
+    # tests/test_gpu_dist.py): the eager step costs 3.8 ms of Python enqueueing per 4.2 ms of kernels, and 8 such processes
+    # share one host.  NUDF_DP_GRAPH=0 keeps the eager launches; the gloo test backend stages through the host and cannot be
+    # captured; a capture that fails falls back to eager launches by itself (GraphedStep) -- `config.launch` says which ran.
+    dp_graph = os.environ.get("NUDF_DP_GRAPH", "1") == "1" and backend == "nccl"
+    gstep = GraphedStep(tr, eager_steps=2, capture_collectives=dp_graph) if args.graph else None
+    coll_eager = None
     use_graph = bool(gstep is not None and gstep.enabled)
     run_step = (lambda: gstep(batch, **step_kw)) if use_graph else (lambda: tr.step(batch, **step_kw))
     if use_graph:                      # set-up, not warm-up: two eager steps, then the capture (+ its first replay)
-        for _ in range(3):
+        nd.collective_counts(reset=True)
+        run_step()
+        coll_eager = dict(nd.collective_counts())      # what ONE step issues (a replay issues them from inside the graph)
+        for _ in range(2):
             run_step()
         st_in = gstep.static_inputs()
         if gstep.replays != 1 or st_in is None:      # this configuration could not be captured: eager launches
@@ -376,29 +414,39 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    barrier()
-    torch.cuda.synchronize()
+    def timed_window(fn, steps):
+        """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; -> seconds, MAX over ranks"""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dtw = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dtw], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtw = float(t.item())
+        return dtw
+
     nd.collective_counts(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    n_win = max(1, args.windows)
+    wins = [timed_window(run_step, args.steps) for _ in range(n_win)]
+    coll = nd.collective_counts()
+    dt = sorted(wins)[len(wins) // 2]                      # the median window
     ms_per_step = dt / args.steps * 1e3
     value = world * rays_per_gpu * s_core / (dt / args.steps)
-    coll = nd.collective_counts()
+    if use_graph and coll_eager is not None:               # replays issue the collectives from inside the graph
+        coll = {k: v * args.steps * n_win for k, v in coll_eager.items()}
 
     result = {
         "metric": "ray-samples/sec (train step)", "value": value, "unit": "ray-samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": scaling, "vs_baseline": None,
+        "window_ms": [w / args.steps * 1e3 for w in wins], "windows": n_win,
         "dtype": DTYPE[args.precision],
         "data": "synthetic",
         "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
@@ -406,11 +454,13 @@ def main():
                    "step": "render + L1/eikonal loss + backward + Adam", "parallelism": f"ray-sharded dp{world}",
                    "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam",
                    "launch": ("HIP graph replay: one graph launch + one 0.8 KB H2D copy of the step's scalars per step "
-                              "(train.GraphedStep; replays are bit-identical to eager steps, tests/test_gpu_graph.py)")
-                   if use_graph else "eager launches"},
+                              "(train.GraphedStep; replays are bit-identical to eager steps, tests/test_gpu_graph.py)"
+                              + ("; the two RCCL all-reduces of the ray-sharded step are nodes of the graph" if world > 1 else ""))
+                   if use_graph else ("eager launches" + (" (ray-sharded step not captured: NUDF_DP_GRAPH=0, a non-RCCL "
+                                                         "backend, or the capture failed)" if world > 1 and args.graph else ""))},
         # data-parallel exchange of the timed region (neuraludf_amd/dist.py): packed loss sums + gradient bucket
         "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend if world > 1 else None,
-        "collectives_per_step": {k: v / args.steps for k, v in coll.items()} if world > 1 else None,
+        "collectives_per_step": {k: v / (args.steps * n_win) for k, v in coll.items()} if world > 1 else None,
         "gradient_message_floats": (tr.bucket.last_message_floats if world > 1 else None),
     }
 
@@ -433,18 +483,19 @@ def main():
         result["forward_only"] = {"value": world * rays_per_gpu * s_core / dtf, "unit": "ray-samples/s", "ms": dtf * 1e3,
                                   "what": "render + loss under no_grad, rank-local clock"}
 
-    if not args.no_roofline:
-        # ---- one instrumented step: HIP events around every GEMM launch on the launch stream.  EVERY rank takes
-        # the step (it contains the data-parallel collectives); only rank 0 records and reports. ----
+    def instrumented(precision):
+        """ONE extra step with HIP events around every libnudf launch class on the launch stream (mlp.PROFILE).  EVERY rank
+        takes the step (it contains the data-parallel collectives); rank 0 returns (roofline, kernels), the others None."""
         mlp.PROFILE = [] if rank == 0 else None
         tr.step(batch, **step_kw)
         torch.cuda.synchronize()
         barrier()
         prof, mlp.PROFILE = mlp.PROFILE, None
-    if rank == 0 and not args.no_roofline:
+        if rank != 0:
+            return None
         agg, per = {}, {}
-        for name, flops, s, e, detail, nbytes in prof:
-            dur = s.elapsed_time(e) * 1e-3
+        for name, flops, s_ev, e_ev, detail, nbytes in prof:
+            dur = s_ev.elapsed_time(e_ev) * 1e-3
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
@@ -454,66 +505,118 @@ def main():
             b[2] += flops
             b[3] += dur
             b[4] += nbytes
-        dom = max(agg, key=lambda k: agg[k][2])
+        mfma_cls = {k: v for k, v in agg.items() if v[1] > 0}          # (the HBM-bound classes carry units <= 0 there)
+        dom = max(mfma_cls, key=lambda k: mfma_cls[k][2])
         n, fl, sec = agg[dom]
         # flops the launches EXECUTE on the pipe they run on: algorithmic (2 M N K) for the fp32 and 16-bit modes, six bf16
         # products per fp32 product in the bf16x3 mode (weight-gradient GEMMs only when they take split operands)
-        x3 = args.precision == "bf16x3"
+        x3 = precision == "bf16x3"
         factor = {k: (X3_PRODUCTS if x3 and (k != "gemm_tn" or mlp.TN_SPLIT) else 1) for k in agg}
-        peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS
-        result["roofline"] = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": factor[dom] * fl / sec / 1e12,
-                              "peak": peak, "unit": "TFLOP/s", "frac": factor[dom] * fl / sec / 1e12 / peak,
-                              "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
-                              "algorithmic_gflop_per_step": fl / 1e9, "executed_flops_per_algorithmic_flop": factor[dom]}
+        peak = MFMA_F32_PEAK_TFLOPS if precision == "fp32" else MFMA_F16_PEAK_TFLOPS
+        roof = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": factor[dom] * fl / sec / 1e12,
+                "peak": peak, "unit": "TFLOP/s", "frac": factor[dom] * fl / sec / 1e12 / peak,
+                "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
+                "algorithmic_gflop_per_step": fl / 1e9, "executed_flops_per_algorithmic_flop": factor[dom],
+                # the convention of `achieved` / `frac`, in one key
+                "flops": ("executed on the bf16 matrix pipe (6 x the algorithmic 2 M N K of SURVEY 8(d))" if x3 else
+                          "algorithmic 2 M N K"),
+                "frac_algorithmic_vs_fp32_pipe": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS}
         if x3:
-            result["roofline"]["what"] = (
+            roof["what"] = (
                 "achieved = EXECUTED bf16 MFMA flops (6 x the algorithmic fp32 flops 2 M N K) / summed HIP-event time of the "
                 "class, against the dense bf16 peak; fp32_equivalent = the algorithmic flops per second, next to the 157.3 "
                 "TFLOP/s of the fp32 MFMA pipe this mode replaces")
-            result["roofline"]["fp32_equivalent"] = {"achieved": fl / sec / 1e12, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
-                                                     "ratio": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            roof["fp32_equivalent"] = {"achieved": fl / sec / 1e12, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
+                                       "ratio": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
         cls_bytes = sum(b[4] for b in per.values() if b[0] == dom)
-        result["roofline"]["vs_hbm_algorithmic"] = {"achieved": cls_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": cls_bytes / sec / 1e9 / HBM_PEAK_GBS,
-                                                   "what": "the class's algorithmic stored-state bytes (every operand / output "
-                                                           "array of every step once) / the same time"}
+        roof["vs_hbm_algorithmic"] = {"achieved": cls_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": cls_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                                      "what": "the class's algorithmic stored-state bytes (every operand / output "
+                                              "array of every step once) / the same time"}
         if dom == "mlp_chain":
             # the class is several instantiations in a rocprofv3 summary: sum them when comparing the average duration
-            result["roofline"]["kernel_names"] = (
+            roof["kernel_names"] = (
                 ["mlp_chain_kernel<64|32, 2> (every chain launch of the bf16x3 mode)"] if x3 else
                 ["mlp_chain_tq_kernel<0|1|2> (UDF sweeps, > 16384 points, fp32)",
-                 "mlp_chain_kernel<64|32, 0|1> (all other chain launches)"])
-        # every MFMA launch class of the step on its own: instantiation + sweep + size, launches, algorithmic GFLOP, summed
-        # HIP-event time, and BOTH roofs -- MFMA (fp32 157.3 TFLOP/s, or 2.5 PFLOP/s for 16-bit chains) and HBM (the
-        # launch's algorithmic stored-state bytes, every operand / output array once, against 8 TB/s); "binding" names the
-        # larger of the two floors, i.e. the roof that launch could at best run into
-        pk = []
+                 "mlp_chain_kernel<64|32, 0|1|3> (all other chain launches)"])
+        # every launch class of the step on its own.  MFMA classes: instantiation + sweep + size, launches, algorithmic
+        # GFLOP, summed HIP-event time, and BOTH roofs -- MFMA (fp32 157.3 TFLOP/s, or 2.5 PFLOP/s for the 16-bit pipe) and
+        # HBM (the launch's algorithmic stored-state bytes, every operand / output array once, against 8 TB/s); "binding"
+        # names the larger of the two floors, i.e. the roof that launch could at best run into.  HBM-bound classes
+        # (composite, upsample, the blending gathers): algorithmic bytes against 8 TB/s and their unit rate.
+        pk, by_bind = [], {"mfma": 0.0, "hbm": 0.0}
         for detail, (name, cnt, f, t, by) in sorted(per.items(), key=lambda kv: -kv[1][3]):
+            if f <= 0:
+                unit = {"patch_blend": "taps", "pixel_blend": "taps"}.get(name, "samples")
+                pk.append({"kernel": detail, "class": name, "launches": cnt, "us": t * 1e6, "algorithmic_mb": by / 1e6,
+                           "gbs": by / t / 1e9, "frac_hbm": by / t / 1e9 / HBM_PEAK_GBS, "binding": "hbm",
+                           "frac_of_binding_roof": by / t / 1e9 / HBM_PEAK_GBS, unit: -f, unit + "_per_s": -f / t})
+                continue
             # executed flops against the peak of the pipe the launch runs on (bf16x3 / mixed16: the dense 16-bit peak)
-            pkp = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_F16_PEAK_TFLOPS
             fx = f * factor.get(name, 1)
-            t_mfma, t_hbm = fx / (pkp * 1e12), by / (HBM_PEAK_GBS * 1e9)
+            t_mfma, t_hbm = fx / (peak * 1e12), by / (HBM_PEAK_GBS * 1e9)
+            bind = "hbm" if t_hbm > t_mfma else "mfma"
+            if name == dom:
+                by_bind[bind] += t
             pk.append({"kernel": detail, "class": name, "launches": cnt, "gflop": f / 1e9, "executed_gflop": fx / 1e9,
-                       "us": t * 1e6, "tflops": fx / t / 1e12, "frac_mfma": fx / t / 1e12 / pkp,
+                       "us": t * 1e6, "tflops": fx / t / 1e12, "frac_mfma": fx / t / 1e12 / peak,
                        "fp32_equivalent_tflops": f / t / 1e12,
                        "algorithmic_mb": by / 1e6, "gbs": by / t / 1e9, "frac_hbm": by / t / 1e9 / HBM_PEAK_GBS,
-                       "binding": "hbm" if t_hbm > t_mfma else "mfma", "frac_of_binding_roof": max(t_mfma, t_hbm) / t})
-        result["roofline"]["per_kernel"] = pk
-        result["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
-                                 "tflops": v[1] / v[2] / 1e12, "executed_tflops": factor[k] * v[1] / v[2] / 1e12}
-                             for k, v in agg.items()}
-        result["roofline"]["traffic"] = pmc_traffic(dom, args.workload, args.precision)
-        result["roofline"]["traffic_source"] = getattr(pmc_traffic, "source", None) if result["roofline"]["traffic"] else None
-        if args.precision != "fp32" and result["roofline"]["traffic"]:
-            # the 16-bit mode is priced against BOTH roofs: the sweeps are nowhere near the 2.5 PFLOP/s matrix peak, so the
-            # HBM side (measured bytes per launch / average launch time) is the one to watch
-            gbs = result["roofline"]["traffic"] / (sec / n) / 1e9
-            result["roofline"]["vs_hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+                       "binding": bind, "frac_of_binding_roof": max(t_mfma, t_hbm) / t})
+        roof["per_kernel"] = pk
+        # `bound` of the class = the roof that binds most of its launch time; the per-launch `binding` is the precise statement
+        roof["bound"] = "hbm" if by_bind["hbm"] > by_bind["mfma"] else "mfma"
+        roof["class_ms_by_binding_roof"] = {k: v * 1e3 for k, v in by_bind.items()}
+        kernels = {k: ({"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12,
+                        "executed_tflops": factor[k] * v[1] / v[2] / 1e12} if v[1] > 0 else
+                       {"launches": v[0], "ms": v[2] * 1e3})
+                   for k, v in agg.items()}
+        roof["traffic"] = pmc_traffic(dom, args.workload, precision)
+        roof["traffic_source"] = getattr(pmc_traffic, "source", None) if roof["traffic"] else None
+        if roof["traffic"]:
+            roof["traffic_note"] = ("PMC passes are recorded beforehand over this command (rocprofv3 cannot wrap the timed "
+                                    "process from inside); the file is keyed on workload + precision + round")
+        if precision != "fp32" and roof["traffic"]:
+            # priced against BOTH roofs: the HBM side = measured bytes per launch / average launch time
+            gbs = roof["traffic"] / (sec / n) / 1e9
+            roof["vs_hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        return roof, kernels
+
+    inst = None
+    if not args.no_roofline:
+        inst = instrumented(args.precision)
+    if rank == 0 and inst is not None:
+        result["roofline"], result["kernels"] = inst
         # ---- fused composite kernel alone (HBM roof) ----
         try:
             result["roofline_composite"] = composite_roofline(dev, rays_per_gpu, s_core)
         except Exception as ex:  # pragma: no cover
             result["roofline_composite"] = {"error": repr(ex)}
+
+    # ---- secondary leg: the EXACT fp32 kernels (v_mfma_f32_32x32x2_f32) on the same trainer, batch and process -- the
+    # conservative number beside the emulated-fp32 headline, timed by the same clock: its own captured step, 2 warm-up
+    # replays, ONE window of min(steps, 10) steps, and its own instrumented step for the fraction of the fp32 pipe's peak
+    if world == 1 and args.precision == "bf16x3" and not args.no_fp32_leg:
+        try:
+            mlp.set_precision("fp32")
+            g32 = GraphedStep(tr, eager_steps=1) if args.graph else None
+            step32 = (lambda: g32(batch, **step_kw)) if (g32 is not None and g32.enabled) else (lambda: tr.step(batch, **step_kw))
+            for _ in range(5):                 # 1 eager + capture + replays
+                step32()
+            n32 = min(args.steps, 10)
+            dt32 = timed_window(step32, n32)
+            leg = {"ms_per_step": dt32 / n32 * 1e3, "value": rays_per_gpu * s_core / (dt32 / n32), "unit": "ray-samples/s",
+                   "steps": n32, "dtype": DTYPE["fp32"],
+                   "launch": "HIP graph replay" if (g32 is not None and g32.replays > 0) else "eager launches"}
+            if not args.no_roofline:
+                r32, k32 = instrumented("fp32")
+                leg.update({"frac": r32["frac"], "achieved": r32["achieved"], "peak": r32["peak"], "unit_roof": "TFLOP/s",
+                            "kernel": r32["kernel"], "kernels": k32})
+            result["fp32_exact"] = leg
+        except Exception as ex:  # pragma: no cover - the headline above must still be reported
+            result["fp32_exact"] = {"error": repr(ex)}
+        finally:
+            mlp.set_precision(args.precision)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -537,11 +640,13 @@ def pmc_traffic(kernel, workload, precision="fp32"):
     timed process from inside, so the counters are collected beforehand; corrected as MI355X_MICROARCH.md
     prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
     if (workload, precision) == ("dtu_scan24_512x128", "bf16x3"):
-        names = ["r04_traffic_%s_bf16x3.json" % kernel]
+        names = ["r%02d_traffic_%s_bf16x3.json" % (r, kernel) for r in (5, 4)]
     elif (workload, precision) == ("dtu_scan24_512x128", "fp32"):
         names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (3, 2, 1)]
     elif (workload, precision) == ("dtu_scan24_1024x256", "mixed16"):
-        names = ["r%02d_traffic_%s_cfg5_mixed16.json" % (r, kernel) for r in (3, 2)]
+        names = ["r%02d_traffic_%s_cfg5_mixed16.json" % (r, kernel) for r in (5, 3, 2)]
+    elif (workload, precision) == ("garment_blend_1024x128", "bf16x3"):
+        names = ["r05_traffic_%s_garment_bf16x3.json" % kernel]
     else:
         return None
     path = next((q for q in (os.path.join(ROOT, "profiles", nm) for nm in names) if os.path.exists(q)), None)

@@ -1,6 +1,10 @@
 """Host-side sequencing of the MLP GEMM chains on libnudf (no torch arithmetic on activations).
 
-Three engines, each a pair of (forward, hand-derived backward) over `nudf_gemm_nn/_tn`:
+Three engines, each a pair of (forward, hand-derived backward).  The default path of every engine is the FUSED LAYER CHAIN
+(`nudf_mlp_chain`: all layers of a sweep in one launch, activations resident in LDS, csrc/mlp_chain.hip) plus the grouped
+weight-gradient GEMM (`nudf_gemm_tn_grouped`); the per-layer launches over `nudf_gemm_nn / nudf_gemm_tn` remain as the
+cross-check path (`USE_CHAIN = False`).  MFMA operand precision: `PRECISION` ("bf16x3" by default = fp32 products emulated on
+the bf16 matrix pipe, "fp32" = exact fp32 MFMA, "mixed16" = BASELINE config 5):
   * UDFEngine    -- UDFNetwork.forward + .gradient (models/fields.py:192-231) and their
                     backward, including the second-order part (the reference differentiates
                     through autograd.grad(create_graph=True));
@@ -170,6 +174,16 @@ def _timed(name, flops, fn, detail=None, nbytes=0.0):
     fn()
     e.record()
     PROFILE.append((name, flops, s, e, detail or name, nbytes))
+
+
+def call_timed(cls, detail, nbytes, name, *args, units=0.0):
+    """`call(name, *args)`; during bench.py's instrumented step (PROFILE is a list) bracketed by HIP events and recorded as
+    a launch of the non-MFMA class `cls` with its ALGORITHMIC bytes (`units`: taps / samples, carried in the flops slot with
+    a negative sign so that the MFMA accounting skips it)."""
+    if PROFILE is None:
+        call(name, *args)
+    else:
+        _timed(cls, -float(units), lambda: call(name, *args), detail, float(nbytes))
 
 
 def gemm_tn(A1, na1, B1, C, NA, NB, M, dbias=None, A2=None, na2=0, B2=None):
@@ -517,7 +531,7 @@ class PackedLinear:
         return [dv, db]
 
 
-# MFMA operand precision of the fused chains.  "fp32" (default) is the parity path (exact fp32 MFMA).  "mixed16" is
+# MFMA operand precision of the fused chains.  "fp32" is the exact fp32 MFMA path (v_mfma_f32_32x32x2_f32).  "mixed16" is
 # BASELINE config 5 (16-bit MLP weights on the CDNA4 matrix cores): fp16 operands in the forward sweeps (value,
 # input gradient, colour), bf16 operands in the backward sweeps (tiny adjoints need fp32's exponent range), fp32
 # accumulation, fp32 activations / stored state / epilogues / weight gradients / optimizer.  The abs-head column
@@ -525,6 +539,11 @@ class PackedLinear:
 # "bf16x3": fp32 EMULATED on the bf16 matrix pipe (NudfChainStep.prec = 3): weights and activations split exactly into
 # three bf16 parts, six partial products per fp32 product, fp32 accumulation -- fp32-level accuracy (the dropped terms are
 # the size of one fp32 rounding) at 12 instead of 32 matrix-pipe cycles per k; state, epilogues, optimizer: fp32.
+# This is the library DEFAULT (and bench.py's headline): its results are fp32-accurate (tests/test_gpu_bf16x3.py: errors against
+# float64 equal the exact kernels') but NOT bit-comparable with the "fp32" kernels -- tests that assert bit-identity between
+# kernels pin set_precision("fp32").  Non-finite inputs: the split of +-inf is inf - inf = NaN in the remainder parts, so an
+# infinite activation or weight comes out as NaN where the fp32 kernels propagate inf; both are non-finite, and the status
+# word (include/nudf.h: nudf_set_status_flag) reports either.  NUDF_PRECISION=fp32 selects the exact kernels.
 PRECISION = os.environ.get("NUDF_PRECISION", "bf16x3")
 _PREC = {"f32": 0, "f16": 1, "bf16": 2, "bf16x3": 3}
 TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too

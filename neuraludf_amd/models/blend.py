@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from .._lib import PatchBlend, PixelBlend, PixelComposite, call, ptr
+from ..mlp import call_timed
 
 
 def _c(t):
@@ -39,7 +40,8 @@ class _PixelBlendFn(torch.autograd.Function):
         a.P, a.V, a.H, a.W, a.img_layout = P, V, H, W, layout
         pix = torch.empty(P, 3, device=pts.device)
         a.pix = ptr(pix)
-        call("nudf_pixel_blend_fwd", a)
+        # algorithmic bytes of the gathers: 4 texels x 12 B per (point, view) tap
+        call_timed("pixel_blend", "pixel_blend_fwd P=%d V=%d" % (P, V), 48.0 * P * V, "nudf_pixel_blend_fwd", a, units=P * V)
         ctx.save_for_backward(pts, logits, proj, imgs)
         ctx.img = (V, H, W, layout)
         return pix
@@ -53,7 +55,8 @@ class _PixelBlendFn(torch.autograd.Function):
         a.pts, a.logits, a.nl, a.proj, a.imgs = ptr(pts), ptr(logits), logits.shape[1], ptr(proj), ptr(imgs)
         a.P, a.V, a.H, a.W, a.img_layout = P, V, H, W, layout
         d_logits = torch.empty_like(logits)
-        call("nudf_pixel_blend_bwd", a, ptr(d_pix.contiguous()), ptr(d_logits))
+        call_timed("pixel_blend", "pixel_blend_bwd P=%d V=%d" % (P, V), 48.0 * P * V, "nudf_pixel_blend_bwd", a,
+                   ptr(d_pix.contiguous()), ptr(d_logits), units=P * V)
         return None, d_logits, None, None
 
 
@@ -110,7 +113,10 @@ class _PatchBlendFn(torch.autograd.Function):
         pc = torch.empty(N, npx, 3, device=pts.device)
         pm = torch.empty(N, device=pts.device)
         a.patch_colors, a.patch_mask = ptr(pc), ptr(pm)
-        call("nudf_patch_blend_fwd", a)
+        S = pts.shape[1]
+        taps = float(N) * S * V * npx          # one bilinear tap = 4 texels x 12 B
+        call_timed("patch_blend", "patch_blend_fwd N=%d S=%d V=%d Npx=%d" % (N, S, V, npx), 48.0 * taps, "nudf_patch_blend_fwd", a,
+                   units=taps)
         ctx.hps = hps
         ctx.save_for_backward(pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs)
         ctx.mark_non_differentiable(pm)      # only ever thresholded by the caller (exp_runner_blending.py:314)
@@ -126,7 +132,10 @@ class _PatchBlendFn(torch.autograd.Function):
         _fill_patch(a, pts, grad, rays_d, uv, logits, w, ref_cam, src_cam, imgs, ctx.hps, ctx.img)
         d_logits = torch.empty_like(logits)
         d_ws = torch.empty(N, S, device=pts.device)
-        call("nudf_patch_blend_bwd", a, ptr(d_pc.contiguous()), ptr(d_logits), ptr(d_ws))
+        V, npx = ctx.img[0], (2 * ctx.hps + 1) ** 2
+        taps = float(N) * S * V * npx          # the backward recomputes the gathers
+        call_timed("patch_blend", "patch_blend_bwd N=%d S=%d V=%d Npx=%d" % (N, S, V, npx), 48.0 * taps, "nudf_patch_blend_bwd", a,
+                   ptr(d_pc.contiguous()), ptr(d_logits), ptr(d_ws), units=taps)
         d_w = torch.zeros_like(w)
         d_w[:, :S] = d_ws
         return None, None, None, None, d_logits, d_w, None, None, None, None

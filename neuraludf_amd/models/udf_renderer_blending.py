@@ -123,7 +123,9 @@ class _CompositeFn(torch.autograd.Function):
             a.defer_sums = 1
             sums.fill_(float("nan"))
             sums._nudf_ws = (ws, (N + 3) // 4)
-        call("nudf_composite_fwd", a)
+        ST = weights.shape[1]
+        mlp.call_timed("composite", "composite_fwd N=%d S=%d" % (N, ST), (48.0 if color is not None else 24.0) * N * ST + 68.0 * N,
+                       "nudf_composite_fwd", a, units=N * ST)
         ctx.c = c
         ctx.save_for_backward(rays_o, rays_d, z, sample_dist, t(background_rgb), udf, grad, color, color_base, bg_z,
                               bg_sigma, bg_color, scal, p_var, p_beta, p_gamma)
@@ -167,7 +169,8 @@ class _CompositeFn(torch.autograd.Function):
         g.ws = ptr(ws)
         g.o_d_udf, g.o_d_grad, g.o_d_color, g.o_d_color_base = ptr(o_udf), ptr(o_grad), ptr(o_col), ptr(o_cb)
         g.o_d_bg_sigma, g.o_d_bg_color, g.o_d_scal, g.o_d_param = ptr(o_sig), ptr(o_bgc), ptr(o_scal), ptr(o_par)
-        call("nudf_composite_bwd", a, g)
+        mlp.call_timed("composite", "composite_bwd N=%d S=%d" % (N, S + n_out), 84.0 * N * (S + n_out) + 68.0 * N,
+                       "nudf_composite_bwd", a, g, units=N * (S + n_out))
         d_par = (None, None, None) if o_par is None else (o_par[0:1].reshape(p_var.shape), o_par[1:2].reshape(p_beta.shape),
                                                          o_par[2:3].reshape(p_gamma.shape))
         return (None, None, None, None, None, None, o_udf, o_grad, o_col, o_cb, None, o_sig, o_bgc, o_scal) + d_par
@@ -397,7 +400,9 @@ class UDFRendererBlending:
         z_new = torch.empty(N, k, device=dev)
         pts_new = torch.empty(N * k, 3, device=dev)
         a.z_new, a.pts_new, a.dbg = ptr(z_new), ptr(pts_new), ptr(dbg)
-        call("nudf_upsample", a)
+        # algorithmic bytes per ray and round: z, udf in (8 M), quantiles (4 K), the merged lists out (8 (M + K)), ray (24)
+        mlp.call_timed("upsample", "upsample N=%d M=%d K=%d" % (N, M, k), float(N) * (8 * M + 4 * k + 8 * (M + k) + 24),
+                       "nudf_upsample", a, units=N * M)
         if pending is not None:
             return z_new, pts_new, z, udf
         return z_new, pts_new

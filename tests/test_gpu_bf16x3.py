@@ -163,3 +163,27 @@ def test_packed_weight_planes_sum_to_the_weight_bit_for_bit(dev):
     ref = ref.reshape(G16, 2, 8, NT, 32).permute(0, 3, 1, 4, 2).reshape(G16, NT, 64, 8)
     assert torch.equal(total, ref)
     assert float(w[:, :, 1].abs().max()) > 0 and float(w[:, :, 2].abs().max()) > 0
+
+
+def test_non_finite_values_stay_non_finite(dev):
+    """The split of +-inf is inf - inf = NaN in the remainder parts: an infinite activation comes out of a bf16x3 layer as
+    NaN where the exact-fp32 kernels may propagate inf.  What must hold in BOTH modes is that a non-finite
+    value is never laundered into a finite one: with the bias of a hidden layer at +inf every point's udf, features and
+    input gradient are non-finite, and the renderer's status word (nudf_set_status_flag) would report it downstream."""
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = perturb_(build_modules(fields, seed=0))
+    udf = mods["udf"].to(dev)
+    with torch.no_grad():
+        udf.lin3.bias.fill_(float("inf"))
+    eng = udf.engine()
+    x = (torch.rand(2048, 3, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
+    for mode in ("fp32", "bf16x3"):
+        mlp.set_precision(mode)
+        eng.invalidate()
+        st = eng.forward(x, need_grad_state=True, feat_ld=288)
+        gr, _ = eng.gradient(x, st)
+        torch.cuda.synchronize()
+        assert not bool(torch.isfinite(st["udf"][:2048]).any()), mode
+        assert not bool(torch.isfinite(st["feat"][:2048, :256]).all(dim=1).any()), mode
+        assert not bool(torch.isfinite(gr[:2048]).all(dim=1).any()), mode

@@ -137,6 +137,26 @@ def test_bench_two_rank_flow():
     assert "cpu_baseline" not in d
 
 
+def test_bench_two_rank_strong_scaling_flow():
+    """`bench.py --scaling strong` ("global N fixed per config, rays sharded"; BASELINE configs[3] is 4096 global
+    rays): 2 ranks on this GPU over the gloo test backend share a FIXED global batch -- the line says so, counts the global
+    rays once, and carries the windowed timing."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "3", "--scaling",
+              "strong", "--global-rays", "128"], {"NUDF_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    assert d["config"]["global_rays"] == 128 and d["config"]["rays_per_gpu"] == 64
+    assert len(d["window_ms"]) == 3 and sorted(d["window_ms"])[1] == pytest.approx(d["ms_per_step"])
+    assert d["value"] == pytest.approx(128 * d["config"]["samples_per_ray"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["collectives_per_step"] == {"all_reduce": 2.0, "all_gather": 0.0}
+    assert "eager" in d["config"]["launch"]          # gloo stages through the host: the ray-sharded step is not captured
+
+
 def test_two_rank_step_rccl(tmp_path):
     """the same 2-rank ray-sharded step over RCCL (backend "nccl"), one rank per GPU: needs two GPUs -- skipped on the
     one-GPU boxes, runs wherever the driver gives the tests a multi-GPU node.  Checks loss / gradients against the
