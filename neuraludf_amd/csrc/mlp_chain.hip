@@ -556,6 +556,16 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     sacc += __shfl_xor(sacc, 32);
     if (h == 0 && col < st.iparam && col < 4) st.row_sums[(size_t)(grow0 >> 5) * 4 + col] = sacc;
   }
+#ifdef NUDF_X3_PROBE_NOSTORE   // timing probe (wrong results downstream): the stored-state arrays are not written
+  if (EPI == NUDF_CH_SOFTPLUS || EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD) {
+    if (st.act_write) {
+      float* ap = act + r0 * CH_LD + st.act_col0 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
+    }
+    return;
+  }
+#endif
   // ---- stores ----
   if (EPI == NUDF_CH_UDFHEAD) {
     if (col == 0) {
@@ -716,6 +726,17 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
     const int col = (ct0 + j) * 32 + ln;
     const unsigned colc = (unsigned)((col < st.N) ? col : 0);
     const unsigned row0 = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h);
+#ifdef NUDF_X3_PROBE_NOX      // timing probe (wrong results): the epilogues' stored operands cost nothing -- the upper bound
+    if (U1) {                 // of what an LDS-DMA prefetch of them under the K loop could buy
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.01f * (float)(row0 & 7);
+    }
+    if (U2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] = 0.5f;
+    }
+    return;
+#endif
     if (U1) {
       const unsigned vo = row0 * (unsigned)st.ldx1 + colc;
 #pragma unroll
@@ -971,6 +992,20 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
         const size_t bstride3 = (size_t)NT * 192;
         const int G16 = st.K >> 4;
         constexpr bool PIPE3 = (NUDF_X3_PIPE == 1) || (NUDF_X3_PIPE == 2 && TM == 32);
+#ifdef NUDF_X3_PROBE_COLSPLIT
+        // probe of VERDICT r4's column split (profiles/r05_chain_colsplit_probe.txt): the wave's two column tiles as two
+        // passes over K -- the K-loop shape a half-step of 128 columns would have (each activation split feeds 12 MFMAs
+        // instead of 24), bit-identical results (same k order per output)
+        if (nrt == 2 && nct == 2) {
+          f32x16 t[2][2];
+          t[0][0] = acc[0][0]; t[1][0] = acc[1][0];
+          ch_mma16x3<2, 1, PIPE3>(arow16, bp3, bstride3, G16, t);
+          acc[0][0] = t[0][0]; acc[1][0] = t[1][0];
+          t[0][0] = acc[0][1]; t[1][0] = acc[1][1];
+          ch_mma16x3<2, 1, PIPE3>(arow16, bp3 + 192, bstride3, G16, t);
+          acc[0][1] = t[0][0]; acc[1][1] = t[1][0];
+        } else
+#endif
         if (nrt == 2 && nct == 2) ch_mma16x3<2, 2, PIPE3>(arow16, bp3, bstride3, G16, acc);
         else if (nrt == 2) ch_mma16x3<2, 1, PIPE3>(arow16, bp3, bstride3, G16, acc);
         else if (nct == 2) ch_mma16x3<1, 2, PIPE3>(arow16, bp3, bstride3, G16, acc);

@@ -1,0 +1,37 @@
+#!/bin/bash
+# round 5, call A: the new parity / status / dist tests with their printed numbers, the whole GPU suite, the default bench line in
+# its new form, and the chain probes (column-split K loop; epilogue memory operations free) as interleaved A/B pairs.
+set -u
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r5a; rm -rf $O; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_jitter_parity.py tests/test_gpu_status_flag.py tests/test_gpu_fullsize_parity.py tests/test_gpu_bf16x3.py "tests/test_gpu_kernels.py::test_render_end_to_end_and_param_grads" tests/test_gpu_dist.py -q -s --tb=short -p no:cacheprovider > $O/pytest_new.log 2>&1; echo "pytest exit $?" >> $O/pytest_new.log
+timeout 1200 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider --deselect tests/test_gpu_fullsize_parity.py --deselect tests/test_gpu_jitter_parity.py > $O/pytest_rest.log 2>&1; echo "pytest exit $?" >> $O/pytest_rest.log
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 300 python bench.py --workload garment_blend_1024x128 --steps 10 --warmup 3 --no-cpu-baseline --windows 3 > $O/bench_blend.json 2>> $O/bench.err
+timeout 300 python bench.py --workload dtu_scan118_4096x128 --steps 5 --warmup 2 --no-cpu-baseline --windows 3 --no-fp32-leg > $O/bench_strong4096.json 2>> $O/bench.err
+# chain probes: interleaved pairs on this box
+for rep in 1; do
+  for tag in ship colsplit nox noxst; do
+    if [ $tag = ship ]; then lib=$R/neuraludf_amd/libnudf.so; else lib=$R/neuraludf_amd/build/libnudf_$tag.so; fi
+    NUDF_LIB=$lib timeout 300 python bench.py --steps 30 --warmup 8 --windows 3 --no-cpu-baseline --no-forward-only --no-fp32-leg > $O/probe_${tag}_$rep.json 2>> $O/probe.err
+  done
+done
+python - "$O" <<'PY'
+import json, glob, sys
+O = sys.argv[1]
+for f in sorted(glob.glob(O + "/probe_*.json")) + [O + "/bench.json", O + "/bench_blend.json", O + "/bench_strong4096.json"]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        pk = {e["kernel"].replace("mlp_chain_kernel", "mck"): round(e["us"], 1) for e in d["roofline"]["per_kernel"]}
+        print(f.split("/")[-1], round(d["ms_per_step"], 3), [round(w, 3) for w in d.get("window_ms", [])], d.get("fp32_exact", {}).get("ms_per_step"), pk)
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+NUDF_LIB=$R/neuraludf_amd/build/libnudf_colsplit.so timeout 300 python scripts/chain_hash.py > $O/hash_colsplit.txt 2>&1
+timeout 300 python scripts/chain_hash.py > $O/hash_ship.txt 2>&1
+cmp $O/hash_ship.txt $O/hash_colsplit.txt && echo "colsplit probe: chain outputs bit-identical ($(wc -l < $O/hash_ship.txt) tensors)"
+timeout 300 python scripts/chain_timeline.py 65536 > $O/timeline_ship.txt 2>&1
+NUDF_LIB=$R/neuraludf_amd/build/libnudf_colsplit.so timeout 300 python scripts/chain_timeline.py 65536 > $O/timeline_colsplit.txt 2>&1
+grep -E "passed|failed|error" $O/pytest_new.log | tail -3; grep -E "passed|failed|error" $O/pytest_rest.log | tail -3

@@ -759,6 +759,7 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
     # ('theorical' weights come from 1 - sigmoid(x) near sigmoid = 1, see test_upsample_and_merge_stagewise: more rays
     # change a bin in one of the five rounds; everything downstream is still checked exactly on the oracle's own samples)
     # ('square': udf = h0^2 is flat around the surface, so the sharp late rounds see relative ulp noise of h0 doubled)
+    print(f"render end to end [{case}]: {int(good.sum())} / {n} rays keep the oracle's samples")
     assert good.float().mean() > {"theorical_bg": 0.3, "square_bg": 0.4}.get(case, 0.7)
     for k in ["color", "color_base", "depth", "weight_sum"]:
         assert rel(out[k][good.to(dev)], ref[k][good]) < 1e-4, k
