@@ -25,14 +25,17 @@ const char* nudf_last_error(void);
  * (models/udf_renderer_blending.py:97-101), up_sample_unbias / up_sample_no_occ_aware's (:265-269, :860-864), the eikonal
  * term of render_core (:543-544) -- each a `.cpu()` sync in the middle of a step.  Here the caller hands the library ONE
  * int32 of device memory (zeroed by the caller); nudf_upsample ORs NUDF_STATUS_NONFINITE_SAMPLES into it when a new sample
- * is not finite, nudf_composite_fwd NUDF_STATUS_NONFINITE_WEIGHTS when a ray's compositing weights are not, and
- * nudf_step_loss_fwd NUDF_STATUS_NONFINITE_LOSS when the step's total loss is not.  Nothing on the device reads the word
+ * is not finite, nudf_composite_fwd NUDF_STATUS_NONFINITE_RENDER when a ray's composited outputs (weight sum, depth, the two
+ * colours) or one of the three renderer scalars / their parameters (inv_s, beta, gamma) are not, and nudf_step_loss_fwd
+ * NUDF_STATUS_NONFINITE_LOSS when the step's total loss is not.  (The per-sample alphas and weights themselves cannot leave
+ * [0, 1]: the reference's clips are hardware min / max here, which drop a NaN operand -- a NaN network output or parameter
+ * therefore shows up in the colours, the scalars and the loss, which is where the bits look.)  Nothing on the device reads the word
  * and no call waits for it: the caller polls it when it likes (UDFRendererBlending.status(), Trainer.iteration every
  * `status_every` iterations).  NULL (the default) switches the checks off.  The pointer is per process (one process per
  * GPU); it is passed to the kernels as an argument, so launches captured in a HIP graph keep the word they were captured with.
  * ---------------------------------------------------------------------------------- */
 enum {
-  NUDF_STATUS_NONFINITE_WEIGHTS = 1,
+  NUDF_STATUS_NONFINITE_RENDER = 1,
   NUDF_STATUS_NONFINITE_SAMPLES = 2,
   NUDF_STATUS_NONFINITE_LOSS = 4
 };
@@ -570,6 +573,12 @@ typedef struct NudfChain {
   NudfChainStep step[NUDF_CH_MAX_STEPS];
 } NudfChain;
 int nudf_mlp_chain(const NudfChain* args, void* stream);
+/* 16-bit mode (prec 1 / 2), 64-point tiles: chains whose steps ALL contract in the same 16-bit type run on the 16-bit-tile
+ * kernel -- the LDS activation tile holds that type (the MFMA operand itself: one ds_read_b128 per 32-row tile and k step, no
+ * conversion in the K loop, 37 KB per workgroup = three workgroups per CU), the epilogue rounds the new activations once on
+ * their way into the tile.  Bit-identical to the fp32-tile kernel (same values rounded to the same type).  0 switches it off
+ * (A/B, tests; env NUDF_CHAIN_T16); returns the old setting. */
+int nudf_set_chain_t16(int on);
 /* out[((g*NT + T)*64 + lane)*4 + j] = B[8g + 4(lane>>5) + j][32T + (lane&31)], zero outside K x N;
  * out holds roundup(K,16)/8 * roundup(N,32)/32 * 256 floats */
 int nudf_pack_frag(const float* B, int ldb, int K, int N, float* out, void* stream);

@@ -196,7 +196,7 @@ SYMBOLS = [
     "nudf_weightnorm_pack", "nudf_weightnorm_unpack_grad",
     "nudf_pixel_blend_fwd", "nudf_pixel_blend_bwd", "nudf_pixel_composite_fwd", "nudf_pixel_composite_bwd",
     "nudf_patch_blend_fwd", "nudf_patch_blend_bwd", "nudf_ssim_patch", "nudf_pixel_warp", "nudf_patch_warp",
-    "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_pack_frag",
+    "nudf_adam_step", "nudf_adam_chunk", "nudf_mlp_chain", "nudf_set_chain_t16", "nudf_pack_frag",
     "nudf_weightnorm_pack_multi", "nudf_weightnorm_unpack_grad_multi",
     "nudf_scalars_fwd", "nudf_scalars_bwd", "nudf_l1_sum_fwd", "nudf_l1_sum_bwd",
     "nudf_sums_errors_fwd", "nudf_sums_errors_bwd", "nudf_color_loss_fwd", "nudf_color_loss_bwd",
@@ -292,6 +292,8 @@ def lib():
         _lib.nudf_adam_chunk.restype = C.c_int
         _bind(_lib)
         _lib.nudf_gemm_tn_grouped_workspace.restype = C.c_int64
+        _lib.nudf_set_chain_t16.argtypes = [C.c_int]
+        _lib.nudf_set_chain_t16.restype = C.c_int
         _lib.nudf_set_status_flag.argtypes = [C.c_void_p]
         _lib.nudf_set_status_flag.restype = C.c_int
         _lib.nudf_status_flag.argtypes = []
@@ -300,7 +302,7 @@ def lib():
 
 
 # ---- the non-finite status word (include/nudf.h: nudf_set_status_flag) -----------------------------------------------
-STATUS_NONFINITE_WEIGHTS, STATUS_NONFINITE_SAMPLES, STATUS_NONFINITE_LOSS = 1, 2, 4
+STATUS_NONFINITE_RENDER, STATUS_NONFINITE_SAMPLES, STATUS_NONFINITE_LOSS = 1, 2, 4
 _STATUS_WORDS = {}        # device index -> the int32 tensor the kernels OR their bits into
 _STATUS_BOUND = None      # device index the library currently points at
 
@@ -334,7 +336,7 @@ def read_status(dev, clear=False):
 
 def status_text(bits):
     names = [(STATUS_NONFINITE_SAMPLES, "non-finite new samples in the hierarchical re-sampling (nudf_upsample)"),
-             (STATUS_NONFINITE_WEIGHTS, "non-finite compositing weights (nudf_composite_fwd)"),
+             (STATUS_NONFINITE_RENDER, "non-finite composited ray outputs or renderer scalars (nudf_composite_fwd)"),
              (STATUS_NONFINITE_LOSS, "non-finite loss (nudf_step_loss_fwd)")]
     return "; ".join(t for b, t in names if bits & b) or "finite"
 

@@ -42,12 +42,20 @@ __device__ __forceinline__ void comp_scalars(const NudfComposite& p, float& inv_
     inv_s = p.scal[0]; beta = p.scal[1]; gamma = p.scal[2];
   }
 }
-__device__ __forceinline__ void comp_scalars_out(const NudfComposite& p) {
-  if (blockIdx.x == 0 && threadIdx.x == 0 && p.p_variance) {
-    float s, b, g;
-    comp_scalars(p, s, b, g);
-    if (p.scal_out) { p.scal_out[0] = s; p.scal_out[1] = b; p.scal_out[2] = g; }
-    if (p.recip_out) { p.recip_out[0] = 1.0f / s; p.recip_out[1] = 1.0f / b; }
+__device__ __forceinline__ void comp_scalars_out(const NudfComposite& p, int32_t* status = nullptr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (p.p_variance) {
+      float s, b, g;
+      comp_scalars(p, s, b, g);
+      if (p.scal_out) { p.scal_out[0] = s; p.scal_out[1] = b; p.scal_out[2] = g; }
+      if (p.recip_out) { p.recip_out[0] = 1.0f / s; p.recip_out[1] = 1.0f / b; }
+    }
+    // the clips above are hardware min / max, which drop a NaN operand: a NaN parameter would otherwise train on
+    // silently as inv_s = 1e-6 (torch's clip hands the NaN on, and the reference stops on it a few lines later)
+    if (status) {
+      const float chk = p.p_variance ? (p.p_variance[0] + p.p_beta[0]) + p.p_gamma[0] : (p.scal[0] + p.scal[1]) + p.scal[2];
+      if (!(fabsf(chk) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_RENDER);
+    }
   }
 }
 
@@ -352,9 +360,10 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p, int
       p.out_normals[ray * 3 + 0] = a_nx; p.out_normals[ray * 3 + 1] = a_ny; p.out_normals[ray * 3 + 2] = a_nz;
       p.out_wsum[ray] = a_ws;
       p.out_wsum_all[ray] = a_wall;
-      // a non-finite weight anywhere on the ray makes this sum non-finite (inf - inf = NaN): the value is in a register,
-      // the check is one compare per ray, the atomic only fires when something is wrong (nudf_set_status_flag)
-      if (status && !(fabsf(a_wall) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_WEIGHTS);
+      // a non-finite composited output of the ray (the values are in registers: seven additions and one compare per ray;
+      // the atomic only fires when something is wrong -- nudf_set_status_flag)
+      if (status && !(fabsf(((a_wall + a_depth) + (a_cr + a_cg)) + ((a_cb + a_br) + (a_bg + a_bb))) <= 3.0e38f))
+        atomicOr(status, NUDF_STATUS_NONFINITE_RENDER);
     }
   }
 
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(NudfComposite p, int
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (p.ws) p.ws[(size_t)blockIdx.x * 5 + threadIdx.x] = t;   // summed by partial_sums_kernel
     else atomicAdd(p.sums + threadIdx.x, t);
-  }  comp_scalars_out(p);
+  }  comp_scalars_out(p, status);
 }
 
 // out[k] = sum_b ws[b * K + k]  (one block of 1024 threads; fixed order -> deterministic batch-global sums; ASSIGNS).
@@ -884,7 +893,8 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p,
       p.out_normals[ray * 3 + 0] = a[7]; p.out_normals[ray * 3 + 1] = a[8]; p.out_normals[ray * 3 + 2] = a[9];
       p.out_wsum[ray] = a[10];
       p.out_wsum_all[ray] = a[11];
-      if (status && !(fabsf(a[11]) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_WEIGHTS);
+      if (status && !(fabsf(((a[11] + a[6]) + (a[0] + a[1])) + ((a[2] + a[3]) + (a[4] + a[5]))) <= 3.0e38f))
+        atomicOr(status, NUDF_STATUS_NONFINITE_RENDER);
     }
   }
   {
@@ -899,7 +909,7 @@ __global__ __launch_bounds__(256) void composite_fwd_blk_kernel(NudfComposite p,
     float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (p.ws) p.ws[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
     else atomicAdd(p.sums + threadIdx.x, t);
-  }  comp_scalars_out(p);
+  }  comp_scalars_out(p, status);
 }
 
 template <int PER>

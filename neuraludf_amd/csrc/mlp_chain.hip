@@ -22,6 +22,7 @@
 
 #include "mlp_chain_shared.h"
 #include <stdlib.h>
+#include <type_traits>
 
 template <int TM>
 struct ChainSmem {
@@ -30,10 +31,20 @@ struct ChainSmem {
   float vs[TM * 3];
 };
 
+// MODE 3 (16-bit-tile kernel, BASELINE config 5): the activation tile holds the MFMA operand type of the chain's steps (fp16 in
+// the forward sweeps, bf16 in the backward ones): 37 KB instead of 75 KB per 64-point workgroup -> three workgroups per CU
 template <int TM>
-__device__ __forceinline__ void ch_write_pe(ChainSmem<TM>& sm, const NudfChain& p, int m0, int col0, float scale,
-                                            float* gdst, int ldg, int gcol0, int zero_to, bool dst16 = false) {
-  ch_write_pe_rows<CH_THREADS>(sm.act, sm.xs, sm.vs, TM, threadIdx.x, p, m0, col0, scale, gdst, ldg, gcol0, zero_to, dst16);
+struct ChainSmem16 {
+  unsigned short act[TM * CH_LD16];
+  float xs[TM * 3];
+  float vs[TM * 3];
+};
+
+template <int TM, class SM>
+__device__ __forceinline__ void ch_write_pe(SM& sm, const NudfChain& p, int m0, int col0, float scale,
+                                            float* gdst, int ldg, int gcol0, int zero_to, bool dst16 = false, int tfmt = 0) {
+  ch_write_pe_rows<CH_THREADS>(reinterpret_cast<float*>(sm.act), sm.xs, sm.vs, TM, threadIdx.x, p, m0, col0, scale, gdst, ldg,
+                               gcol0, zero_to, dst16, false, tfmt);
 }
 
 // K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
@@ -248,6 +259,81 @@ __device__ __forceinline__ void ch_mma16(const float* __restrict__ arow, const u
 #endif
 }
 
+// 16-bit-TILE K loop (MODE 3): the LDS tile already holds the operand type, row-major [row][CH_LD16] halfwords -- lane (i, h)
+// reads its 8 consecutive k of row i as ONE ds_read_b128 per 32-row tile and k step (the fp32-tile loop above: two reads and
+// four v_cvt_pk per tile and step, in every one of the four waves that share the tile), the weight fragments stream exactly
+// as in ch_mma16 (ring of four sets, three k steps in flight).  Same operands in the same order as ch_mma16: the results
+// are bit-identical to the fp32-tile 16-bit kernel's.
+template <int NRT, int NCT, bool BF>
+__device__ __forceinline__ void ch_mma16t(const unsigned short* __restrict__ arow, const uint4* __restrict__ bptr,
+                                          size_t bstride, int G16, f32x16 (&acc)[2][2]) {
+  uint4 a0[NRT], a1[NRT];
+  uint4 br[4][NCT];
+  auto lda = [&](uint4 (&a)[NRT], int g) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) a[i] = *reinterpret_cast<const uint4*>(arow + i * 32 * CH_LD16 + g * 16);
+  };
+  auto ldb = [&](uint4 (&b)[NCT], int g) {
+    const uint4* bq = bptr + (size_t)g * bstride;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j) b[j] = bq[j * 64];
+  };
+  auto mma = [&](const uint4 (&a)[NRT], const uint4 (&b)[NCT]) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i)
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) {
+        if (BF)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                              acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]),
+                                                             acc[i][j], 0, 0, 0);
+      }
+  };
+  const int gl = G16 - 1;
+  lda(a0, 0);
+  ldb(br[0], 0);
+  ldb(br[1], min(1, gl));
+  ldb(br[2], min(2, gl));
+  int g = 0;
+#pragma unroll 1
+  for (; g + 4 <= G16; g += 4) {
+    ldb(br[3], min(g + 3, gl));
+    lda(a1, min(g + 1, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, br[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    ldb(br[0], min(g + 4, gl));
+    lda(a0, min(g + 2, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, br[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    ldb(br[1], min(g + 5, gl));
+    lda(a1, min(g + 3, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, br[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    ldb(br[2], min(g + 6, gl));
+    lda(a0, min(g + 4, gl));
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, br[3]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int rem = G16 - g;          // 0..3 steps left: fragments in br[0..rem-1], activations of step g in a0
+  if (rem > 0) {
+    if (rem > 1) lda(a1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, br[0]);
+    if (rem > 1) {
+      if (rem > 2) lda(a0, g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, br[1]);
+      if (rem > 2) mma(a0, br[2]);
+    }
+  }
+}
+
 // bf16x3 K loop (NudfChainStep.prec == 3): the fp32 product EMULATED on the bf16 matrix pipe, which is 16x faster than
 // the fp32 one.  Every fp32 value is the exact sum of three bf16 parts, x = hi + mid + lo (round to nearest each: 8 + 8 + 8
 // significant bits with signed remainders cover fp32's 24); the weights are split once per optimizer step by the pack kernel
@@ -446,10 +532,14 @@ __device__ __forceinline__ void ch_p4_store(float* C, int ld, unsigned q0, unsig
 // Global addresses are <uniform row pointer> + <per-lane 32-bit offset>.
 // S16: the step's stored-state arrays (X1, X2, C1, and the TANGENT mirror C2) hold bf16 (config-5 mode, NUDF_CH_STATE16)
 // RT16: ReLU-family step in the 16-bit instantiation -- X1 / C1 are bf16 (packed) where the step's layout bits say so
-template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false>
+// T16: the activation tile is the 16-bit one of the MODE 3 kernel (`act` points at halfwords, row stride CH_LD16; tile_bf: it
+// holds bf16, else fp16) -- the new activations are rounded ONCE here, on their way into the tile, instead of in the K loop of
+// each of the four waves that read them (same values: the next step's MFMAs see the same operands)
+template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false, bool T16 = false>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
-                                                 const float* x2in = nullptr, const float* bias_pre = nullptr) {
+                                                 const float* x2in = nullptr, const float* bias_pre = nullptr,
+                                                 bool tile_bf = false) {
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -623,9 +713,20 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     }
   }
   if (st.act_write) {
-    float* ap = act + r0 * CH_LD + st.act_col0 + col;
+    if constexpr (T16) {
+      unsigned short* ap = reinterpret_cast<unsigned short*>(act) + r0 * CH_LD16 + st.act_col0 + col;
+      if (tile_bf) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
+        for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD16] = ch_f2bf(col_ok ? out[r] : 0.0f);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD16] = ch_f2h(col_ok ? out[r] : 0.0f);
+      }
+    } else {
+      float* ap = act + r0 * CH_LD + st.act_col0 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
+    }
   }
 }
 
@@ -669,9 +770,9 @@ __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* 
 #ifndef NUDF_SEQ16
 #define NUDF_SEQ16 1     // A/B build switch (scripts/build_variants.sh): 0 = per-tile loop for the 16-bit stored state
 #endif
-template <int EPI, int NRT, int NCT>
+template <int EPI, int NRT, int NCT, bool T16 = false>
 __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
-                                                  int ln, f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+                                                  int ln, f32x16 (&acc)[2][2], const float (&bpre)[2], bool tile_bf = false) {
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
   uint2 r1[2][4], r2[2][4];      // raw 4-point packs of tile t and t + 1
   auto issue = [&](uint2 (&a1)[4], uint2 (&a2)[4], int i, int j) {
@@ -707,8 +808,8 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 #pragma unroll
       for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
     }
-    ch_epilogue_tile<EPI, true, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1, false, x2,
-                                      &bpre[t % NCT]);
+    ch_epilogue_tile<EPI, true, true, false, T16>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1,
+                                                  false, x2, &bpre[t % NCT], tile_bf);
   }
 }
 
@@ -773,10 +874,10 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
 template <int EPI, int MODE>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
-                                            const float (&px1)[2][2][16], const float (&bpre)[2]) {
-  constexpr bool ANY16 = MODE == 1, X3 = MODE == 2;
+                                            const float (&px1)[2][2][16], const float (&bpre)[2], bool tile_bf = false) {
+  constexpr bool ANY16 = MODE == 1 || MODE == 3, X3 = MODE == 2, T16 = MODE == 3;
   constexpr bool PF = CH_USES_X1(EPI);
-  if constexpr (CH_USES_X2(EPI)) {
+  if constexpr (CH_USES_X2(EPI) && !T16) {
     if (!X3 && st.prec == 0 && nrt == 2 && !(ANY16 && (st.layout & NUDF_CH_STATE16))) {
       float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
       if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1, bpre);
@@ -794,8 +895,8 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
   }
   if constexpr (ANY16 && (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
     if (NUDF_SEQ16 && (st.layout & NUDF_CH_STATE16) && nrt == 2) {
-      if (nct == 2) ch_epilogue_seq16<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else ch_epilogue_seq16<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      if (nct == 2) ch_epilogue_seq16<EPI, 2, 2, T16>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
+      else ch_epilogue_seq16<EPI, 2, 1, T16>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
       return;
     }
   }
@@ -839,12 +940,13 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
     }
     if constexpr (ANY16 && (EPI == NUDF_CH_SOFTPLUS || EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
       if (st.layout & NUDF_CH_STATE16) {
-        ch_epilogue_tile<EPI, false, true>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true, nullptr, &bpre[j]);
+        ch_epilogue_tile<EPI, false, true, false, T16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true, nullptr, &bpre[j], tile_bf);
         continue;
       }
     }
     constexpr bool RT16 = ANY16 && (EPI == NUDF_CH_RELU || EPI == NUDF_CH_MULMASK || EPI == NUDF_CH_ADDMASK);
-    ch_epilogue_tile<EPI, false, false, RT16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3, nullptr, &bpre[j]);
+    ch_epilogue_tile<EPI, false, false, RT16, T16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3, nullptr, &bpre[j],
+                                                   tile_bf);
   }
 }
 
@@ -852,16 +954,28 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
 // the 16-bit code: its register pressure (conversions, raw-bf16 operand prefetch) would otherwise spill into them.
 // MODE 2: some step runs the bf16x3 K loop (fp32 emulated on the bf16 pipe, fp32 stored state): its own instantiation for
 // the same reason -- the split's registers next to the 16-bit state code spilled.
+// MODE 3: every step of the chain uses the SAME 16-bit operand type (fp16: forward sweeps, bf16: backward sweeps) and the LDS
+// tile holds that type (ChainSmem16, ch_mma16t): no conversion and half the LDS reads in the K loop, 37 KB per 64-point
+// workgroup -> THREE workgroups per CU (168 VGPRs).  Results are bit-identical to MODE 1 (the same values are rounded to the
+// same type, once in the epilogue instead of in every reading wave).
+#ifndef NUDF_T16_WGS
+#define NUDF_T16_WGS 3       // A/B build switch: workgroups per CU the 16-bit-tile kernel is register-allocated for
+#endif
 template <int TM, int MODE>
-__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_arg) {
-  constexpr bool ANY16 = MODE == 1, X3 = MODE == 2;
+__global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void mlp_chain_kernel(NudfChain p_arg) {
+  constexpr bool ANY16 = MODE == 1 || MODE == 3, X3 = MODE == 2, T16 = MODE == 3;
   // The descriptor is read where it lies, in the kernarg segment: the by-value parameter is otherwise a private copy that
   // the optimiser has to prove away, and once it fails (it did when the 16-bit epilogues grew) all 2 KB go to scratch and
   // every K loop pays vmcnt(0) for it.
   (void)p_arg;
   const NudfChain& p = *(const NudfChain*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int WMT = TM / 32;  // row tiles per wave in the wide layout
-  __shared__ __attribute__((aligned(16))) ChainSmem<TM> sm;
+  using Smem = typename std::conditional<T16, ChainSmem16<TM>, ChainSmem<TM>>::type;
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  // MODE 3: operand type of the tile = the (common) operand type of the chain's steps
+  const bool tile_bf = T16 && p.step[0].prec == 2;
+  const int tfmt = T16 ? (tile_bf ? 2 : 1) : 0;
+  float* const act_f = reinterpret_cast<float*>(sm.act);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -885,10 +999,22 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
       int gr = m0 + r;
       if (gr > p.P - 1) gr = p.P - 1;
       const f32x4 val = *reinterpret_cast<const f32x4*>(p.A0 + (size_t)gr * p.lda0 + c4 * 4);
-      *reinterpret_cast<f32x4*>(sm.act + r * CH_LD + c4 * 4) = val;
+      if constexpr (T16) {
+        uint2 w;
+        if (tile_bf) {
+          w.x = (unsigned)ch_f2bf(val[0]) | ((unsigned)ch_f2bf(val[1]) << 16);
+          w.y = (unsigned)ch_f2bf(val[2]) | ((unsigned)ch_f2bf(val[3]) << 16);
+        } else {
+          w.x = (unsigned)ch_f2h(val[0]) | ((unsigned)ch_f2h(val[1]) << 16);
+          w.y = (unsigned)ch_f2h(val[2]) | ((unsigned)ch_f2h(val[3]) << 16);
+        }
+        *reinterpret_cast<uint2*>(sm.act + r * CH_LD16 + c4 * 4) = w;
+      } else {
+        *reinterpret_cast<f32x4*>(act_f + r * CH_LD + c4 * 4) = val;
+      }
     }
   } else if (p.init == NUDF_CH_INIT_POSENC) {
-    ch_write_pe<TM>(sm, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0);
+    ch_write_pe<TM>(sm, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0, false, tfmt);
   } else if (p.init == NUDF_CH_INIT_SEED) {
     // da[r, c] = sign[r] * w_row0[c] * inv_scale * softplus'(.)   (reverse-sweep seed, fields.py:219-231)
     const int C = p.k0;
@@ -902,7 +1028,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
                                              : p.A0[(size_t)gr * p.lda0 + c];
       ch_sp_derivs(hst, p.seed_xscale, s, om);
       const float val = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * s;
-      sm.act[r * CH_LD + c] = val;
+      if constexpr (T16) sm.act[r * CH_LD16 + c] = tile_bf ? ch_f2bf(val) : ch_f2h(val);
+      else act_f[r * CH_LD + c] = val;
       if (p.G0 && live) {
         if (p.init_state16 & 2) reinterpret_cast<unsigned short*>(p.G0)[ch_p4_off(gr, c, p.ldg0)] = ch_f2bf(val);
         else p.G0[(size_t)gr * p.ldg0 + c] = val;
@@ -969,8 +1096,27 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
       bpre[j] = st.bias ? st.bias[(col < st.N) ? col : 0] : 0.0f;
     }
 
+    if constexpr (T16) {
+      if (nct > 0) {     // (the dispatcher sends only chains whose steps all have the tile's operand type here)
+        const unsigned short* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD16 + 8 * h;
+        const uint4* bp16 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 64 + lane;
+        const size_t bstride = (size_t)NT * 64;
+        const int G16 = st.K >> 4;
+        if (tile_bf) {
+          if (nrt == 2 && nct == 2) ch_mma16t<2, 2, true>(arow16, bp16, bstride, G16, acc);
+          else if (nrt == 2) ch_mma16t<2, 1, true>(arow16, bp16, bstride, G16, acc);
+          else if (nct == 2) ch_mma16t<1, 2, true>(arow16, bp16, bstride, G16, acc);
+          else ch_mma16t<1, 1, true>(arow16, bp16, bstride, G16, acc);
+        } else {
+          if (nrt == 2 && nct == 2) ch_mma16t<2, 2, false>(arow16, bp16, bstride, G16, acc);
+          else if (nrt == 2) ch_mma16t<2, 1, false>(arow16, bp16, bstride, G16, acc);
+          else if (nct == 2) ch_mma16t<1, 2, false>(arow16, bp16, bstride, G16, acc);
+          else ch_mma16t<1, 1, false>(arow16, bp16, bstride, G16, acc);
+        }
+      }
+    } else
     if (nct > 0) {
-      const float* arow = sm.act + (rt0 * 32 + ln) * CH_LD + 4 * h;
+      const float* arow = act_f + (rt0 * 32 + ln) * CH_LD + 4 * h;
       const f32x4* bptr = Bp + (size_t)ct0 * 64 + lane;
       const size_t bstride = (size_t)NT * 64;  // float4 per k group
       // the 16-bit instantiation never prefetches X1 under the K loop (its conversions need the registers; the fp32 steps
@@ -987,7 +1133,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
           pf.vo[i][j] = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx1 + (unsigned)((col < st.N) ? col : 0);
         }
       if (X3 && st.prec == 3) {
-        const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
+        const float* arow16 = act_f + (rt0 * 32 + ln) * CH_LD + 8 * h;
         const uint4* bp3 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 192 + lane;
         const size_t bstride3 = (size_t)NT * 192;
         const int G16 = st.K >> 4;
@@ -1011,7 +1157,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
         else if (nct == 2) ch_mma16x3<1, 2, PIPE3>(arow16, bp3, bstride3, G16, acc);
         else ch_mma16x3<1, 1, PIPE3>(arow16, bp3, bstride3, G16, acc);
       } else if (ANY16 && st.prec != 0) {
-        const float* arow16 = sm.act + (rt0 * 32 + ln) * CH_LD + 8 * h;
+        const float* arow16 = act_f + (rt0 * 32 + ln) * CH_LD + 8 * h;
         const uint4* bp16 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 64 + lane;
         const int G16 = st.K >> 4;
         const bool bf = st.prec == 2;
@@ -1037,17 +1183,17 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
-        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, sm.act, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre); break;
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
       }
     }
     if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -1057,7 +1203,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(NudfChain p_ar
       // finite zeros (columns never written before hold arbitrary LDS contents)
       const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
       ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col,
-                      min((pe_end + 15) & ~15, 288), (st.layout & NUDF_CH_STATE16) != 0);
+                      min((pe_end + 15) & ~15, 288), (st.layout & NUDF_CH_STATE16) != 0, tfmt);
     }
     __syncthreads();
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -1094,6 +1240,20 @@ static int nudf_chain_quad_mode() {
     return e ? atoi(e) : 0;
   }();
   return mode;
+}
+
+static int g_chain_t16 = -1;     // NUDF_CHAIN_T16 / nudf_set_chain_t16
+static bool nudf_chain_t16_enabled() {
+  if (g_chain_t16 < 0) {
+    const char* e = getenv("NUDF_CHAIN_T16");
+    g_chain_t16 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_chain_t16 != 0;
+}
+extern "C" int nudf_set_chain_t16(int on) {
+  const int old = nudf_chain_t16_enabled() ? 1 : 0;
+  g_chain_t16 = on ? 1 : 0;
+  return old;
 }
 
 extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
@@ -1173,6 +1333,12 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     const int cls = nudf_chain_rows_class(p);
     if (cls >= 0) return nudf_mlp_chain_tq_launch(p, cls, st);
   }
+  // 16-bit mode, 64-point tiles: the 16-bit-TILE kernel (MODE 3) when every step contracts in the same 16-bit type (the
+  // tile holds ONE type): the UDF network's four sweeps with the 16-bit head, the colour / NeRF chains.  NUDF_CHAIN_T16=0
+  // keeps the fp32-tile kernel (A/B; the two are bit-identical).
+  bool t16 = any16 && !roww && nudf_chain_t16_enabled();
+  for (int i = 0; i < p.n_steps && t16; ++i)
+    t16 = (p.step[i].prec == 1 || p.step[i].prec == 2) && p.step[i].prec == p.step[0].prec;
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {
     if (any3) hipLaunchKernelGGL((mlp_chain_kernel<32, 2>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
@@ -1180,6 +1346,7 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     else hipLaunchKernelGGL((mlp_chain_kernel<32, 0>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
   } else {
     if (any3) hipLaunchKernelGGL((mlp_chain_kernel<64, 2>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    else if (t16) hipLaunchKernelGGL((mlp_chain_kernel<64, 3>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
     else if (any16) hipLaunchKernelGGL((mlp_chain_kernel<64, 1>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
     else hipLaunchKernelGGL((mlp_chain_kernel<64, 0>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
   }

@@ -7,6 +7,9 @@
 #define CH_LD 292          // activation row stride in floats (K <= 288): m*292 mod 64 = 36m -> 16 consecutive rows hit
                            // 16 distinct multiples of 4 -> conflict-free ds_read_b128
 #define CH_THREADS 256
+#define CH_LD16 296        // row stride of the 16-bit activation tile in HALFWORDS (K <= 288): 592 bytes = 148 dwords, and
+                           // 148 m mod 32 = 0, 20, 8, 28, 16, 4, 24, 12: the 16-byte reads of 8 consecutive rows cover the 32
+                           // banks exactly -> conflict-free ds_read_b128
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -63,11 +66,52 @@ __device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, 
 // global mirror), NTHR cooperating threads.  One work item per (point, coordinate, octave): ONE sincosf gives the sin
 // and the cos column of that octave (the per-element form called sinf or cosf once per column: 2.2x the libm calls;
 // the PE of a 64-point tile took 46 k cycles, 6 % of a forward sweep).  Same arguments 2^k x, same libm kernels.
+// TFMT: element type of the LDS tile -- 0 fp32 (row stride CH_LD floats), 1 fp16, 2 bf16 (row stride CH_LD16 halfwords: the
+// 16-bit-tile chain kernel, whose tile IS the MFMA operand)
+__device__ __forceinline__ unsigned short ch_f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
 template <int NTHR>
 __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, const float* vs, int rows, int tid,
                                                  const NudfChain& p, int m0, int col0, float scale, float* gdst,
                                                  int ldg, int gcol0, int zero_to, bool dst16 = false,
-                                                 bool dstblk = false) {
+                                                 bool dstblk = false, int tfmt = 0) {
+  if (tfmt != 0) {   // 16-bit tile: same work items, same values, rounded once on their way into the tile
+    unsigned short* a16 = reinterpret_cast<unsigned short*>(act);
+    const int L = p.pe_L;
+    const int E = 3 * (2 * L + 1);
+    for (int it = tid; it < rows * 3 * (L + 1); it += NTHR) {
+      const int rj = it / (L + 1), k = it - rj * (L + 1) - 1;
+      const int r = rj / 3, j = rj - 3 * r;
+      const float xv = xs[rj] * p.pe_in_scale;
+      const float tv = vs[rj] * p.pe_in_scale;
+      unsigned short* arow = a16 + r * CH_LD16 + col0;
+      const bool mirror = gdst && (m0 + r) < p.P;
+      const size_t goff = (size_t)(m0 + r) * ldg + gcol0;
+      auto put = [&](int c, float val) {
+        val *= scale;
+        arow[c] = (tfmt == 2) ? ch_f2bf(val) : ch_f2h(val);
+        if (mirror) {
+          if (dst16) reinterpret_cast<unsigned short*>(gdst)[ch_p4_off(m0 + r, gcol0 + c, ldg)] = ch_f2bf(val);
+          else gdst[goff + c] = val;
+        }
+      };
+      if (k < 0) {
+        put(j, p.pe_jvp ? tv : xv);
+      } else {
+        const float f = (float)(1 << k);
+        float sn, cs;
+        sincosf(xv * f, &sn, &cs);
+        put(3 + 6 * k + j, p.pe_jvp ? cs * f * tv : sn);
+        put(6 + 6 * k + j, p.pe_jvp ? -sn * f * tv : cs);
+      }
+    }
+    const int npad = zero_to - (col0 + E);
+    if (npad > 0)
+      for (int e = tid; e < rows * npad; e += NTHR) {
+        const int r = e / npad, c = e - r * npad;
+        a16[r * CH_LD16 + col0 + E + c] = 0;
+      }
+    return;
+  }
   const int L = p.pe_L;
   const int E = 3 * (2 * L + 1);
   for (int it = tid; it < rows * 3 * (L + 1); it += NTHR) {

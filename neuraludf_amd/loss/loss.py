@@ -61,7 +61,7 @@ class LossWeights:
         # of a loss that has not run its backward yet may still hold views of the previous vector, so it is never
         # overwritten in place; staged through pinned host memory, so the copy does not stall the host-ahead pipeline
         import torch as _t
-        h = _t.tensor(vals, dtype=_t.float32)
+        h = _t.tensor(vals, dtype=_t.float32, device="cpu")     # (the reference runner makes CUDA the default tensor type)
         if _t.device(device).type == "cuda":
             h = h.pin_memory()
         self._own = h.to(device, non_blocking=True)

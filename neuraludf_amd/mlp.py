@@ -358,6 +358,10 @@ class ChainBuilder:
         else:
             mode = {"fp32": 0, "mixed16": 1, "bf16x3": 2}[PRECISION]
             t32 = self.c.tile_rows == 32 or (self.c.tile_rows != 64 and P <= 256 * 64)
+            if mode == 1 and not t32 and os.environ.get("NUDF_CHAIN_T16", "1") != "0":
+                precs = {int(self.c.step[i].prec) for i in range(self.n)}
+                if len(precs) == 1 and precs <= {1, 2}:
+                    mode = 3           # the 16-bit-tile kernel (one operand type in every step)
             kern = "mlp_chain_kernel<%d, %d>" % (32 if t32 else 64, mode)
         sweep = ("tangent" if "TANGENT" in e else "adjoint" if "BWD" in e else "input-gradient" if "MULSP" in e
                  else "relu-backward" if e & {"MULMASK", "ADDMASK"} else "udf-forward" if "SOFTPLUS" in e
@@ -560,6 +564,16 @@ def _tn_prec():
 # 16-bit mode: the UDF engine's saved-for-backward arrays (X, DA, R, EX, ABAR) are stored as bf16 -- half the HBM
 # traffic of the sweeps and of the weight-gradient GEMMs that read them.  STATE16 = False keeps them fp32 (A-B).
 STATE16 = os.environ.get("NUDF_STATE16", "1") != "0"
+# 16-bit mode: the abs-head column (K = 256, N = 1) contracts in fp16 like every other step of the forward sweep, so that the
+# whole sweep has ONE operand type and runs on the 16-bit-TILE chain kernel (mlp_chain_kernel<64, 3>: the LDS activation tile IS
+# the fp16 operand, three workgroups per CU).  The activations the head sees are the fp16-rounded ones every hidden layer sees;
+# only the head's 256 weights lose their fp32 mantissa.  HEAD16 = False keeps the head on the fp32 MFMA (and the sweep on the
+# fp32-tile kernel): A/B, and the reference point of tests/test_gpu_mixed16.py.
+HEAD16 = os.environ.get("NUDF_HEAD16", "1") != "0"
+
+
+def _head_kind():
+    return "fwd_head0@f16" if (PRECISION == "mixed16" and HEAD16) else "fwd_head0"
 
 
 # fp32 mode, large launches: the UDF engine's saved state in the BLOCKED layout + the transposed-product chain kernel
@@ -830,8 +844,8 @@ class UDFEngine:
         """fragment-ordered weight copies each layer needs for the four sweeps."""
         kinds = []
         for l, pl in enumerate(self.layers):
-            if l == self.L:      # the abs-head column (udf itself) always in fp32
-                ks = ["fwd_head0", _kind("fwd_feat", "fwd"), _kind("bwd_feat", "bwd")]
+            if l == self.L:      # the abs-head column (udf itself): fp32, or fp16 in the 16-bit mode (HEAD16)
+                ks = [_head_kind(), _kind("fwd_feat", "fwd"), _kind("bwd_feat", "bwd")]
             elif l in self.skip:
                 ks = [_kind("fwd", "fwd"), _kind("bwd", "fwd"), _kind("bwd_hid:%d" % self.layers[l - 1].out, "bwd")]
                 if PRECISION != "fp32":
@@ -889,7 +903,7 @@ class UDFEngine:
                     _zero_cols(feat, F)
             cb.step("NONE", pl.frag(_kind("fwd_feat", "fwd")), k8(pl.inp), F, bias=pl.bias, bias_off=1, C1=feat,
                     act_write=0)
-        cb.step("UDFHEAD", pl.frag("fwd_head0"), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,
+        cb.step("UDFHEAD", pl.frag(_head_kind()), k8(pl.inp), 1, bias=pl.bias, C1=sign, C2=udf, ldc1=1, ldc2=1,
                 act_write=0, scale=1.0 / float(net.scale), iparam=self.head_type)
         cb.launch()
         return dict(udf=udf[:P], sign=(sign[:P] if sign is not None else None),

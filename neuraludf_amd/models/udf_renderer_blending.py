@@ -620,8 +620,8 @@ class UDFRendererBlending:
         return next(self.udf_network.parameters()).device
 
     def status(self, clear=False):
-        """bits seen since the last clear: 1 = non-finite compositing weights, 2 = non-finite new samples, 4 = non-finite
-        loss (_lib.STATUS_*).  Reads 4 bytes from the device, i.e. waits for the work enqueued so far."""
+        """bits seen since the last clear: 1 = non-finite composited ray outputs / renderer scalars, 2 = non-finite new
+        samples, 4 = non-finite loss (_lib.STATUS_*).  Reads 4 bytes from the device, i.e. waits for the work enqueued so far."""
         return _lib.read_status(self._device(), clear=clear)
 
     def clear_status(self):

@@ -760,7 +760,8 @@ def test_render_end_to_end_and_param_grads(dev, nets, case):
     # change a bin in one of the five rounds; everything downstream is still checked exactly on the oracle's own samples)
     # ('square': udf = h0^2 is flat around the surface, so the sharp late rounds see relative ulp noise of h0 doubled)
     print(f"render end to end [{case}]: {int(good.sum())} / {n} rays keep the oracle's samples")
-    assert good.float().mean() > {"theorical_bg": 0.3, "square_bg": 0.4}.get(case, 0.7)
+    # measured (round 5): 64 / 62 / 64 / 62 of 64 rays for the default settings, 46 ('theorical'), 51 ('square')
+    assert good.float().mean() > {"theorical_bg": 0.55, "square_bg": 0.6}.get(case, 0.85)
     for k in ["color", "color_base", "depth", "weight_sum"]:
         assert rel(out[k][good.to(dev)], ref[k][good]) < 1e-4, k
     mse = ((out["color"].cpu() - ref["color"]) ** 2).mean()
