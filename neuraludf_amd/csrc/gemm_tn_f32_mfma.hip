@@ -45,6 +45,7 @@
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 #define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
 #define TNF_NO_SPLIT_IMAGE 512      // bf16x3 mode through the generic kernel (split on the way out of the fp32 image; A/B of gemm_tn3_group_kernel)
+#define TNF_NO_WIDE 1024            // bf16x3 mode: the 128 x 128 two-barrier kernel instead of the wide double-buffered one (A/B; bit-identical)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -64,7 +65,11 @@ struct TnPlan {
   NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
   TnTile tile[TN_MAX_TILES + 1];   // tile[n_tiles].blk_start = total workgroups
   int n_tiles, M, prec, flags;
+  short partner[TN_MAX_TILES];     // wide bf16x3 kernel (gemm_tn3w_group_kernel): >= 0 = this tile leads a pair with the tile one
+                                   // tile row below (same problem, same tile column, same chunks); -1 = a leader without partner;
+                                   // -2 = follower (its workgroups exit: the leader's workgroup computes both tiles)
   int assign;                      // reduce kernel: C = 0 + sum instead of C += sum
+  int wide;                        // the wide bf16x3 kernel runs this plan (partner[] is set)
   float* ws;
   long long* dbg;                  // tuning: per workgroup {start, end} of wall_clock64 (100 MHz), layout, n
 };
@@ -1169,6 +1174,216 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
   }
 }
 
+// =======================================================================================================
+// bf16x3 mode, WIDE form (round 5): one 8-wave workgroup per CU computes TWO vertically adjacent 128 x 128 tiles of a problem
+// -- a 256 x 128 block: 25 % less operand traffic per flop than two 128 x 128 workgroups (the B panel is staged once) -- from a
+// DOUBLE-BUFFERED split image (2 x 72 KB), so a k-step has ONE barrier: step kt's MFMAs read buffer kt & 1 while step kt + 1
+// is split into the other one.  The two waves of every SIMD run the two halves of a step in OPPOSITE order -- waves 0..3
+// multiply first and stage afterwards, waves 4..7 stage first and multiply afterwards (both orders are legal between the
+// same two barriers: the staged rows were requested two steps ago and the target buffer was last read before the previous
+// barrier) -- so one wave's split / LDS stores run beside its partner's 48 MFMAs instead of both waves leaving the matrix
+// pipe idle together (what the two-barrier 128 x 128 kernel does: 36 % MFMA-busy).
+// Same 32-row k-steps, same row chunks, same MFMA order per accumulator, same workspace slots (a wave's 64 x 64 quadrant is
+// written where the 128 x 128 kernel's wave writes it) and the same fixed-order reduce: C and dbias are BIT-IDENTICAL to
+// gemm_tn3_group_kernel's (tests/test_gpu_bf16x3.py).  The plan keeps its 128 x 128 tiles; TnPlan.partner pairs them, the
+// workgroups of a follower tile exit at once.
+// =======================================================================================================
+#define T3WA (4 * 256 * 4)   // dwords per plane of the A image [k-pair group 4][column 256][4]
+#define T3WB (4 * 128 * 4)   // ... of the B image
+#define T3W_BUF (3 * T3WA + 3 * T3WB)
+__global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
+  __shared__ __attribute__((aligned(16))) unsigned smem_w[2 * T3W_BUF];   // 144 KB: one workgroup per CU
+  int t, chunk;
+  tn_decode(g, t, chunk);
+  const int partner = g.partner[t];
+  if (partner == -2) return;                      // follower tile: computed by its leader's workgroup
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const bool two = partner >= 0;
+  const int slot0 = tl.blk_start + chunk;
+  const int slot1 = two ? g.tile[partner].blk_start + chunk : slot0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;                       // 0..7: A quadrant wave >> 1 (64 columns), B half wave & 1
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const int mbeg = chunk * tl.rows_per_block;
+  const int mend = min(mbeg + tl.rows_per_block, g.M);
+  const int nk = (mend - mbeg + BK3 - 1) / BK3;
+  const int sca = tid & 255, sga = tid >> 8;       // A staging: column of the 256-wide panel, rows 16 sga .. + 15 of the step
+  const int scb = tid & 127, sgb = tid >> 7;       // B staging: column, rows 8 sgb .. + 7 (one k-pair group)
+  const bool bias_tile = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
+  const bool do_bias = bias_tile && (two || sca < BM);
+  float bias_acc = 0.0f;
+  const bool mm_live = two || wave < 4;            // an unpaired tile: waves 4..7 only stage
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s2][r] = 0.0f;
+
+  const float* pa = q.A1 + min(i0 + sca, q.lda1 - 1);
+  const float* pb = q.B1 + min(j0 + scb, q.ldb1 - 1);
+  const size_t lda = (size_t)q.lda1, ldb = (size_t)q.ldb1;
+  auto load_a = [&](float (&st)[16], int kt) {
+    const int r0 = mbeg + kt * BK3 + 16 * sga;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = pa[(size_t)min(r0 + r, g.M - 1) * lda];
+  };
+  auto load_b = [&](float (&st)[8], int kt) {
+    const int r0 = mbeg + kt * BK3 + 8 * sgb;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) st[r] = pb[(size_t)min(r0 + r, g.M - 1) * ldb];
+  };
+  auto store_a = [&](const float (&st)[16], int kt, unsigned* img) {
+    const int r0 = mbeg + kt * BK3 + 16 * sga;
+    u32x4 hq[2], mq[2], lq[2];
+    float ps[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      const float x0 = (r0 + 2 * pp < mend) ? st[2 * pp] : 0.0f;
+      const float x1 = (r0 + 2 * pp + 1 < mend) ? st[2 * pp + 1] : 0.0f;
+      unsigned a, b, d;
+      tn_split3_pair(x0, x1, a, b, d);
+      hq[pp >> 2][pp & 3] = a; mq[pp >> 2][pp & 3] = b; lq[pp >> 2][pp & 3] = d;
+      ps[pp] = x0 + x1;
+    }
+    // (the same tree per 16 rows and the same running sum as gemm_tn3_group_kernel: identical bias gradients)
+    if (do_bias) bias_acc += ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    unsigned* dst = img + ((2 * sga) * 256 + sca) * 4;
+    *reinterpret_cast<u32x4*>(dst) = hq[0];
+    *reinterpret_cast<u32x4*>(dst + 1024) = hq[1];
+    *reinterpret_cast<u32x4*>(dst + T3WA) = mq[0];
+    *reinterpret_cast<u32x4*>(dst + T3WA + 1024) = mq[1];
+    *reinterpret_cast<u32x4*>(dst + 2 * T3WA) = lq[0];
+    *reinterpret_cast<u32x4*>(dst + 2 * T3WA + 1024) = lq[1];
+  };
+  auto store_b = [&](const float (&st)[8], int kt, unsigned* img) {
+    const int r0 = mbeg + kt * BK3 + 8 * sgb;
+    u32x4 hq, mq, lq;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const float x0 = (r0 + 2 * pp < mend) ? st[2 * pp] : 0.0f;
+      const float x1 = (r0 + 2 * pp + 1 < mend) ? st[2 * pp + 1] : 0.0f;
+      unsigned a, b, d;
+      tn_split3_pair(x0, x1, a, b, d);
+      hq[pp] = a; mq[pp] = b; lq[pp] = d;
+    }
+    unsigned* dst = img + 3 * T3WA + (sgb * 128 + scb) * 4;
+    *reinterpret_cast<u32x4*>(dst) = hq;
+    *reinterpret_cast<u32x4*>(dst + T3WB) = mq;
+    *reinterpret_cast<u32x4*>(dst + 2 * T3WB) = lq;
+  };
+  auto mma = [&](const unsigned* img) {
+    const unsigned* as = img + ((lane >> 5) * 256 + (wave >> 1) * 64 + (lane & 31)) * 4;
+    const unsigned* bs = img + 3 * T3WA + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK3 / 16; ++kk) {
+      u32x4 a[2][3], b[2][3];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[s2][pl] = *reinterpret_cast<const u32x4*>(as + pl * T3WA + (2 * kk) * 1024 + 128 * s2);
+          b[s2][pl] = *reinterpret_cast<const u32x4*>(bs + pl * T3WB + (2 * kk) * 512 + 128 * s2);
+        }
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt) {
+        const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
+        const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][qa]),
+                                                                     __builtin_bit_cast(bf16x8, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+      }
+    }
+  };
+  unsigned* buf0 = smem_w;
+  unsigned* buf1 = smem_w + T3W_BUF;
+  float sa[16], sb[8], sa2[16], sb2[8];
+  if (nk > 0) {
+    load_a(sa, 0);
+    load_b(sb, 0);
+    if (nk > 1) {
+      load_a(sa2, 1);
+      load_b(sb2, 1);
+    }
+    store_a(sa, 0, buf0);
+    store_b(sb, 0, buf0);
+  }
+  __syncthreads();
+  const bool mma_first = wave < 4;
+  auto kstep = [&](int kt, float (&la)[16], float (&lb)[8], float (&ua)[16], float (&ub)[8], const unsigned* cur, unsigned* nxt) {
+    // la / lb: free staging set, receives step kt + 2; ua / ub: holds step kt + 1, split into `nxt` during this step
+    if (kt + 2 < nk) {
+      load_a(la, kt + 2);
+      load_b(lb, kt + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (mma_first) {
+      if (mm_live) mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        store_a(ua, kt + 1, nxt);
+        store_b(ub, kt + 1, nxt);
+      }
+    } else {
+      if (kt + 1 < nk) {
+        store_a(ua, kt + 1, nxt);
+        store_b(ub, kt + 1, nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (mm_live) mma(cur);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, sa, sb, sa2, sb2, buf0, buf1);
+    if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb, buf1, buf0);
+  }
+
+  if (g.flags & TNF_NO_EPILOGUE) return;
+  const int tsel = wave >> 2;                                   // which tile of the pair this wave's quadrant belongs to
+  const int vw = 2 * ((wave >> 1) & 1) + (wave & 1);            // its wave id in the 128 x 128 kernel's quadrant layout
+  float* slot_t[2] = {g.ws ? g.ws + (size_t)slot0 * TN_WS_TILE : nullptr, g.ws ? g.ws + (size_t)slot1 * TN_WS_TILE : nullptr};
+  if (bias_tile) {   // the loop's last barrier has passed: the image is free
+    float* red = reinterpret_cast<float*>(smem_w);
+    red[sga * 256 + sca] = bias_acc;
+    __syncthreads();
+    if (tid < 256 && (two || tid < BM)) {
+      const float sum = red[tid] + red[256 + tid];
+      float* sl = slot_t[tid >> 7];
+      if (sl) sl[BM * BN + (tid & 127)] = sum;
+      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
+    }
+  }
+  if (!mm_live) return;
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    float* slot = slot_t[tsel];
+    if (slot) {
+      float* w = slot + ((vw * 4 + s2) * 64 + lane) * 16;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {acc[s2][4 * qd], acc[s2][4 * qd + 1], acc[s2][4 * qd + 2], acc[s2][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
+      }
+    } else {
+      const int col = j0 + 32 * tn_jsub(2, vw, s2) + (lane & 31);
+      if (col >= q.NB) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 128 * tsel + 32 * tn_isub(2, vw, s2) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s2][r]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side: the plan (tiles, layouts, cost-weighted row chunks) and the C ABI
 // ---------------------------------------------------------------------------------------
@@ -1280,6 +1495,37 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   pl.M = g.M;
   pl.prec = g.prec;
   pl.flags = flags;
+  // bf16x3 groups of fp32 row-major operands: pair every tile with the tile one tile row below it (same problem, same tile
+  // column) for the wide kernel -- one 8-wave workgroup per CU computes both.  Worth it when most tiles find a partner (the
+  // UDF network's 256-wide layers; the colour net's 128-wide ones do not).
+  pl.wide = 0;
+  int n_units = nt;
+  for (int t = 0; t < nt; ++t) pl.partner[t] = -1;
+  {
+    bool ok = g.prec == 3 && !(flags & (TNF_NO_SPLIT_IMAGE | TNF_NO_WIDE));
+    for (int i = 0; i < g.n_problems && ok; ++i)
+      if (g.prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) ok = false;
+    if (ok) {
+      int pairs = 0;
+      for (int t = 0; t < nt; ++t) {
+        if (pl.partner[t] != -1 || (pl.tile[t].ti & 1)) continue;
+        const NudfGemmTNProblem& q = g.prob[pl.tile[t].prob];
+        const int tj_n = (q.NB + BN - 1) / BN;
+        const int u = t + tj_n;                        // tiles of a problem are enumerated tile row by tile row
+        if (u < nt && pl.tile[u].prob == pl.tile[t].prob && pl.tile[u].ti == pl.tile[t].ti + 1 && pl.tile[u].tj == pl.tile[t].tj) {
+          pl.partner[t] = (short)u;
+          pl.partner[u] = -2;
+          ++pairs;
+        }
+      }
+      if (4 * pairs >= nt) {                           // at least half of the tiles are in pairs
+        pl.wide = 1;
+        n_units = nt - pairs;
+      } else {
+        for (int t = 0; t < nt; ++t) pl.partner[t] = -1;
+      }
+    }
+  }
   const int nkt = (g.M + BK - 1) / BK;                 // k-steps over all points
   int chunks_of[TN_MAX_TILES];
   if (g.rows_per_block > 0) {
@@ -1298,6 +1544,15 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
     static int target = -1;
     if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
     const int max_chunks = nkt / 8 > 0 ? nkt / 8 : 1;
+    if (pl.wide) {
+      // one resident wave of WIDE workgroups: a pair (or an unpaired tile) per CU, every tile the same number of chunks
+      static int target_w = -1;
+      if (target_w < 0) { const char* e = getenv("NUDF_TNW_BLOCKS"); target_w = e ? atoi(e) : 256; }
+      int n = target_w / n_units;
+      if (n < 1) n = 1;
+      if (n > max_chunks) n = max_chunks;
+      for (int t = 0; t < nt; ++t) chunks_of[t] = n;
+    } else {
     auto count = [&](double T, bool store) {
       long total = 0;
       for (int t = 0; t < nt; ++t) {
@@ -1320,6 +1575,7 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
       }
     }
     count(hi, true);
+    }
     for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = ((nkt + chunks_of[t] - 1) / chunks_of[t]) * BK;
   }
   int blocks = 0;
@@ -1404,7 +1660,8 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   bool split3 = pl.prec == 3 && !(pl.flags & TNF_NO_SPLIT_IMAGE);
   for (int i = 0; i < args->n_problems && split3; ++i)
     if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;
-  if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  if (split3 && pl.wide) hipLaunchKernelGGL(gemm_tn3w_group_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, pl);
+  else if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");

@@ -720,7 +720,11 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
         for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD16] = ch_f2bf(col_ok ? out[r] : 0.0f);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD16] = ch_f2h(col_ok ? out[r] : 0.0f);
+        for (int r = 0; r < 16; r += 2) {      // rows CH_KOFF(r), CH_KOFF(r + 1) are consecutive: one packed conversion
+          const unsigned w = ch_f2h2(col_ok ? out[r] : 0.0f, col_ok ? out[r + 1] : 0.0f);
+          ap[CH_KOFF(r) * CH_LD16] = (unsigned short)(w & 0xffffu);
+          ap[CH_KOFF(r + 1) * CH_LD16] = (unsigned short)(w >> 16);
+        }
       }
     } else {
       float* ap = act + r0 * CH_LD + st.act_col0 + col;
@@ -875,7 +879,7 @@ template <int EPI, int MODE>
 __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
                                             const float (&px1)[2][2][16], const float (&bpre)[2], bool tile_bf = false) {
-  constexpr bool ANY16 = MODE == 1 || MODE == 3, X3 = MODE == 2, T16 = MODE == 3;
+  constexpr bool ANY16 = MODE == 1 || MODE == 3 || MODE == 4, X3 = MODE == 2, T16 = MODE == 3 || MODE == 4;
   constexpr bool PF = CH_USES_X1(EPI);
   if constexpr (CH_USES_X2(EPI) && !T16) {
     if (!X3 && st.prec == 0 && nrt == 2 && !(ANY16 && (st.layout & NUDF_CH_STATE16))) {
@@ -958,12 +962,15 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
 // tile holds that type (ChainSmem16, ch_mma16t): no conversion and half the LDS reads in the K loop, 37 KB per 64-point
 // workgroup -> THREE workgroups per CU (168 VGPRs).  Results are bit-identical to MODE 1 (the same values are rounded to the
 // same type, once in the epilogue instead of in every reading wave).
+// MODE 4: the same 16-bit-tile kernel register-allocated for TWO workgroups per CU (201 VGPRs, no spills): the TANGENT
+// sweeps -- two stored operands in, two arrays out per tile, 176 live registers in the epilogue -- spill 54 registers at the
+// 168 of three workgroups and run 1115 instead of 872 us at config 5's shape; every other sweep is faster with three.
 #ifndef NUDF_T16_WGS
-#define NUDF_T16_WGS 3       // A/B build switch: workgroups per CU the 16-bit-tile kernel is register-allocated for
+#define NUDF_T16_WGS 3       // A/B build switch: workgroups per CU MODE 3 is register-allocated for
 #endif
 template <int TM, int MODE>
 __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void mlp_chain_kernel(NudfChain p_arg) {
-  constexpr bool ANY16 = MODE == 1 || MODE == 3, X3 = MODE == 2, T16 = MODE == 3;
+  constexpr bool ANY16 = MODE == 1 || MODE == 3 || MODE == 4, X3 = MODE == 2, T16 = MODE == 3 || MODE == 4;
   // The descriptor is read where it lies, in the kernarg segment: the by-value parameter is otherwise a private copy that
   // the optimiser has to prove away, and once it fails (it did when the 16-bit epilogues grew) all 2 KB go to scratch and
   // every K loop pays vmcnt(0) for it.
@@ -1005,8 +1012,8 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
           w.x = (unsigned)ch_f2bf(val[0]) | ((unsigned)ch_f2bf(val[1]) << 16);
           w.y = (unsigned)ch_f2bf(val[2]) | ((unsigned)ch_f2bf(val[3]) << 16);
         } else {
-          w.x = (unsigned)ch_f2h(val[0]) | ((unsigned)ch_f2h(val[1]) << 16);
-          w.y = (unsigned)ch_f2h(val[2]) | ((unsigned)ch_f2h(val[3]) << 16);
+          w.x = ch_f2h2(val[0], val[1]);
+          w.y = ch_f2h2(val[2], val[3]);
         }
         *reinterpret_cast<uint2*>(sm.act + r * CH_LD16 + c4 * 4) = w;
       } else {
@@ -1186,7 +1193,9 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
         case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
         case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
         case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_TANGENT: ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_TANGENT:     // (MODE 3 never runs a TANGENT chain: the dispatcher sends those to MODE 4)
+          if constexpr (MODE != 3) ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf);
+          break;
         case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
         case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
         case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
@@ -1337,8 +1346,11 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   // tile holds ONE type): the UDF network's four sweeps with the 16-bit head, the colour / NeRF chains.  NUDF_CHAIN_T16=0
   // keeps the fp32-tile kernel (A/B; the two are bit-identical).
   bool t16 = any16 && !roww && nudf_chain_t16_enabled();
-  for (int i = 0; i < p.n_steps && t16; ++i)
+  bool t16_tangent = false;
+  for (int i = 0; i < p.n_steps && t16; ++i) {
     t16 = (p.step[i].prec == 1 || p.step[i].prec == 2) && p.step[i].prec == p.step[0].prec;
+    t16_tangent = t16_tangent || p.step[i].epi == NUDF_CH_TANGENT;
+  }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {
     if (any3) hipLaunchKernelGGL((mlp_chain_kernel<32, 2>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
@@ -1346,6 +1358,7 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
     else hipLaunchKernelGGL((mlp_chain_kernel<32, 0>), dim3((p.P + 31) / 32), dim3(CH_THREADS), 0, st, p);
   } else {
     if (any3) hipLaunchKernelGGL((mlp_chain_kernel<64, 2>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
+    else if (t16 && t16_tangent) hipLaunchKernelGGL((mlp_chain_kernel<64, 4>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
     else if (t16) hipLaunchKernelGGL((mlp_chain_kernel<64, 3>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
     else if (any16) hipLaunchKernelGGL((mlp_chain_kernel<64, 1>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);
     else hipLaunchKernelGGL((mlp_chain_kernel<64, 0>), dim3((p.P + 63) / 64), dim3(CH_THREADS), 0, st, p);

@@ -68,7 +68,16 @@ __device__ __forceinline__ float ch_pe(const float* x3, const float* v3, int c, 
 // the PE of a 64-point tile took 46 k cycles, 6 % of a forward sweep).  Same arguments 2^k x, same libm kernels.
 // TFMT: element type of the LDS tile -- 0 fp32 (row stride CH_LD floats), 1 fp16, 2 bf16 (row stride CH_LD16 halfwords: the
 // 16-bit-tile chain kernel, whose tile IS the MFMA operand)
-__device__ __forceinline__ unsigned short ch_f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+// fp32 -> fp16 for the 16-bit tile.  The fp32-tile kernel converts its operands with v_cvt_pk_f16_f32 (what hipcc emits for a
+// vector fptrunc on gfx950); a scalar `(_Float16)x` becomes v_cvt_f16_f32, which treats fp16 DENORMAL results differently
+// (measured: softplus outputs below 6.1e-5 made 0.3 % of the points differ between the two kernels).  The packed instruction
+// is named here so that both kernels round every value the same way.
+__device__ __forceinline__ unsigned ch_f2h2(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned short ch_f2h(float x) { return (unsigned short)(ch_f2h2(x, 0.0f) & 0xffffu); }
 template <int NTHR>
 __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, const float* vs, int rows, int tid,
                                                  const NudfChain& p, int m0, int col0, float scale, float* gdst,

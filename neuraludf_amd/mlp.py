@@ -361,7 +361,7 @@ class ChainBuilder:
             if mode == 1 and not t32 and os.environ.get("NUDF_CHAIN_T16", "1") != "0":
                 precs = {int(self.c.step[i].prec) for i in range(self.n)}
                 if len(precs) == 1 and precs <= {1, 2}:
-                    mode = 3           # the 16-bit-tile kernel (one operand type in every step)
+                    mode = 4 if "TANGENT" in e else 3      # the 16-bit-tile kernel (one operand type in every step)
             kern = "mlp_chain_kernel<%d, %d>" % (32 if t32 else 64, mode)
         sweep = ("tangent" if "TANGENT" in e else "adjoint" if "BWD" in e else "input-gradient" if "MULSP" in e
                  else "relu-backward" if e & {"MULMASK", "ADDMASK"} else "udf-forward" if "SOFTPLUS" in e

@@ -40,9 +40,10 @@ def test_clean_step_leaves_the_word_zero_and_planted_nans_set_the_bits():
         tr.var.variance.copy_(good)
     tr.loss(batch)
     assert tr.renderer.status() == 0
-    # (b) a NaN in the colour network: NaN colours -> the rays' composited colours and the loss
+    # (b) a NaN in the colour head (a NaN in a HIDDEN ReLU layer is swallowed by relu = max(x, 0), a hardware max): NaN base
+    # colours -> the rays' composited colours and the loss
     with torch.no_grad():
-        tr.color.lin_base0.bias.fill_(float("nan"))
+        tr.color.lin_base4.bias.fill_(float("nan"))
     loss, out = tr.loss(batch)
     assert not bool(torch.isfinite(out["color_base"]).any()) and not bool(torch.isfinite(loss))
     bits = tr.renderer.status()
@@ -91,7 +92,7 @@ def test_a_replayed_graph_keeps_reporting():
     assert g.replays >= 2
     assert tr.renderer.status() == 0
     with torch.no_grad():
-        tr.color.lin_base0.bias.fill_(float("nan"))
+        tr.color.lin_base4.bias.fill_(float("nan"))
     g(batch)
     bits = tr.renderer.status(clear=True)
     assert bits & _lib.STATUS_NONFINITE_RENDER and bits & _lib.STATUS_NONFINITE_LOSS, bits
