@@ -394,13 +394,14 @@ def tn_can_assign():
     return TN_ASSIGN and TN_DETERMINISTIC and not (int(os.environ.get("NUDF_TN_FLAGS", "0")) & (8 | 2))
 
 
-def gemm_tn_grouped(jobs, M, assign=False):
+def gemm_tn_grouped(jobs, M, assign=False, rows_per_block=0):
     """jobs: [(A1 [M, lda], NA, B1 [M, ldb], NB, C [NA_pad, ldc], dbias | None)] -> one launch per <= 12 problems.
-    assign: C / dbias are assigned, not accumulated into (every C must then appear in ONE job; see `alloc_grads`)."""
+    assign: C / dbias are assigned, not accumulated into (every C must then appear in ONE job; see `alloc_grads`).
+    rows_per_block: 0 = the library chooses the row chunks (tests pin them to compare kernels bit for bit)."""
     for base in range(0, len(jobs), _lib.TN_MAX_PROBLEMS):
         chunk = jobs[base:base + _lib.TN_MAX_PROBLEMS]
         g = _lib.GemmTNGroup()
-        g.n_problems, g.M, g.rows_per_block = len(chunk), M, 0
+        g.n_problems, g.M, g.rows_per_block = len(chunk), M, rows_per_block
         g.prec = _tn_prec()                            # mixed16: bf16 operands for the weight gradients as well
         flops = nbytes = 0.0
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):

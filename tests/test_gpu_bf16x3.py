@@ -138,6 +138,48 @@ def test_weight_gradient_gemm_against_float64(dev, M):
         assert b3 <= 3e-6 and b3g <= 3e-6 and b32 <= 3e-6, (b32, b3, b3g)
 
 
+@pytest.mark.parametrize("M,rpb", [(8192, 1024), (5000, 640)])
+def test_wide_weight_gradient_kernel_equals_the_128x128_kernel_bit_for_bit(dev, M, rpb):
+    """gemm_tn3w_group_kernel (one 8-wave workgroup per pair of vertically adjacent 128 x 128 tiles, double-buffered split
+    image, the two waves of a SIMD running the halves of a k-step in opposite order) against gemm_tn3_group_kernel
+    (NUDF_TN_FLAGS bit 1024) on the SAME row chunks: same k-steps, same MFMA order per accumulator, same workspace slots and
+    reduce -> identical C and dbias, for paired tiles, unpaired ones (NA <= 128, a ragged second tile row) and a ragged last
+    k-step."""
+    from neuraludf_amd import mlp, _lib
+    g = torch.Generator().manual_seed(7)
+    shapes = [(256, 256), (217, 256), (256, 40), (3, 128), (129, 72), (1, 256), (256, 224)]
+    ops = []
+    for NA, NB in shapes:
+        lda, ldb = (NA + 3) // 4 * 4, (NB + 3) // 4 * 4
+        ops.append(((torch.randn(M, lda, generator=g) * torch.exp(torch.randn(1, lda, generator=g))).to(dev),
+                    torch.randn(M, ldb, generator=g).to(dev), NA, NB))
+    base = mlp.PRECISION
+
+    def run(flags, assign):
+        old = _lib.lib().nudf_set_tn_flags(flags)
+        try:
+            fill = torch.empty if assign else torch.zeros
+            jobs = [(A, NA, B, NB, fill(mlp.pad32(NA), B.shape[1], device=dev), fill(mlp.pad32(NA), device=dev))
+                    for A, B, NA, NB in ops]
+            mlp.gemm_tn_grouped(jobs, M, assign=assign, rows_per_block=rpb)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().nudf_set_tn_flags(old)
+        return [(j[4][:NA, :NB].clone(), j[5][:NA].clone()) for j, (A, B, NA, NB) in zip(jobs, ops)]
+
+    try:
+        mlp.set_precision("bf16x3")
+        for assign in (False, True):
+            wide, narrow = run(0, assign), run(1024, assign)
+            for (cw, bw), (cn, bn), (A, B, NA, NB) in zip(wide, narrow, ops):
+                assert torch.equal(cw, cn), (NA, NB, assign, float((cw - cn).abs().max()))
+                assert torch.equal(bw, bn), (NA, NB, assign)
+                ref = A[:, :NA].double().t() @ B[:, :NB].double()
+                assert _err(cw, ref) < 2e-6
+    finally:
+        mlp.set_precision(base)
+
+
 def test_packed_weight_planes_sum_to_the_weight_bit_for_bit(dev):
     """NudfPackFrag.dtype 3: the three bf16 planes of a fragment-ordered weight copy add up to the fp32 weight exactly."""
     from neuraludf_amd import mlp
