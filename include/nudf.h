@@ -152,8 +152,10 @@ int nudf_gemm_tn_grouped_plan(const NudfGemmTNGroup* args, int32_t* out, int cap
  * the bias sums, 8 = ignore the workspace (atomics), 16 = equal row chunks for every tile instead of the cost-weighted
  * split, 32 = no 2 x 2 quadrant layout for full tiles, 64 = tile-major workgroup order instead of the XCD-aware one,
  * 128 = full fp32 tiles through the generic k-loop instead of the interleaved one, 256 = 16-bit MFMA mode (prec != 0)
- * through the generic kernel's fp32 LDS image instead of the packed k-pair image (bit-identical C either way).
- * Default 0 (env NUDF_TN_FLAGS). */
+ * through the generic kernel's fp32 LDS image instead of the packed k-pair image (bit-identical C either way), 512 = bf16x3
+ * mode through the generic kernel (split on the way out of the fp32 image), 1024 = bf16x3 mode through the WIDE kernel (one
+ * 8-wave workgroup per pair of vertically adjacent tiles, double-buffered split image; bit-identical on equal row chunks,
+ * measured slower: opt-in).  Default 0 (env NUDF_TN_FLAGS). */
 int nudf_set_tn_flags(int flags);
 /* tuning only: device buffer of >= 4 int64 per workgroup receiving {start, end} (wall_clock64, 100 MHz), tile layout * 16
  * + live sub-tiles per wave | CU identity (HW_ID [15:8] << 8, XCC_ID << 32), k-steps | shader-clock ticks of the same

@@ -45,7 +45,9 @@
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 #define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
 #define TNF_NO_SPLIT_IMAGE 512      // bf16x3 mode through the generic kernel (split on the way out of the fp32 image; A/B of gemm_tn3_group_kernel)
-#define TNF_NO_WIDE 1024            // bf16x3 mode: the 128 x 128 two-barrier kernel instead of the wide double-buffered one (A/B; bit-identical)
+#define TNF_WIDE 1024               // bf16x3 mode: the wide double-buffered kernel (gemm_tn3w_group_kernel) instead of the 128 x 128
+                                    // two-barrier one -- opt-in: bit-identical on equal row chunks, measured 8-12 % SLOWER
+                                    // (profiles/r05_tn_wide.txt)
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -70,6 +72,11 @@ struct TnPlan {
                                    // -2 = follower (its workgroups exit: the leader's workgroup computes both tiles)
   int assign;                      // reduce kernel: C = 0 + sum instead of C += sum
   int wide;                        // the wide bf16x3 kernel runs this plan (partner[] is set)
+  short unit_tile[TN_MAX_TILES];   // wide kernel: workgroup unit u = the leader (or unpaired) tile unit_tile[u] ...
+  int n_units, unit_chunks;        // ... and its row chunks: blockIdx = u * unit_chunks + chunk.  n_units * unit_chunks <= 256
+                                   // workgroups, one per CU and 32 per XCD whatever the chunk count (the 128 x 128 kernels'
+                                   // XCD-aware order puts a chunk's tiles on ONE XCD: 13 chunks x 19 units would load five
+                                   // XCDs with 38 one-per-CU workgroups and three with 19 -- two rounds, measured 2x slower)
   float* ws;
   long long* dbg;                  // tuning: per workgroup {start, end} of wall_clock64 (100 MHz), layout, n
 };
@@ -1175,28 +1182,34 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
 }
 
 // =======================================================================================================
-// bf16x3 mode, WIDE form (round 5): one 8-wave workgroup per CU computes TWO vertically adjacent 128 x 128 tiles of a problem
-// -- a 256 x 128 block: 25 % less operand traffic per flop than two 128 x 128 workgroups (the B panel is staged once) -- from a
-// DOUBLE-BUFFERED split image (2 x 72 KB), so a k-step has ONE barrier: step kt's MFMAs read buffer kt & 1 while step kt + 1
-// is split into the other one.  The two waves of every SIMD run the two halves of a step in OPPOSITE order -- waves 0..3
-// multiply first and stage afterwards, waves 4..7 stage first and multiply afterwards (both orders are legal between the
-// same two barriers: the staged rows were requested two steps ago and the target buffer was last read before the previous
-// barrier) -- so one wave's split / LDS stores run beside its partner's 48 MFMAs instead of both waves leaving the matrix
-// pipe idle together (what the two-barrier 128 x 128 kernel does: 36 % MFMA-busy).
-// Same 32-row k-steps, same row chunks, same MFMA order per accumulator, same workspace slots (a wave's 64 x 64 quadrant is
-// written where the 128 x 128 kernel's wave writes it) and the same fixed-order reduce: C and dbias are BIT-IDENTICAL to
-// gemm_tn3_group_kernel's (tests/test_gpu_bf16x3.py).  The plan keeps its 128 x 128 tiles; TnPlan.partner pairs them, the
-// workgroups of a follower tile exit at once.
+// bf16x3 mode, WIDE form (round 5; OPT-IN through NUDF_TN_FLAGS bit 1024 -- it measured slower): one
+// 8-wave workgroup per CU computes TWO vertically adjacent 128 x 128 tiles of a problem -- a 256 x 128 block: 25 % less
+// operand traffic per flop than two 128 x 128 workgroups (the B panel is staged once) -- from a DOUBLE-BUFFERED split image
+// (2 x 72 KB), so a k-step has ONE barrier: step kt's MFMAs read buffer kt & 1 while step kt + 1 is split into the other one.
+// The two waves of every SIMD run the two halves of a step in OPPOSITE order -- waves 0..3 multiply first and stage
+// afterwards, waves 4..7 stage first and multiply afterwards (both orders are legal between the same two barriers) -- so that
+// one wave's split / LDS stores run beside its partner's 48 MFMAs.
+// Same 32-row k-steps, same MFMA order per accumulator, same workspace slots (a wave's 64 x 64 quadrant is written where the
+// 128 x 128 kernel's wave writes it) and the same fixed-order reduce: on equal row chunks C and dbias are BIT-IDENTICAL to
+// gemm_tn3_group_kernel's (tests/test_gpu_bf16x3.py).  The plan keeps its 128 x 128 tiles; TnPlan.partner pairs them and
+// TnPlan.unit_tile enumerates the workgroups.
+// MEASURED (profiles/r05_tn_wide.txt): 511-541 us against 467-495 us for the UDF adjoint group at 65 536 points.  Per k-step
+// and wave (nudf_set_tn_debug, shader-clock ticks): MFMA segment 1.8-2.1 k (48 MFMAs = 1.5 k of pipe), split + LDS stores
+// 2.0-3.3 k, load issue 0.8-1.7 k, barrier wait 1.1-3.1 k = 8.1 k per step where the pipe needs 3.1 k -- the staging of a
+// step (24 four-byte loads with clamped 64-bit addresses, 12 pair splits of 11 VALU operations, 9 LDS stores per thread) costs
+// a wave more issue time than its 48 MFMAs, and two such waves per SIMD do not hide each other's; the 128 x 128 kernel's two
+// independent workgroups per CU interleave better than one barrier domain of eight waves.  What would move both kernels is
+// less staging work per MFMA (a 256 x 256 block per workgroup needs 128 accumulator registers per wave: no room beside the
+// staging sets), not a different overlap of the same work.
 // =======================================================================================================
 #define T3WA (4 * 256 * 4)   // dwords per plane of the A image [k-pair group 4][column 256][4]
 #define T3WB (4 * 128 * 4)   // ... of the B image
 #define T3W_BUF (3 * T3WA + 3 * T3WB)
 __global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
   __shared__ __attribute__((aligned(16))) unsigned smem_w[2 * T3W_BUF];   // 144 KB: one workgroup per CU
-  int t, chunk;
-  tn_decode(g, t, chunk);
+  const int t = g.unit_tile[blockIdx.x / g.unit_chunks];
+  const int chunk = blockIdx.x % g.unit_chunks;
   const int partner = g.partner[t];
-  if (partner == -2) return;                      // follower tile: computed by its leader's workgroup
   const TnTile tl = g.tile[t];
   const NudfGemmTNProblem& q = g.prob[tl.prob];
   const bool two = partner >= 0;
@@ -1275,19 +1288,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
     *reinterpret_cast<u32x4*>(dst + T3WB) = mq;
     *reinterpret_cast<u32x4*>(dst + 2 * T3WB) = lq;
   };
+  // one k-step of MFMAs: the 12 operand fragments of the SECOND group of 16 rows are requested before the first group's 24
+  // MFMAs (two register sets), so only the first group's LDS latency is exposed per step
   auto mma = [&](const unsigned* img) {
     const unsigned* as = img + ((lane >> 5) * 256 + (wave >> 1) * 64 + (lane & 31)) * 4;
     const unsigned* bs = img + 3 * T3WA + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
-#pragma unroll
-    for (int kk = 0; kk < BK3 / 16; ++kk) {
-      u32x4 a[2][3], b[2][3];
+    u32x4 fa[2][2][3], fb[2][2][3];
+    auto ldf = [&](int kk) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          a[s2][pl] = *reinterpret_cast<const u32x4*>(as + pl * T3WA + (2 * kk) * 1024 + 128 * s2);
-          b[s2][pl] = *reinterpret_cast<const u32x4*>(bs + pl * T3WB + (2 * kk) * 512 + 128 * s2);
+          fa[kk][s2][pl] = *reinterpret_cast<const u32x4*>(as + pl * T3WA + (2 * kk) * 1024 + 128 * s2);
+          fb[kk][s2][pl] = *reinterpret_cast<const u32x4*>(bs + pl * T3WB + (2 * kk) * 512 + 128 * s2);
         }
+    };
+    ldf(0);
+#pragma unroll
+    for (int kk = 0; kk < BK3 / 16; ++kk) {
+      if (kk + 1 < BK3 / 16) ldf(kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 6; ++tt) {
         const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
@@ -1296,9 +1316,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][qa]),
-                                                                     __builtin_bit_cast(bf16x8, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kk][i][qa]),
+                                                                     __builtin_bit_cast(bf16x8, fb[kk][j][qb]), acc[i * 2 + j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   unsigned* buf0 = smem_w;
@@ -1314,38 +1335,71 @@ __global__ __launch_bounds__(512, 1) void gemm_tn3w_group_kernel(TnPlan g) {
     store_a(sa, 0, buf0);
     store_b(sb, 0, buf0);
   }
-  __syncthreads();
   const bool mma_first = wave < 4;
+  // tuning (nudf_set_tn_debug): shader-clock ticks this wave spent in its three segments and waiting at the barrier
+  long long tk_mma = 0, tk_store = 0, tk_load = 0, tk_bar = 0;
+  const bool prof = g.dbg != nullptr;
+  const long long tk_begin = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#define TNW_STAMP(acc_) if (prof) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); acc_ += n_ - tk_last; tk_last = n_; }
+  if (!mma_first && nk > 2) {     // the staging-first waves run one request further ahead (see kstep)
+    load_a(sa, 2);
+    load_b(sb, 2);
+  }
+  __syncthreads();
   auto kstep = [&](int kt, float (&la)[16], float (&lb)[8], float (&ua)[16], float (&ub)[8], const unsigned* cur, unsigned* nxt) {
-    // la / lb: free staging set, receives step kt + 2; ua / ub: holds step kt + 1, split into `nxt` during this step
-    if (kt + 2 < nk) {
-      load_a(la, kt + 2);
-      load_b(lb, kt + 2);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    // la / lb: free staging set, receives step kt + 2; ua / ub: holds step kt + 1, split into `nxt` during this step.
+    // Matrix-first waves: the rows of step kt + 2 are requested at the top of step kt and split at the END of step kt + 1.
+    long long tk_last = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
     if (mma_first) {
+      if (kt + 2 < nk) {
+        load_a(la, kt + 2);
+        load_b(lb, kt + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      TNW_STAMP(tk_load)
       if (mm_live) mma(cur);
       __builtin_amdgcn_sched_barrier(0);
+      TNW_STAMP(tk_mma)
       if (kt + 1 < nk) {
         store_a(ua, kt + 1, nxt);
         store_b(ub, kt + 1, nxt);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      TNW_STAMP(tk_store)
     } else {
+      // staging-first waves: ua / ub (step kt + 1) is split right away and its registers take the rows of step kt + 3 --
+      // la / lb keep step kt + 2, requested one step ago -- so every request has two whole steps to land here as well
       if (kt + 1 < nk) {
         store_a(ua, kt + 1, nxt);
         store_b(ub, kt + 1, nxt);
       }
       __builtin_amdgcn_sched_barrier(0);
+      TNW_STAMP(tk_store)
+      if (kt + 3 < nk) {
+        load_a(ua, kt + 3);
+        load_b(ub, kt + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      TNW_STAMP(tk_load)
       if (mm_live) mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      TNW_STAMP(tk_mma)
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    TNW_STAMP(tk_bar)
   };
   for (int kt = 0; kt < nk; kt += 2) {
     kstep(kt, sa, sb, sa2, sb2, buf0, buf1);
     if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb, buf1, buf0);
   }
 
+#undef TNW_STAMP
+  if (prof && lane == 0 && (wave == 0 || wave == 4)) {   // 8 int64 per workgroup: waves 0 (matrix-first) and 4 (staging-first)
+    long long* d = g.dbg + 8 * (size_t)blockIdx.x + (wave ? 4 : 0);
+    d[0] = ((long long)__builtin_amdgcn_s_memtime() - tk_begin) | ((long long)nk << 40);
+    d[1] = tk_mma; d[2] = tk_store | (tk_load << 32); d[3] = tk_bar;
+  }
   if (g.flags & TNF_NO_EPILOGUE) return;
   const int tsel = wave >> 2;                                   // which tile of the pair this wave's quadrant belongs to
   const int vw = 2 * ((wave >> 1) & 1) + (wave & 1);            // its wave id in the 128 x 128 kernel's quadrant layout
@@ -1502,7 +1556,7 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   int n_units = nt;
   for (int t = 0; t < nt; ++t) pl.partner[t] = -1;
   {
-    bool ok = g.prec == 3 && !(flags & (TNF_NO_SPLIT_IMAGE | TNF_NO_WIDE));
+    bool ok = g.prec == 3 && (flags & TNF_WIDE) && !(flags & TNF_NO_SPLIT_IMAGE);
     for (int i = 0; i < g.n_problems && ok; ++i)
       if (g.prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) ok = false;
     if (ok) {
@@ -1585,6 +1639,14 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   }
   pl.tile[nt].blk_start = blocks;
   pl.tile[nt].gfirst = (short)nt; pl.tile[nt].gn = 1;
+  pl.n_units = 0;
+  pl.unit_chunks = nt > 0 ? pl.tile[1].blk_start - pl.tile[0].blk_start : 1;
+  if (pl.wide) {
+    for (int t = 0; t < nt; ++t) {
+      if (pl.tile[t + 1].blk_start - pl.tile[t].blk_start != pl.unit_chunks) pl.wide = 0;   // (cannot happen: uniform chunks)
+      if (pl.partner[t] != -2) pl.unit_tile[pl.n_units++] = (short)t;
+    }
+  }
   for (int t = 0; t < nt;) {   // tile groups: same problem, same chunking
     int e = t + 1;
     while (e < nt && pl.tile[e].prob == pl.tile[t].prob && pl.tile[e].rows_per_block == pl.tile[t].rows_per_block) ++e;
@@ -1660,7 +1722,8 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   bool split3 = pl.prec == 3 && !(pl.flags & TNF_NO_SPLIT_IMAGE);
   for (int i = 0; i < args->n_problems && split3; ++i)
     if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;
-  if (split3 && pl.wide) hipLaunchKernelGGL(gemm_tn3w_group_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, pl);
+  if (split3 && pl.wide)
+    hipLaunchKernelGGL(gemm_tn3w_group_kernel, dim3(pl.n_units * pl.unit_chunks), dim3(512), 0, (hipStream_t)stream, pl);
   else if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
   else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);

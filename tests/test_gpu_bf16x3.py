@@ -142,7 +142,7 @@ def test_weight_gradient_gemm_against_float64(dev, M):
 def test_wide_weight_gradient_kernel_equals_the_128x128_kernel_bit_for_bit(dev, M, rpb):
     """gemm_tn3w_group_kernel (one 8-wave workgroup per pair of vertically adjacent 128 x 128 tiles, double-buffered split
     image, the two waves of a SIMD running the halves of a k-step in opposite order) against gemm_tn3_group_kernel
-    (NUDF_TN_FLAGS bit 1024) on the SAME row chunks: same k-steps, same MFMA order per accumulator, same workspace slots and
+    (the default; the wide kernel is opt-in, NUDF_TN_FLAGS bit 1024) on the SAME row chunks: same k-steps, same MFMA order per accumulator, same workspace slots and
     reduce -> identical C and dbias, for paired tiles, unpaired ones (NA <= 128, a ragged second tile row) and a ragged last
     k-step."""
     from neuraludf_amd import mlp, _lib
@@ -170,7 +170,7 @@ def test_wide_weight_gradient_kernel_equals_the_128x128_kernel_bit_for_bit(dev, 
     try:
         mlp.set_precision("bf16x3")
         for assign in (False, True):
-            wide, narrow = run(0, assign), run(1024, assign)
+            wide, narrow = run(1024, assign), run(0, assign)
             for (cw, bw), (cn, bn), (A, B, NA, NB) in zip(wide, narrow, ops):
                 assert torch.equal(cw, cn), (NA, NB, assign, float((cw - cn).abs().max()))
                 assert torch.equal(bw, bn), (NA, NB, assign)

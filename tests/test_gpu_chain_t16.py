@@ -37,11 +37,11 @@ def _all_sweeps(dev, P, seed):
     st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
     out.update(udf=st["udf"][:P], sign=st["sign"][:P], feat=st["feat"][:P, :256])
     for l in (1, 4, 5, 8):
-        out[f"X{l}"] = _plain(st["X"][l], P)
+        out[f"X{l}"] = _plain(st["X"][l], P)[:, :eng.layers[l].inp]
     gr, DA = eng.gradient(x, st)
     out["g"] = gr[:P]
     for l in (0, 3, 7):
-        out[f"DA{l}"] = _plain(DA[l], P)
+        out[f"DA{l}"] = _plain(DA[l], P)[:, :eng.layers[l].out]       # (pad columns are never written)
     Pc = (P // S) * S
     cb, cc, logits, cst = ceng.forward(st["feat"], rays_d, S, Pc)
     out.update(cb=cb[:Pc], cc=cc[:Pc])
