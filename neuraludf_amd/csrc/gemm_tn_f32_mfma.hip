@@ -45,6 +45,8 @@
 #define TNF_NO_INTERLEAVE 128       // full fp32 tiles through the generic k-loop (A/B of kloop_full)
 #define TNF_NO_PACK16 256           // 16-bit MFMA mode through the generic kernel's fp32 LDS image (A/B of gemm_tn16_group_kernel)
 #define TNF_NO_SPLIT_IMAGE 512      // bf16x3 mode through the generic kernel (split on the way out of the fp32 image; A/B of gemm_tn3_group_kernel)
+#define TNF_GENERIC_STAGE 2048      // bf16x3 split-image kernel: every k-step through the generic (clamped-address) staging: A/B of the
+                                    // loop-invariant addressing of round 5; bit-identical
 #define TNF_WIDE 1024               // bf16x3 mode: the wide double-buffered kernel (gemm_tn3w_group_kernel) instead of the 128 x 128
                                     // two-barrier one -- opt-in: bit-identical on equal row chunks, measured 8-12 % SLOWER
                                     // (profiles/r05_tn_wide.txt)
@@ -1138,7 +1140,68 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
     }
     __syncthreads();
   };
-  for (int kt = 0; kt < nk; kt += 2) {
+  // ---- steady state (round 5): FULL k-steps with loop-invariant addressing.  The generic `load` forms every address with a
+  // row clamp, a 64-bit multiply-add and a 64-bit shift-add per element (4 VALU operations per 4-byte load, 128 per thread and
+  // step -- as many as the split), and hipcc, recycling those address registers, put an s_waitcnt vmcnt(0) in front of every
+  // step's requests: the "two steps ahead" prefetch waited for the previous step's rows first.  Here a step's rows start at a
+  // wave-uniform base (SGPR pairs formed by the scalar unit) and a thread's only address register is its column offset: a
+  // load is ONE instruction (global_load_dword v, v_col, s[row base]), no vector address arithmetic, nothing to wait for; full
+  // steps also need no row-validity selects in the split.  Same values, same order: C and dbias are unchanged bit for bit.
+  int kt0 = 0;
+  if (!(g.flags & TNF_GENERIC_STAGE)) {
+    const bool last_ragged = ((mend - mbeg) % BK3) != 0 || mend > g.M;
+    const int n_fast = nk - 2 - (last_ragged ? 1 : 0);          // steps kt with kt + 1 and kt + 2 full and inside the chunk
+    if (n_fast >= 2) {
+      // (16 sg is wave-uniform: waves 0-1 stage rows 0..15 of a step, waves 2-3 rows 16..31)
+      const int sgu = __builtin_amdgcn_readfirstlane(sg);
+      const unsigned ca = (unsigned)min(i0 + sc, q.lda1 - 1), cbb = (unsigned)min(j0 + sc, q.ldb1 - 1);
+      auto load_f = [&](const float* __restrict__ base, size_t ld, unsigned col, float (&st)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = (base + (size_t)r * ld)[col];     // scalar row base + one 32-bit lane offset
+      };
+      auto store_f = [&](const float (&st)[16], unsigned* tile, bool bias) {
+        u32x4 hq[2], mq[2], lq[2];
+        float ps[8];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+          unsigned a, b, d;
+          tn_split3_pair(st[2 * pp], st[2 * pp + 1], a, b, d);
+          hq[pp >> 2][pp & 3] = a; mq[pp >> 2][pp & 3] = b; lq[pp >> 2][pp & 3] = d;
+          ps[pp] = st[2 * pp] + st[2 * pp + 1];
+        }
+        if (bias) bias_acc += ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+        unsigned* dst = tile + ((2 * sg) * 128 + sc) * 4;
+        *reinterpret_cast<u32x4*>(dst) = hq[0];
+        *reinterpret_cast<u32x4*>(dst + 512) = hq[1];
+        *reinterpret_cast<u32x4*>(dst + T3Q) = mq[0];
+        *reinterpret_cast<u32x4*>(dst + T3Q + 512) = mq[1];
+        *reinterpret_cast<u32x4*>(dst + 2 * T3Q) = lq[0];
+        *reinterpret_cast<u32x4*>(dst + 2 * T3Q + 512) = lq[1];
+      };
+      // uniform bases of the rows of step kt + 2 (scalar registers; the readfirstlane only tells the compiler so)
+      const float* ba = q.A1 + (size_t)(mbeg + 2 * BK3 + 16 * sgu) * lda;
+      const float* bb = q.B1 + (size_t)(mbeg + 2 * BK3 + 16 * sgu) * ldb;
+      const size_t sa_step = (size_t)BK3 * lda, sb_step = (size_t)BK3 * ldb;
+      auto fstep = [&](float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+        load_f(ba, lda, ca, la);
+        load_f(bb, ldb, cbb, lb);
+        ba += sa_step;
+        bb += sb_step;
+        __builtin_amdgcn_sched_barrier(0);
+        mma();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        store_f(ua, As, do_bias);
+        store_f(ub, Bs, false);
+        __syncthreads();
+      };
+      for (; kt0 + 1 < n_fast; kt0 += 2) {
+        fstep(sa, sb, sa2, sb2);
+        fstep(sa2, sb2, sa, sb);
+      }
+    }
+  }
+  for (int kt = kt0; kt < nk; kt += 2) {
     kstep(kt, sa, sb, sa2, sb2);
     if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb);
   }
