@@ -1054,6 +1054,19 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
     for (unsigned d = 0; d < k; ++d) __builtin_amdgcn_s_sleep(127);
   }
 
+#ifdef NUDF_X3_CU_STAGGER   // experiment (profiles/r05_chain_cu_stagger.txt): de-phase the CUs against each other so that the
+  // epilogue phases (HBM) of one half of the chip fall into the K-loop phases (no HBM traffic) of the other half
+  if (X3 && gridDim.x > 256) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((8 << 11) | (8 << 6) | 4);      // HW_REG_HW_ID bits [15:8]: cu_id, sh_id, se_id
+#if NUDF_X3_CU_STAGGER > 0
+    const unsigned late = hw & 1u;                                                // odd CUs
+    for (int d = 0; d < (int)late * NUDF_X3_CU_STAGGER; ++d) __builtin_amdgcn_s_sleep(127);
+#else
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
+    for (int d = 0; d < (int)(xcc & 1u) * (-NUDF_X3_CU_STAGGER); ++d) __builtin_amdgcn_s_sleep(127);
+#endif
+  }
+#endif
   unsigned long long* dbg = p.dbg ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 64 : nullptr;
   if (dbg && lane == 0) {
     dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
