@@ -388,6 +388,41 @@ int nudf_patch_metric(int type, const float* pred, const float* gt, const float*
                       const float* d_out, float* d_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The BLENDING step's loss (BASELINE config 3) in three launches around the caller's sort: ColorLoss with its pixel and
+ * trimmed patch terms (loss/loss.py:105-133, :21-44, :66-84), the patch-mask algebra of the runner
+ * (exp_runner_blending.py:313-315), the three regularisers from the composite sums and the weighted total (:330-371).
+ *   nudf_blend_loss_prepare: m[i] = ((patch_mask[i] * (weight_sum[i] > 0.5)) > 0) as 0 / 1, err_masked[i] = err[i] m[i]
+ *   caller: err_sorted, order = sort(err_masked, descending)   (the trimmed mean needs order statistics)
+ *   nudf_blend_loss_fwd:     out[12] = {total, colour total, Lb, Lc, Lpix, Lpatch, gradient_error, gradient_error_near_surface,
+ *                            sparse_error, den_pix, k = floor(trim_ratio * sum m), kept count}
+ *   nudf_blend_loss_bwd:     d cb, d c, d pix [3 N], d err [N] (through the sort's permutation), d sums [5]
+ * The weights are read from the device vector w_dev (NUDF_LW_*).  ORs NUDF_STATUS_NONFINITE_LOSS like nudf_step_loss_fwd.
+ * ---------------------------------------------------------------------------------- */
+typedef struct NudfBlendLoss {
+  const float* cb; const float* c; const float* pix; const float* gt;   /* [N,3]                                     */
+  const float* err;            /* [N] per-ray patch error (nudf_patch_metric)                                        */
+  const float* patch_mask;     /* [N] the renderer's patch validity weight (render result 'patch_mask')              */
+  const float* weight_sum;     /* [N]                                                                                */
+  const float* err_sorted;     /* [N] descending sort of err_masked (fwd / bwd)                                      */
+  const int64_t* order;        /* [N] its permutation                                                                */
+  float* m;                    /* [N] prepare: out; fwd / bwd: in                                                     */
+  float* err_masked;           /* [N] prepare: out                                                                   */
+  float* sums;                 /* [5] composite sums: read -- or, with sums_ws, reduced here and written              */
+  const float* sums_ws;        /* NULL, or the composite launch's per-block partials (NudfComposite.defer_sums)      */
+  const float* w_dev;          /* [NUDF_LW_COUNT] device                                                             */
+  float* out;                  /* [12] fwd: out; bwd: in                                                             */
+  const float* d_total;        /* bwd: device scalar upstream gradient of out[0] (NULL = 1)                          */
+  float* d_cb; float* d_c; float* d_pix;   /* [N,3] bwd out                                                          */
+  float* d_err;                /* [N] bwd out (every entry written)                                                  */
+  float* d_sums;               /* [5] bwd out                                                                        */
+  int32_t N, sums_nblk;
+  float n_rays, trim_ratio;
+} NudfBlendLoss;
+int nudf_blend_loss_prepare(const NudfBlendLoss* args, void* stream);
+int nudf_blend_loss_fwd(const NudfBlendLoss* args, void* stream);
+int nudf_blend_loss_bwd(const NudfBlendLoss* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * ray sampling helpers (models/udf_renderer_blending.py:605-630, 352-357, 164-173, 205)
  * ---------------------------------------------------------------------------------- */
 int nudf_coarse_z(const float* near, const float* far, int nf_stride, const float* t_rand, int N, int S,

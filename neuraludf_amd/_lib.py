@@ -50,6 +50,14 @@ class GemmTNGroup(C.Structure):
                 ("assign", i32)]
 
 
+class BlendLoss(C.Structure):
+    _fields_ = [("cb", c_fp), ("c", c_fp), ("pix", c_fp), ("gt", c_fp), ("err", c_fp), ("patch_mask", c_fp),
+                ("weight_sum", c_fp), ("err_sorted", c_fp), ("order", c_fp), ("m", c_fp), ("err_masked", c_fp), ("sums", c_fp),
+                ("sums_ws", c_fp), ("w_dev", c_fp), ("out", c_fp), ("d_total", c_fp), ("d_cb", c_fp), ("d_c", c_fp),
+                ("d_pix", c_fp), ("d_err", c_fp), ("d_sums", c_fp), ("N", i32), ("sums_nblk", i32), ("n_rays", f32),
+                ("trim_ratio", f32)]
+
+
 class RayBatch(C.Structure):
     _fields_ = [("image", c_fp), ("mask", c_fp), ("intrinsics_inv", c_fp), ("pose", c_fp), ("pixels_x", c_fp),
                 ("pixels_y", c_fp), ("N", i32), ("H", i32), ("W", i32), ("h_patch_size", i32), ("rays", c_fp),
@@ -202,6 +210,7 @@ SYMBOLS = [
     "nudf_sums_errors_fwd", "nudf_sums_errors_bwd", "nudf_color_loss_fwd", "nudf_color_loss_bwd",
     "nudf_gen_ray_batch", "nudf_color_loss_sums", "nudf_color_loss_finish",
     "nudf_step_loss_fwd", "nudf_step_loss_bwd", "nudf_col0_seed4",
+    "nudf_blend_loss_prepare", "nudf_blend_loss_fwd", "nudf_blend_loss_bwd",
 ]
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
@@ -263,6 +272,9 @@ _ARGTYPES = {
     "nudf_step_loss_fwd": [_P, _P, _P, _I, _P, _I, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _P],
     "nudf_step_loss_bwd": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "nudf_col0_seed4": [_P, _P, _F, _I, _I, _P, _P, _P],
+    "nudf_blend_loss_prepare": [C.POINTER(BlendLoss), _P],
+    "nudf_blend_loss_fwd": [C.POINTER(BlendLoss), _P],
+    "nudf_blend_loss_bwd": [C.POINTER(BlendLoss), _P],
 }
 
 _lib = None

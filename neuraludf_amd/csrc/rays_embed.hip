@@ -1067,3 +1067,160 @@ extern "C" int nudf_col0_seed4(const float* sign, const float* d, float scale, i
   NUDF_CHECK_LAUNCH("nudf_col0_seed4");
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The BLENDING step's loss in three launches around torch's sort (BASELINE config 3: ColorLoss with the pixel and the trimmed
+// patch term, loss/loss.py:105-133, :66-84, the patch-mask algebra of exp_runner_blending.py:313-315, the three regularisers
+// and the runner's weighted total, :330-371).  The generic path is ~90 one-element / per-ray torch launches of ~4.7 us each
+// between the two patch-blend kernels (profiles/r04_step_sequence_garment_blend.txt).
+//   prepare : m[i] = ((patch_mask[i] * (weight_sum[i] > 0.5)) > 0), err_masked[i] = err[i] * m[i]
+//   (torch.sort(err_masked, descending=True) -> err_sorted, order: the trimmed mean needs order statistics)
+//   fwd     : out[12] = {total, cl, Lb, Lc, Lpix, Lpatch, ge, gens, sparse, den_pix, k, keep_sum}
+//   bwd     : d cb, d c, d pix [3 N], d err [N], d sums [5]
+// Every product / sum of the weighted totals is rounded on its own, as the chain of 0-d torch ops rounds them.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void blend_loss_prepare_kernel(NudfBlendLoss p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.N) return;
+  const float mk = (p.patch_mask[i] * ((p.weight_sum[i] > 0.5f) ? 1.0f : 0.0f)) > 0.0f ? 1.0f : 0.0f;
+  p.m[i] = mk;
+  p.err_masked[i] = p.err[i] * mk;
+}
+extern "C" int nudf_blend_loss_prepare(const NudfBlendLoss* args, void* stream) {
+  if (args->N <= 0) return 0;
+  hipLaunchKernelGGL(blend_loss_prepare_kernel, dim3(nblocks(args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+  NUDF_CHECK_LAUNCH("nudf_blend_loss_prepare");
+  return 0;
+}
+
+__global__ __launch_bounds__(1024) void blend_loss_fwd_kernel(NudfBlendLoss p, int32_t* status) {
+  __shared__ float red[8][16];
+  __shared__ float s5[5];
+  __shared__ float tot[8];
+  const int tid = threadIdx.x;
+  if (p.sums_ws) {      // the composite launch left its per-block partials: partial_sums_kernel's reduction, same order
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = tid; b < p.sums_nblk; b += 1024) {
+      const float* row = p.sums_ws + (size_t)b * 5;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc[k] += row[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float t = wave_sum(acc[k]);
+      if ((tid & 63) == 0) red[k][tid >> 6] = t;
+    }
+    __syncthreads();
+    if (tid < 5) {
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += red[tid][w];
+      p.sums[tid] = t;
+      s5[tid] = t;
+    }
+    __syncthreads();
+  }
+  const float* sv = p.sums_ws ? s5 : p.sums;
+  // pass 1: the three L1 sums and the mask count
+  float sb = 0.f, sc = 0.f, sp = 0.f, cnt = 0.f;
+  const int n3 = 3 * p.N;
+  for (int i = tid; i < n3; i += 1024) {
+    const float g = p.gt[i];
+    sb += fabsf(p.cb[i] - g);
+    sc += fabsf(p.c[i] - g);
+    sp += fabsf(p.pix[i] - g);
+  }
+  for (int i = tid; i < p.N; i += 1024) cnt += p.m[i];
+  sb = wave_sum(sb); sc = wave_sum(sc); sp = wave_sum(sp); cnt = wave_sum(cnt);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sb; red[1][tid >> 6] = sc; red[2][tid >> 6] = sp; red[3][tid >> 6] = cnt; }
+  __syncthreads();
+  if (tid < 4) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[tid][w];
+    tot[tid] = t;
+  }
+  __syncthreads();
+  // pass 2: trimmed mean over the descending-sorted masked errors: the first k = floor(ratio * count) positions lose their
+  // mask (loss/loss.py:79-84), mean of the errors still masked
+  const float kf = floorf(p.trim_ratio * tot[3]);
+  float es = 0.f, ks = 0.f;
+  for (int j = tid; j < p.N; j += 1024) {
+    const float keep = (p.m[p.order[j]] > 0.f && (float)j >= kf) ? 1.0f : 0.0f;
+    es += p.err_sorted[j] * keep;
+    ks += keep;
+  }
+  es = wave_sum(es); ks = wave_sum(ks);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[4][tid >> 6] = es; red[5][tid >> 6] = ks; }
+  __syncthreads();
+  if (tid == 0) {
+    float tes = 0.f, tks = 0.f;
+    for (int w = 0; w < 16; ++w) { tes += red[4][w]; tks += red[5][w]; }
+    const float* w = p.w_dev;
+    const float w_b = w[NUDF_LW_COLOR_BASE], w_c = w[NUDF_LW_COLOR], w_px = w[NUDF_LW_COLOR_PIXEL], w_pa = w[NUDF_LW_COLOR_PATCH];
+    const float w_sum = w[NUDF_LW_COLOR_SUM];
+    const float Lb = tot[0] / (float)n3, Lc = tot[1] / (float)n3;
+    const float den_pix = tot[3] + 1e-4f;
+    const float Lpix = tot[2] / den_pix;
+    const float Lpatch = tes / tks;
+    float cl = __fadd_rn(__fadd_rn(__fmul_rn(Lb, w_b), __fmul_rn(Lc, w_c)), __fmul_rn(Lpix, w_px));
+    cl = __fadd_rn(__fdiv_rn(cl, w_sum), __fmul_rn(Lpatch, w_pa));
+    const float ge = sv[0] / (sv[1] + 1e-5f);
+    const float gens = sv[2] / (sv[3] + 1e-5f);
+    const float spr = sv[4] / p.n_rays;
+    float total = __fadd_rn(cl, __fmul_rn(gens, w[NUDF_LW_IGR_NS]));
+    total = __fadd_rn(total, __fmul_rn(spr, w[NUDF_LW_SPARSE]));
+    total = __fadd_rn(total, __fmul_rn(ge, w[NUDF_LW_IGR]));
+    float* o = p.out;
+    o[0] = total; o[1] = cl; o[2] = Lb; o[3] = Lc; o[4] = Lpix; o[5] = Lpatch; o[6] = ge; o[7] = gens; o[8] = spr;
+    o[9] = den_pix; o[10] = kf; o[11] = tks;
+    if (status && !(fabsf(total) <= 3.0e38f)) atomicOr(status, NUDF_STATUS_NONFINITE_LOSS);
+  }
+}
+extern "C" int nudf_blend_loss_fwd(const NudfBlendLoss* args, void* stream) {
+  if (args->N <= 0 || !args->w_dev) {
+    nudf_set_error("nudf_blend_loss_fwd: N >= 1 and the device weight vector required", hipErrorInvalidValue);
+    return (int)hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(blend_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *args, nudf_status_flag());
+  NUDF_CHECK_LAUNCH("nudf_blend_loss_fwd");
+  return 0;
+}
+
+__global__ void blend_loss_bwd_kernel(NudfBlendLoss p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float* w = p.w_dev;
+  const float g = p.d_total ? p.d_total[0] : 1.0f;
+  const float w_sum = w[NUDF_LW_COLOR_SUM];
+  if (i == 0) {
+    const float d_ge = __fmul_rn(g, w[NUDF_LW_IGR]), d_gens = __fmul_rn(g, w[NUDF_LW_IGR_NS]), d_sp = __fmul_rn(g, w[NUDF_LW_SPARSE]);
+    const float a = p.sums[1] + 1e-5f, b = p.sums[3] + 1e-5f;
+    p.d_sums[0] = d_ge / a;
+    p.d_sums[1] = -d_ge * p.sums[0] / (a * a);
+    p.d_sums[2] = d_gens / b;
+    p.d_sums[3] = -d_gens * p.sums[2] / (b * b);
+    p.d_sums[4] = d_sp / p.n_rays;
+  }
+  const int n3 = 3 * p.N;
+  if (i < n3) {
+    const float kb = g * w[NUDF_LW_COLOR_BASE] / w_sum / (float)n3;
+    const float kc = g * w[NUDF_LW_COLOR] / w_sum / (float)n3;
+    const float kp = g * w[NUDF_LW_COLOR_PIXEL] / w_sum / p.out[9];
+    const float t = p.gt[i];
+    const float a = p.cb[i] - t, b = p.c[i] - t, c = p.pix[i] - t;
+    p.d_cb[i] = kb * ((a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f));
+    p.d_c[i] = kc * ((b > 0.f) ? 1.f : ((b < 0.f) ? -1.f : 0.f));
+    p.d_pix[i] = kp * ((c > 0.f) ? 1.f : ((c < 0.f) ? -1.f : 0.f));
+  }
+  if (i < p.N) {      // position i of the sorted list -> ray order[i]: d err = d Lpatch * keep / keep_sum (* m)
+    const long long r = p.order[i];
+    const float keep = (p.m[r] > 0.f && (float)i >= p.out[10]) ? 1.0f : 0.0f;
+    p.d_err[r] = g * w[NUDF_LW_COLOR_PATCH] * keep / p.out[11];
+  }
+}
+extern "C" int nudf_blend_loss_bwd(const NudfBlendLoss* args, void* stream) {
+  if (args->N <= 0) return 0;
+  hipLaunchKernelGGL(blend_loss_bwd_kernel, dim3(nblocks(3 * args->N, 256)), dim3(256), 0, (hipStream_t)stream, *args);
+  NUDF_CHECK_LAUNCH("nudf_blend_loss_bwd");
+  return 0;
+}

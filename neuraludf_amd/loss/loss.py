@@ -59,14 +59,30 @@ class LossWeights:
             return self._own
         # a NEW small device tensor per change (a colour-weight ramp changes the values every iteration): autograd nodes
         # of a loss that has not run its backward yet may still hold views of the previous vector, so it is never
-        # overwritten in place; staged through pinned host memory, so the copy does not stall the host-ahead pipeline
+        # overwritten in place.  Staged through a RING of pinned host slots (as train.StepScalars): the copy does not stall
+        # the host-ahead pipeline, and no pinned block is ever freed -- the host allocator records an event on the stream
+        # when a pinned block dies, which is not permitted while that stream is being captured (a garbage-collection pass
+        # inside GraphedStep._capture hit exactly that).
         import torch as _t
+        dev = _t.device(device)
         h = _t.tensor(vals, dtype=_t.float32, device="cpu")     # (the reference runner makes CUDA the default tensor type)
-        if _t.device(device).type == "cuda":
-            h = h.pin_memory()
-        self._own = h.to(device, non_blocking=True)
-        self._own_host = h            # (keeps the pinned source alive until the copy has run)
-        self._own_vals = vals
+        if dev.type != "cuda":
+            self._own, self._own_vals = h, vals
+            return self._own
+        if getattr(self, "_pins", None) is None:
+            self._pins = [_t.empty(len(vals), dtype=_t.float32, device="cpu").pin_memory() for _ in range(4)]
+            self._pin_ev, self._pin_k = [None] * 4, 0
+        i = self._pin_k % len(self._pins)
+        self._pin_k += 1
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()        # (only ever waits when the host is four weight changes ahead of the GPU)
+        self._pins[i].copy_(h)
+        own = _t.empty(len(vals), dtype=_t.float32, device=dev)
+        own.copy_(self._pins[i], non_blocking=True)
+        ev = _t.cuda.Event()
+        ev.record()
+        self._pin_ev[i] = ev
+        self._own, self._own_vals = own, vals
         return self._own
 
 
@@ -181,6 +197,73 @@ class _StepLossFn(torch.autograd.Function):
         call("nudf_step_loss_bwd", ptr(cb_), ptr(c_), ptr(gt_), cb_.numel(), ptr(den), ptr(sums_), ctx.n_rays,
              0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ptr(w_dev), ptr(d_total), ptr(d_extra), ptr(d_cb), ptr(d_c), ptr(d_sums))
         return (d_cb, d_c, None, None, d_sums, None, None)
+
+
+class _BlendStepLossFn(torch.autograd.Function):
+    """The blending step's whole loss (BASELINE config 3) around ONE torch.sort: ColorLoss with its pixel and trimmed patch
+    terms, the runner's patch-mask algebra, the three regularisers and the weighted total -- nudf_patch_metric +
+    nudf_blend_loss_prepare + sort + nudf_blend_loss_fwd (and nudf_blend_loss_bwd + nudf_patch_metric back) instead of ~90
+    one-element / per-ray torch launches.  -> (total, colour total, Lb, Lc, Lpix, Lpatch, gradient_error,
+    gradient_error_near_surface, sparse_error, patch mask [N] bool).  Same expressions in the same order as the generic path
+    (loss/loss.py:105-133, 21-44, 66-84; exp_runner_blending.py:313-315, 330-371); sums of N terms in this kernel's order."""
+
+    @staticmethod
+    def forward(ctx, cb, c, pix, gt, patch_colors, gt_patch, pm_raw, wsum, sums, n_rays, w_dev, window, kind, ratio):
+        from .._lib import BlendLoss, call, ptr
+        ctx.set_materialize_grads(False)
+        t = lambda x: x.detach().float().contiguous()
+        cb_, c_, pix_, gt_, pc_, gp_ = t(cb), t(c), t(pix), t(gt), t(patch_colors), t(gt_patch)
+        pm_, ws_ = t(pm_raw).reshape(-1), t(wsum).reshape(-1)
+        w_dev = w_dev.detach()
+        dev = cb_.device
+        N, npx = pc_.shape[0], pc_.shape[1]
+        err = torch.empty(N, device=dev)
+        call("nudf_patch_metric", kind, ptr(pc_), ptr(gp_), ptr(window), N, npx, ptr(err), None, None)
+        a = BlendLoss()
+        m, em = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        a.err, a.patch_mask, a.weight_sum, a.m, a.err_masked, a.N = ptr(err), ptr(pm_), ptr(ws_), ptr(m), ptr(em), N
+        call("nudf_blend_loss_prepare", a)
+        es, order = torch.sort(em, descending=True)          # (the same call as ColorPatchLoss.forward: same permutation)
+        pend = getattr(sums, "_nudf_ws", None)
+        if pend is not None:
+            del sums._nudf_ws
+        sums_ = sums.detach()
+        out = torch.empty(12, device=dev)
+        a.cb, a.c, a.pix, a.gt = ptr(cb_), ptr(c_), ptr(pix_), ptr(gt_)
+        a.err_sorted, a.order, a.sums, a.w_dev, a.out = ptr(es), ptr(order), ptr(sums_), ptr(w_dev), ptr(out)
+        if pend is not None:
+            a.sums_ws, a.sums_nblk = ptr(pend[0]), pend[1]
+        a.n_rays, a.trim_ratio = float(n_rays), float(ratio)
+        call("nudf_blend_loss_fwd", a)
+        ctx.save_for_backward(cb_, c_, pix_, gt_, pc_, gp_, m, order, sums_, w_dev, out, window)
+        ctx.meta = (N, npx, kind, float(n_rays), float(ratio))
+        mask = m > 0
+        ctx.mark_non_differentiable(mask)
+        return tuple(out[i] for i in range(9)) + (mask,)
+
+    @staticmethod
+    def backward(ctx, *d):
+        from .._lib import BlendLoss, call, ptr
+        if d[0] is None:
+            return (None,) * 14
+        if any(x is not None for x in d[1:9]):
+            raise NotImplementedError("_BlendStepLossFn: gradients flow through the total only (the other outputs are logged)")
+        cb_, c_, pix_, gt_, pc_, gp_, m, order, sums_, w_dev, out, window = ctx.saved_tensors
+        N, npx, kind, n_rays, ratio = ctx.meta
+        dev = cb_.device
+        a = BlendLoss()
+        a.cb, a.c, a.pix, a.gt, a.m, a.order, a.sums, a.w_dev, a.out = (ptr(cb_), ptr(c_), ptr(pix_), ptr(gt_), ptr(m), ptr(order),
+                                                                           ptr(sums_), ptr(w_dev), ptr(out))
+        a.N, a.n_rays, a.trim_ratio = N, n_rays, ratio
+        d_total = d[0].contiguous()
+        d_cb, d_c, d_pix = torch.empty_like(cb_), torch.empty_like(c_), torch.empty_like(pix_)
+        d_err, d_sums = torch.empty(N, device=dev), torch.empty(5, device=dev)
+        a.d_total, a.d_cb, a.d_c, a.d_pix, a.d_err, a.d_sums = ptr(d_total), ptr(d_cb), ptr(d_c), ptr(d_pix), ptr(d_err), ptr(d_sums)
+        call("nudf_blend_loss_bwd", a)
+        d_pc = torch.empty_like(pc_)
+        scratch = torch.empty(N, device=dev)
+        call("nudf_patch_metric", kind, ptr(pc_), ptr(gp_), ptr(window), N, npx, ptr(scratch), ptr(d_err), ptr(d_pc))
+        return (d_cb, d_c, d_pix, None, d_pc, None, None, None, d_sums, None, None, None, None, None)
 
 
 class _ColorLossFromSumsFn(torch.autograd.Function):
@@ -323,6 +406,23 @@ class ColorLoss(nn.Module):
     def fusable(self, color_base, color, gt_color, color_pixel, patch_colors):
         return (color_base is not None and color is not None and color_pixel is None and patch_colors is None
                 and color.is_cuda and color.dtype == torch.float32 and color.shape == gt_color.shape == color_base.shape)
+
+    def blend_fusable(self, color_base, color, gt_color, color_pixel, pixel_mask, patch_colors, gt_patch_colors):
+        """the blending step's fused loss (_BlendStepLossFn): all four colour terms present, no pixel mask, fp32 on the GPU,
+        single process"""
+        ts = (color_base, color, gt_color, color_pixel, patch_colors, gt_patch_colors)
+        return (all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in ts) and pixel_mask is None
+                and color.shape == gt_color.shape == color_base.shape == color_pixel.shape
+                and patch_colors.shape == gt_patch_colors.shape and not self.patch_func.data_parallel)
+
+    def blend_step_loss(self, color_base, color, gt_color, color_pixel, patch_colors, gt_patch_colors, patch_mask_raw,
+                        weight_sum, sums, n_rays, w_dev):
+        from .patch_metric import PATCH_TYPES, _win_cache, gaussian_window
+        key = (self.h_patch_size, str(color.device))
+        if key not in _win_cache:
+            _win_cache[key] = gaussian_window(self.h_patch_size).to(color.device)
+        return _BlendStepLossFn.apply(color_base, color, color_pixel, gt_color, patch_colors, gt_patch_colors, patch_mask_raw,
+                                      weight_sum, sums, n_rays, w_dev, _win_cache[key], PATCH_TYPES[self.patch_func.type], 0.3)
 
     def local_sums(self, color_base, color, gt_color, pixel_mask):
         """-> [sum|cb-gt|, sum|c-gt|, mask count (or element count)] of the LOCAL rays, no autograd."""

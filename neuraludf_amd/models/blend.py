@@ -136,9 +136,15 @@ class _PatchBlendFn(torch.autograd.Function):
         taps = float(N) * S * V * npx          # the backward recomputes the gathers
         call_timed("patch_blend", "patch_blend_bwd N=%d S=%d V=%d Npx=%d" % (N, S, V, npx), 48.0 * taps, "nudf_patch_blend_bwd", a,
                    ptr(d_pc.contiguous()), ptr(d_logits), ptr(d_ws), units=taps)
-        d_w = torch.zeros_like(w)
-        d_w[:, :S] = d_ws
+        if w.shape[1] == S:                    # no outside samples: the inside weights ARE the weights (no fill + copy)
+            d_w = d_ws
+        else:
+            d_w = torch.zeros_like(w)
+            d_w[:, :S] = d_ws
         return None, None, None, None, d_logits, d_w, None, None, None, None
+
+
+_uv_scale = {}       # (W, H, device) -> [W - 1, H - 1] on the device (filled on the first eager step, before any capture)
 
 
 def patch_cameras(ref_intrinsic, src_intrinsics, ref_c2w, src_c2ws):
@@ -169,8 +175,11 @@ def blend_and_composite(hps, pts, logits, weights, grad, rays_d, color_maps, w2c
     patch_colors = patch_mask = None
     if rays_uv is not None:
         # the reference rescales the caller's uv tensor in place from (-1,1) to pixels (patch_projector.py:75-76)
-        rays_uv[:, 0] = (rays_uv[:, 0] + 1) / 2. * (W - 1)
-        rays_uv[:, 1] = (rays_uv[:, 1] + 1) / 2. * (H - 1)
+        # (the same three roundings per element -- + 1, / 2, * (size - 1) -- on both columns at once: 4 launches, not 8)
+        key = (W, H, str(rays_uv.device))
+        if key not in _uv_scale:
+            _uv_scale[key] = torch.tensor([float(W - 1), float(H - 1)], dtype=torch.float32, device="cpu").to(rays_uv.device)
+        rays_uv.copy_((rays_uv + 1) / 2. * _uv_scale[key])
         ref_cam, src_cam = patch_cams if patch_cams is not None else patch_cameras(intrinsics[0], intrinsics, query_c2w,
                                                                                    torch.inverse(w2cs))
         patch_colors, patch_mask = _PatchBlendFn.apply(pts, grad, rays_d, rays_uv, logits, weights, ref_cam, src_cam,

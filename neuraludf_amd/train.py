@@ -267,6 +267,9 @@ class Trainer:
         self.fuse_loss = not data_parallel
         self._one = {}
         self.defer_sums_reduce = True      # (False: the composite launch is followed by its own reduction launch -- A/B, tests)
+        import os
+        # (False / NUDF_FUSE_BLEND_LOSS=0: the blending step's loss through the generic ColorLoss expressions -- A/B, tests)
+        self.fuse_blend_loss = os.environ.get("NUDF_FUSE_BLEND_LOSS", "1") != "0"
         if data_parallel:
             self.renderer.data_parallel = True
             self.renderer.defer_loss_sums = True
@@ -321,10 +324,22 @@ class Trainer:
         finally:
             self.renderer.defer_loss_sums, self.renderer.defer_sums_reduce = defer, defer_r
         weight_sum = out["weight_sum"]
+        pixel_mask = batch["mask"] if tc["mask_weight"] > 0 else None
+        if (self.fuse_blend_loss and "_loss_sums" in out and not self.data_parallel and tc["mask_weight"] <= 0
+                and out["patch_mask"] is not None
+                and self.color_loss.blend_fusable(out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"],
+                                                  pixel_mask, out["patch_colors"], batch.get("gt_patch_colors"))):
+            # the blending step (pixel + patch terms): the patch-mask algebra, ColorLoss, the trimmed patch loss, the three
+            # regularisers and the total in three launches around one sort (loss._BlendStepLossFn)
+            sums = out.pop("_loss_sums")
+            r = self.color_loss.blend_step_loss(out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"],
+                                                out["patch_colors"], batch["gt_patch_colors"], out["patch_mask"], weight_sum,
+                                                sums, float(weight_sum.shape[0]), w)
+            out["gradient_error"], out["gradient_error_near_surface"], out["sparse_error"] = r[6], r[7], r[8]
+            return r[0], out
         patch_mask = None
         if out["patch_mask"] is not None:
             patch_mask = (out["patch_mask"].float()[:, None] * (weight_sum > 0.5).float()) > 0.
-        pixel_mask = batch["mask"] if tc["mask_weight"] > 0 else None
         cargs = (out["color_base"], out["color"], batch["true_rgb"], out["color_pixel"], pixel_mask, out["patch_colors"],
                  batch.get("gt_patch_colors"), patch_mask)
         bce_sum = None

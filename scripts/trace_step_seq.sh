@@ -3,7 +3,7 @@
 # BENCH_ARGS selects eager / graph etc.
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof8
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof8 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-forward-only --no-roofline ${BENCH_ARGS:-} > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof8 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-forward-only --no-roofline --no-fp32-leg ${BENCH_ARGS:-} > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/prof8/**/*kernel_trace.csv", recursive=True)[0]

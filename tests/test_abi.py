@@ -31,7 +31,7 @@ def test_ctypes_structs_match_header_field_counts():
                       ("NudfPixelBlend", _lib.PixelBlend), ("NudfPixelComposite", _lib.PixelComposite),
                       ("NudfPatchBlend", _lib.PatchBlend), ("NudfPatchWarp", _lib.PatchWarp), ("NudfAdamTensor", _lib.AdamTensor),
                       ("NudfAdamGroup", _lib.AdamGroup), ("NudfChainStep", _lib.ChainStep), ("NudfRayBatch", _lib.RayBatch),
-                      ("NudfGemmTNProblem", _lib.GemmTNProblem)]:
+                      ("NudfGemmTNProblem", _lib.GemmTNProblem), ("NudfBlendLoss", _lib.BlendLoss)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -54,7 +54,7 @@ def test_ctypes_struct_layouts_match_a_c_compile_of_the_header(tmp_path):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("no gcc on this box")
-    pairs = [("NudfGemmNN", _lib.GemmNN), ("NudfGemmTN", _lib.GemmTN), ("NudfGemmTNProblem", _lib.GemmTNProblem),
+    pairs = [("NudfBlendLoss", _lib.BlendLoss), ("NudfGemmNN", _lib.GemmNN), ("NudfGemmTN", _lib.GemmTN), ("NudfGemmTNProblem", _lib.GemmTNProblem),
              ("NudfGemmTNGroup", _lib.GemmTNGroup), ("NudfComposite", _lib.Composite), ("NudfCompositeGrad", _lib.CompositeGrad),
              ("NudfUpsample", _lib.Upsample), ("NudfPixelBlend", _lib.PixelBlend), ("NudfPixelComposite", _lib.PixelComposite),
              ("NudfPatchBlend", _lib.PatchBlend), ("NudfPatchWarp", _lib.PatchWarp), ("NudfAdamTensor", _lib.AdamTensor),
