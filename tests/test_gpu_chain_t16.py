@@ -22,7 +22,8 @@ def _plain(t, P):
 
 
 def _all_sweeps(dev, P, seed):
-    """forward with state, input gradient, second-order backward of the UDF network + the colour net's chains -> tensors"""
+    """forward with state, input gradient, second-order backward of the UDF network, the colour net's chains and the
+    background NeRF's forward / backward -> tensors"""
     import chain_sweeps as CS
     from neuraludf_amd import mlp
     st_ = CS.engines(dev)
@@ -57,6 +58,17 @@ def _all_sweeps(dev, P, seed):
     grads = eng.backward(x, st, DA, d_udf, d_feat, ceng.cin_ld, d_g)
     for i, t in enumerate(grads):
         out[f"p{i}"] = t
+    # the background NeRF's chains (ReLU layers, the 340-column skip layer through RELUADD, two positional encodings)
+    nerf = st_["nerf"]
+    Pn = (min(P, 32768) // S) * S
+    pts4 = torch.randn(Pn, 4, generator=g).to(dev) * 0.5
+    sig, rgb = nerf.evaluate(pts4, rays_d[:Pn // S].contiguous(), S)
+    out.update(nsig=sig.detach(), nrgb=rgb.detach())
+    (sig.sum() + (rgb * torch.randn(rgb.shape, generator=g).to(dev)).sum()).backward()
+    for i, prm in enumerate(nerf.parameters()):
+        if prm.grad is not None:
+            out[f"n{i}"] = prm.grad.detach().clone()
+            prm.grad = None
     torch.cuda.synchronize()
     return {k: v.detach().clone() for k, v in out.items() if v is not None}
 
