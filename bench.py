@@ -580,6 +580,14 @@ def main():
             # priced against BOTH roofs: the HBM side = measured bytes per launch / average launch time
             gbs = roof["traffic"] / (sec / n) / 1e9
             roof["vs_hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        if roof["bound"] == "hbm":
+            # most of the class's launch time belongs to launches whose floor is HBM (config 5's 16-bit mode: bf16 state of
+            # 262 144 points per sweep): the headline numbers of the object are the HBM view -- PMC traffic when recorded, the
+            # algorithmic bytes otherwise -- and the matrix-pipe view moves to `vs_mfma`
+            roof["vs_mfma"] = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}
+            h = roof.get("vs_hbm") or roof["vs_hbm_algorithmic"]
+            roof.update({"achieved": h["achieved"], "peak": h["peak"], "unit": h["unit"], "frac": h["frac"],
+                         "bytes": "PMC traffic per launch" if roof.get("vs_hbm") else "algorithmic stored-state bytes"})
         return roof, kernels
 
     inst = None
