@@ -12,6 +12,9 @@ from .._lib import LW, LW_COUNT
 from .patch_metric import PATCH_TYPES, patch_error
 
 
+_PIN_RING = {"slots": [], "events": [], "k": 0}     # pinned staging slots of every LossWeights.device() (never freed)
+
+
 class LossWeights:
     """The loss / regulariser weights of a train step (include/nudf.h NUDF_LW_*) as host floats plus a device mirror.
 
@@ -60,28 +63,30 @@ class LossWeights:
         # a NEW small device tensor per change (a colour-weight ramp changes the values every iteration): autograd nodes
         # of a loss that has not run its backward yet may still hold views of the previous vector, so it is never
         # overwritten in place.  Staged through a RING of pinned host slots (as train.StepScalars): the copy does not stall
-        # the host-ahead pipeline, and no pinned block is ever freed -- the host allocator records an event on the stream
-        # when a pinned block dies, which is not permitted while that stream is being captured (a garbage-collection pass
-        # inside GraphedStep._capture hit exactly that).
+        # the host-ahead pipeline, and no pinned block is ever freed before the interpreter exits -- the host allocator
+        # touches the block's events when a pinned block dies, which is not permitted while a stream is being captured in
+        # global mode, and a garbage-collection pass inside GraphedStep._capture that freed the pinned slots of an EARLIER
+        # trainer's weights hit exactly that (GraphedStep._capture also keeps the collector off for its duration).
         import torch as _t
         dev = _t.device(device)
         h = _t.tensor(vals, dtype=_t.float32, device="cpu")     # (the reference runner makes CUDA the default tensor type)
         if dev.type != "cuda":
             self._own, self._own_vals = h, vals
             return self._own
-        if getattr(self, "_pins", None) is None:
-            self._pins = [_t.empty(len(vals), dtype=_t.float32, device="cpu").pin_memory() for _ in range(4)]
-            self._pin_ev, self._pin_k = [None] * 4, 0
-        i = self._pin_k % len(self._pins)
-        self._pin_k += 1
-        if self._pin_ev[i] is not None:
-            self._pin_ev[i].synchronize()        # (only ever waits when the host is four weight changes ahead of the GPU)
-        self._pins[i].copy_(h)
+        ring = _PIN_RING          # ONE process-wide ring (module level: it outlives every LossWeights object, see above)
+        if not ring["slots"]:
+            ring["slots"] = [_t.empty(LW_COUNT, dtype=_t.float32, device="cpu").pin_memory() for _ in range(8)]
+            ring["events"] = [None] * 8
+        i = ring["k"] % len(ring["slots"])
+        ring["k"] += 1
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()      # (only ever waits when the host is eight weight changes ahead of the GPU)
+        ring["slots"][i][:len(vals)].copy_(h)
         own = _t.empty(len(vals), dtype=_t.float32, device=dev)
-        own.copy_(self._pins[i], non_blocking=True)
+        own.copy_(ring["slots"][i][:len(vals)], non_blocking=True)
         ev = _t.cuda.Event()
         ev.record()
-        self._pin_ev[i] = ev
+        ring["events"][i] = ev
         self._own, self._own_vals = own, vals
         return self._own
 

@@ -208,12 +208,20 @@ class GraphedStep:
         tr.loss_weights().bind(sc.dev[sc.LOSSW:sc.LOSSW + LW_COUNT])
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        # Python's cyclic collector stays OFF while the stream is capturing: a collection pass in there may free objects of
+        # EARLIER work (pinned host buffers, events, other graphs) whose destructors call into the runtime, which a
+        # global-mode capture forbids -- the process aborts inside a destructor.  (torch.cuda.graph collects once on entry.)
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(g):
                 loss, out = tr.step(ent["batch"], cos_anneal_ratio=(1.0 if has_anneal else None),
                                     flip_saturation=flip_saturation, blend=ent["blend"],
                                     perturb_overwrite=perturb_overwrite)
         finally:
+            if gc_was_on:
+                gc.enable()
             tr.renderer.sched_scalars = None
             tr.optimizer.dyn_base = None
             tr.loss_weights().unbind()
