@@ -989,6 +989,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
 #ifndef NUDF_TN3_DIST2
 #define NUDF_TN3_DIST2 1
 #endif
+#ifndef NUDF_TN3_PIPE
+#define NUDF_TN3_PIPE 1      // A/B build switch: 1 = the split of the next k-step interleaved with this step's MFMAs (see pstep)
+#endif
 #ifndef NUDF_TN3_WGS
 #define NUDF_TN3_WGS 2       // workgroups per CU the split-image kernel is register-allocated for (3: 13 spilled registers)
 #endif
@@ -1195,10 +1198,100 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
         store_f(ub, Bs, false);
         __syncthreads();
       };
-      for (; kt0 + 1 < n_fast; kt0 += 2) {
+      // PIPELINED form (build switch NUDF_TN3_PIPE, scripts/build_variants.sh): the split of step kt + 1 -- pure register arithmetic -- is
+      // interleaved with step kt's MFMAs inside the wave (four VALU operations behind every MFMA, pinned with
+      // sched_group_barrier), so that what is left between the two barriers is twelve LDS stores: the stretch in which this
+      // workgroup cannot issue an MFMA shrinks from the whole split to the stores.  Same values, same order: bit-identical.
+      auto store_r = [&](const u32x4 (&pl)[3][2], unsigned* tile) {
+        unsigned* dst = tile + ((2 * sg) * 128 + sc) * 4;
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          *reinterpret_cast<u32x4*>(dst + p3 * T3Q) = pl[p3][0];
+          *reinterpret_cast<u32x4*>(dst + p3 * T3Q + 512) = pl[p3][1];
+        }
+      };
+      const unsigned* fas = As + ((lane >> 5) * 128 + (wave >> 1) * 64 + (lane & 31)) * 4;
+      const unsigned* fbs = Bs + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
+      auto pstep = [&](float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+        load_f(ba, lda, ca, la);
+        load_f(bb, ldb, cbb, lb);
+        ba += sa_step;
+        bb += sb_step;
+        __builtin_amdgcn_sched_barrier(0);
+        // 12 groups of 4 MFMAs (2 groups of 16 rows x 6 plane pairs); behind each of the first eight, the split of TWO row
+        // pairs of the next step (22 VALU operations + the bias partial), pinned in source order by sched_barrier: a wave
+        // issues its four MFMAs (4 x 32 pipe cycles) and splits while they execute
+        u32x4 pa3[3][2], pb3[3][2];
+        float ps[8];
+#pragma unroll
+        for (int kk = 0; kk < BK3 / 16; ++kk) {
+          u32x4 a[2][3], b[2][3];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              a[s2][pl] = *reinterpret_cast<const u32x4*>(fas + pl * T3Q + (2 * kk) * 512 + 128 * s2);
+              b[s2][pl] = *reinterpret_cast<const u32x4*>(fbs + pl * T3Q + (2 * kk) * 512 + 128 * s2);
+            }
+#pragma unroll
+          for (int tt = 0; tt < 6; ++tt) {
+            const int qa = (tt == 0 || tt == 3 || tt == 5) ? 0 : (tt == 1 ? 2 : 1);     // h l m h m h
+            const int qb = (tt == 0) ? 2 : ((tt == 2 || tt == 3) ? 1 : 0);              // l h m m h h
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+                acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][qa]),
+                                                                         __builtin_bit_cast(bf16x8, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+            const int c = kk * 6 + tt;           // chunk 0..11: chunks 0..3 split A's pairs 2c, 2c + 1, chunks 4..7 B's
+            if (c < 8) {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int pp = 2 * (c & 3) + e;
+                unsigned x, y, z;
+                if (c < 4) {
+                  tn_split3_pair(ua[2 * pp], ua[2 * pp + 1], x, y, z);
+                  // (an opaque use HERE: the split is pure arithmetic and LLVM otherwise sinks it to its consumers, the LDS
+                  // stores behind the barrier, before the machine scheduler ever sees the sched_barriers)
+                  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+                  pa3[0][pp >> 2][pp & 3] = x; pa3[1][pp >> 2][pp & 3] = y; pa3[2][pp >> 2][pp & 3] = z;
+                  ps[pp] = ua[2 * pp] + ua[2 * pp + 1];
+                } else {
+                  tn_split3_pair(ub[2 * pp], ub[2 * pp + 1], x, y, z);
+                  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+                  pb3[0][pp >> 2][pp & 3] = x; pb3[1][pp >> 2][pp & 3] = y; pb3[2][pp >> 2][pp & 3] = z;
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // (a select, not a branch; the same tree and running sum as store_f)
+        const float bsum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+        bias_acc = do_bias ? bias_acc + bsum : bias_acc;
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        store_r(pa3, As);
+        store_r(pb3, Bs);
+        __syncthreads();
+      };
+      // (n_fast >= 2 here: a do-while keeps the two steps of an iteration in straight-line code -- with a for loop and both
+      // forms selectable at run time hipcc rotated the loop BETWEEN a step's MFMAs and its split, i.e. put them in different
+      // basic blocks, where nothing can be interleaved)
+#if NUDF_TN3_PIPE
+      do {
+        pstep(sa, sb, sa2, sb2);
+        pstep(sa2, sb2, sa, sb);
+        kt0 += 2;
+      } while (kt0 + 1 < n_fast);
+#else
+      (void)pstep;
+      do {
         fstep(sa, sb, sa2, sb2);
         fstep(sa2, sb2, sa, sb);
-      }
+        kt0 += 2;
+      } while (kt0 + 1 < n_fast);
+#endif
     }
   }
   for (int kt = kt0; kt < nk; kt += 2) {
