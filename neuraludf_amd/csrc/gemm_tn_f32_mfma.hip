@@ -63,12 +63,14 @@ struct TnTile {
   short n;
   short gfirst;         // tile group = consecutive tiles of one problem with the same row chunks: its first tile ...
   short gn;             // ... and its size (the group's workgroups are one contiguous range of blockIdx)
-  short pad;
+  short rot;            // the group's lane rotation of the XCD-aware order (tn_decode_block)
+  int grid_start;       // first blockIdx of the tile's GROUP (the same on every tile of the group)
 };
 struct TnPlan {
   NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
   TnTile tile[TN_MAX_TILES + 1];   // tile[n_tiles].blk_start = total workgroups
   int n_tiles, M, prec, flags;
+  int grid_blocks;                 // workgroups launched (>= tile[n_tiles].blk_start: the XCD-aware order leaves holes, which exit)
   short partner[TN_MAX_TILES];     // wide bf16x3 kernel (gemm_tn3w_group_kernel): >= 0 = this tile leads a pair with the tile one
                                    // tile row below (same problem, same tile column, same chunks); -1 = a leader without partner;
                                    // -2 = follower (its workgroups exit: the leader's workgroup computes both tiles)
@@ -83,6 +85,8 @@ struct TnPlan {
   long long* dbg;                  // tuning: per workgroup {start, end} of wall_clock64 (100 MHz), layout, n
 };
 
+static_assert(sizeof(TnPlan) <= 4096, "TnPlan is passed by value: kernel arguments are limited to 4 KB");
+
 // 32 x 32 sub-tile (row index, column index) held by accumulator s of a wave
 __device__ __forceinline__ int tn_isub(int layout, int wave, int s) {
   return layout == 0 ? s : layout == 1 ? wave : (wave >> 1) * 2 + (s >> 1);
@@ -93,21 +97,25 @@ __device__ __forceinline__ int tn_jsub(int layout, int wave, int s) {
 
 // blockIdx -> (tile, row chunk).  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2:
 // the tiles of one problem that read the same rows (same chunk; tiles of a tile row share the A panel, of a tile column
-// the B panel) are put on the SAME XCD -- within a tile group, blockIdx = first + (chunk / 8) * 8 T + tile * 8 + chunk % 8
-// (T tiles; the last chunk % 8 columns are narrower).  Workspace slots stay tile-major (tile.blk_start + chunk).
+// the B panel) are put on the SAME XCD.  Within a tile group of T > 1 tiles, blockIdx = grid_start + (c / 8) * 8 T + tile * 8 +
+// x with lane x = (c + rot) % 8: EVERY chunk's tiles share blockIdx % 8.  The last row of a group whose chunk count C is not a
+// multiple of 8 has 8 - C % 8 lanes without a chunk: those workgroups are HOLES (t = -1, they exit at once); the group's
+// rotation `rot` is chosen by the planner so that the occupied lanes of all groups load the 8 XCDs evenly.  (Round 2-4 packed
+// the last row without holes -- its tiles landed on different XCDs: with C = 13, 5 of 13 chunks read their panels twice from
+// HBM, 1.91 GB fetched for 1.21 GB of operands in the UDF adjoint group, and the kernel ran at the HBM rate,
+// profiles/r05_tn_l2_sharing.txt.)  Workspace slots stay tile-major (tile.blk_start + chunk).
 __host__ __device__ __forceinline__ void tn_decode_block(const TnPlan& g, int block, int& t, int& chunk) {
-  t = 0;
-  while (t + 1 < g.n_tiles && g.tile[t + 1].blk_start <= block) ++t;
-  chunk = block - g.tile[t].blk_start;
-  if (!(g.flags & TNF_NO_XCD_MAP) && g.tile[t].gn > 1) {
-    const int gf = g.tile[t].gfirst, T = g.tile[gf].gn;
+  int gf = 0;
+  while (gf + g.tile[gf].gn < g.n_tiles && g.tile[gf + g.tile[gf].gn].grid_start <= block) gf += g.tile[gf].gn;
+  const int T = g.tile[gf].gn;
+  const int o = block - g.tile[gf].grid_start;
+  t = gf;
+  chunk = o;
+  if (T > 1) {
     const int C = g.tile[gf + 1].blk_start - g.tile[gf].blk_start;
-    const int o = block - g.tile[gf].blk_start;
     const int c_hi = o / (8 * T), rem = o - c_hi * 8 * T;
-    const int w = (c_hi < (C >> 3)) ? 8 : (C & 7);
-    const int k = rem / w;
-    t = gf + k;
-    chunk = c_hi * 8 + (rem - k * w);
+    chunk = c_hi * 8 + (((rem & 7) - g.tile[gf].rot) & 7);
+    t = chunk < C ? gf + (rem >> 3) : -1;
   }
 }
 __device__ __forceinline__ void tn_decode(const TnPlan& g, int& t, int& chunk) { tn_decode_block(g, (int)blockIdx.x, t, chunk); }
@@ -121,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnPlan g) {
   const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
   int t, chunk;
   tn_decode(g, t, chunk);
+  if (t < 0) return;               // a hole of the XCD-aware order
   const TnTile tl = g.tile[t];
   const NudfGemmTNProblem& q = g.prob[tl.prob];
   const int slot_id = tl.blk_start + chunk;
@@ -723,6 +732,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
   const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
   int t, chunk;
   tn_decode(g, t, chunk);
+  if (t < 0) return;               // a hole of the XCD-aware order
   const TnTile tl = g.tile[t];
   const NudfGemmTNProblem& q = g.prob[tl.prob];
   const int slot_id = tl.blk_start + chunk;
@@ -992,6 +1002,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn16_group_kernel(TnPlan g) {
 #ifndef NUDF_TN3_PIPE
 #define NUDF_TN3_PIPE 1      // A/B build switch: 1 = the split of the next k-step interleaved with this step's MFMAs (see pstep)
 #endif
+#ifndef NUDF_TN3_LDSPREAD
+#define NUDF_TN3_LDSPREAD 0  // A/B build switch (with NUDF_TN3_PIPE): 1 = the row requests of step kt + 2 issued between the MFMA groups (measured 8 % slower: the requests are throttled by the memory path wherever they are issued)
+#endif
+#ifndef NUDF_TN3_BUFLOAD
+#define NUDF_TN3_BUFLOAD 1   // A/B build switch: 1 = the steady state's row requests are buffer loads (scalar row offset, 32-bit lane offset)
+#endif
+#ifndef NUDF_TN3_STAMPS
+#define NUDF_TN3_STAMPS 0
+#endif
 #ifndef NUDF_TN3_WGS
 #define NUDF_TN3_WGS 2       // workgroups per CU the split-image kernel is register-allocated for (3: 13 spilled registers)
 #endif
@@ -1024,6 +1043,7 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
   const long long c_begin = g.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
   int t, chunk;
   tn_decode(g, t, chunk);
+  if (t < 0) return;               // a hole of the XCD-aware order
   const TnTile tl = g.tile[t];
   const NudfGemmTNProblem& q = g.prob[tl.prob];
   const int slot_id = tl.blk_start + chunk;
@@ -1151,17 +1171,43 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
   // load is ONE instruction (global_load_dword v, v_col, s[row base]), no vector address arithmetic, nothing to wait for; full
   // steps also need no row-validity selects in the split.  Same values, same order: C and dbias are unchanged bit for bit.
   int kt0 = 0;
+#if NUDF_TN3_STAMPS     // tuning build (scripts/tn3_phases.py): shader-clock ticks of waves 0 / 3 per segment of the pipelined steps
+  long long tk_load = 0, tk_mma = 0, tk_bar1 = 0, tk_store = 0, tk_bar2 = 0;
+#endif
   if (!(g.flags & TNF_GENERIC_STAGE)) {
     const bool last_ragged = ((mend - mbeg) % BK3) != 0 || mend > g.M;
     const int n_fast = nk - 2 - (last_ragged ? 1 : 0);          // steps kt with kt + 1 and kt + 2 full and inside the chunk
-    if (n_fast >= 2) {
+    // (buffer descriptors hold a 32-bit byte count)
+    if (n_fast >= 2 && (size_t)(g.M - mbeg) * (size_t)max(q.lda1, q.ldb1) * 4 < ((size_t)1 << 31)) {
       // (16 sg is wave-uniform: waves 0-1 stage rows 0..15 of a step, waves 2-3 rows 16..31)
       const int sgu = __builtin_amdgcn_readfirstlane(sg);
       const unsigned ca = (unsigned)min(i0 + sc, q.lda1 - 1), cbb = (unsigned)min(j0 + sc, q.ldb1 - 1);
+#if NUDF_TN3_BUFLOAD
+      // BUFFER loads: address = descriptor base (the chunk's first row) + a 32-bit lane offset (the column) + a scalar offset (the
+      // row): `buffer_load_dword v, v_col, s[rsrc], s_row offen` -- no vector address arithmetic at all.  (The flat form of the
+      // same loop, `(base + r * ld)[col]`, compiled to a chain of 30 v_lshl_add_u64 and 64-bit per-lane addresses.)
+      const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.A1 + (size_t)mbeg * lda), 0,
+                                                                           (int)((size_t)(g.M - mbeg) * lda * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.B1 + (size_t)mbeg * ldb), 0,
+                                                                           (int)((size_t)(g.M - mbeg) * ldb * 4), 0x00020000);
+      const int lda4 = q.lda1 * 4, ldb4 = q.ldb1 * 4;
+      int ba = (2 * BK3 + 16 * sgu) * lda4, bb = (2 * BK3 + 16 * sgu) * ldb4;       // scalar byte offsets of the rows of step kt + 2
+      const int sa_step = BK3 * lda4, sb_step = BK3 * ldb4;
+      auto load_f = [&](__amdgpu_buffer_rsrc_t rs, int so, int ld4, unsigned col, float (&st)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          st[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(col * 4), so + r * ld4, 0));
+      };
+#define TN3_LOAD_A(st) load_f(rsa, ba, lda4, ca, st)
+#define TN3_LOAD_B(st) load_f(rsb, bb, ldb4, cbb, st)
+#else
       auto load_f = [&](const float* __restrict__ base, size_t ld, unsigned col, float (&st)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = (base + (size_t)r * ld)[col];     // scalar row base + one 32-bit lane offset
       };
+#define TN3_LOAD_A(st) load_f(ba, lda, ca, st)
+#define TN3_LOAD_B(st) load_f(bb, ldb, cbb, st)
+#endif
       auto store_f = [&](const float (&st)[16], unsigned* tile, bool bias) {
         u32x4 hq[2], mq[2], lq[2];
         float ps[8];
@@ -1182,12 +1228,14 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
         *reinterpret_cast<u32x4*>(dst + 2 * T3Q + 512) = lq[1];
       };
       // uniform bases of the rows of step kt + 2 (scalar registers; the readfirstlane only tells the compiler so)
+#if !NUDF_TN3_BUFLOAD
       const float* ba = q.A1 + (size_t)(mbeg + 2 * BK3 + 16 * sgu) * lda;
       const float* bb = q.B1 + (size_t)(mbeg + 2 * BK3 + 16 * sgu) * ldb;
       const size_t sa_step = (size_t)BK3 * lda, sb_step = (size_t)BK3 * ldb;
+#endif
       auto fstep = [&](float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
-        load_f(ba, lda, ca, la);
-        load_f(bb, ldb, cbb, lb);
+        TN3_LOAD_A(la);
+        TN3_LOAD_B(lb);
         ba += sa_step;
         bb += sb_step;
         __builtin_amdgcn_sched_barrier(0);
@@ -1212,12 +1260,23 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
       };
       const unsigned* fas = As + ((lane >> 5) * 128 + (wave >> 1) * 64 + (lane & 31)) * 4;
       const unsigned* fbs = Bs + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
+#if NUDF_TN3_STAMPS
+#define TN3_STAMP(acc_) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); acc_ += n_ - tk_last; tk_last = n_; }
+#else
+#define TN3_STAMP(acc_)
+#endif
       auto pstep = [&](float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
-        load_f(ba, lda, ca, la);
-        load_f(bb, ldb, cbb, lb);
+#if NUDF_TN3_STAMPS
+        long long tk_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
+#if !NUDF_TN3_LDSPREAD
+        TN3_LOAD_A(la);
+        TN3_LOAD_B(lb);
         ba += sa_step;
         bb += sb_step;
         __builtin_amdgcn_sched_barrier(0);
+#endif
+        TN3_STAMP(tk_load)
         // 12 groups of 4 MFMAs (2 groups of 16 rows x 6 plane pairs); behind each of the first eight, the split of TWO row
         // pairs of the next step (22 VALU operations + the bias partial), pinned in source order by sched_barrier: a wave
         // issues its four MFMAs (4 x 32 pipe cycles) and splits while they execute
@@ -1263,18 +1322,42 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
                 }
               }
             }
+#if NUDF_TN3_LDSPREAD && !NUDF_TN3_BUFLOAD
+            // the 32 row requests of step kt + 2, spread over the twelve groups as well (3 3 3 3 3 3 3 3 2 2 2 2, in the order
+            // the next step's split consumes them): issued in one burst at the top of the step they held the wave for ~1 800
+            // cycles per step before its first MFMA (8 waves x 32 requests x 256 B against a 64 B / clk vector cache path)
+            if (c < 8) {
+              la[2 * c] = (ba + (size_t)(2 * c) * lda)[ca];
+              la[2 * c + 1] = (ba + (size_t)(2 * c + 1) * lda)[ca];
+              lb[c] = (bb + (size_t)c * ldb)[cbb];
+            } else {
+              lb[2 * c - 8] = (bb + (size_t)(2 * c - 8) * ldb)[cbb];
+              lb[2 * c - 7] = (bb + (size_t)(2 * c - 7) * ldb)[cbb];
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#if NUDF_TN3_LDSPREAD
+        ba += sa_step;
+        bb += sb_step;
+#endif
         // (a select, not a branch; the same tree and running sum as store_f)
         const float bsum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
         bias_acc = do_bias ? bias_acc + bsum : bias_acc;
         __builtin_amdgcn_sched_barrier(0);
+        TN3_STAMP(tk_mma)
         __syncthreads();
+        TN3_STAMP(tk_bar1)
         store_r(pa3, As);
         store_r(pb3, Bs);
+        TN3_STAMP(tk_store)
         __syncthreads();
+        TN3_STAMP(tk_bar2)
       };
+#undef TN3_STAMP
+#undef TN3_LOAD_A
+#undef TN3_LOAD_B
       // (n_fast >= 2 here: a do-while keeps the two steps of an iteration in straight-line code -- with a for loop and both
       // forms selectable at run time hipcc rotated the loop BETWEEN a step's MFMAs and its split, i.e. put them in different
       // basic blocks, where nothing can be interleaved)
@@ -1299,11 +1382,20 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
     if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb);
   }
 
+#if NUDF_TN3_STAMPS
+  if (g.dbg && lane == 0 && (wave == 0 || wave == 3)) {
+    long long* d = g.dbg + 16 * (size_t)blockIdx.x + (wave ? 8 : 0);
+    d[0] = t_begin; d[1] = (long long)wall_clock64();
+    d[2] = nk | ((long long)kt0 << 20) | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 40);
+    d[3] = tk_load; d[4] = tk_mma; d[5] = tk_bar1; d[6] = tk_store; d[7] = tk_bar2;
+  }
+#else
   if (g.dbg && tid == 0) {
     long long* d = g.dbg + 4 * (size_t)blockIdx.x;
     d[0] = t_begin; d[1] = (long long)wall_clock64(); d[2] = 2 * 16 + 4;
     d[3] = nk | (((long long)__builtin_amdgcn_s_memtime() - c_begin) << 16);
   }
+#endif
   if (g.flags & TNF_NO_EPILOGUE) return;
   float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
   if (do_bias) {   // the loop's last barrier has passed: the operand image is free
@@ -1673,7 +1765,7 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
         if (li > 4) li = 4;
         if (lj > 4) lj = 4;
         TnTile& tl = pl.tile[nt];
-        tl.prob = (short)i; tl.ti = (short)ti; tl.tj = (short)tj; tl.pad = 0;
+        tl.prob = (short)i; tl.ti = (short)ti; tl.tj = (short)tj; tl.rot = 0;
         tl.layout = (short)(li <= lj ? 0 : 1);
         tl.n = (short)(li <= lj ? li : lj);
         if (li == 4 && lj == 4 && !(flags & TNF_NO_QUADRANTS)) tl.layout = 2;
@@ -1738,6 +1830,54 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
   }
   const int nkt = (g.M + BK - 1) / BK;                 // k-steps over all points
   int chunks_of[TN_MAX_TILES];
+  int blocks = 0;
+  // workgroup order for a given chunking: workspace slots (tile-major), tile groups, the XCD-aware grid (tn_decode_block);
+  // returns the largest number of LIVE workgroups any XCD receives
+  auto layout = [&]() {
+    blocks = 0;
+    for (int t = 0; t < nt; ++t) {
+      pl.tile[t].blk_start = blocks;
+      blocks += (g.M + pl.tile[t].rows_per_block - 1) / pl.tile[t].rows_per_block;
+    }
+    pl.tile[nt].blk_start = blocks;
+    pl.tile[nt].gfirst = (short)nt; pl.tile[nt].gn = 1; pl.tile[nt].rot = 0;
+    for (int t = 0; t < nt;) {   // tile groups: same problem, same chunking (TNF_NO_XCD_MAP: every tile alone = tile-major order)
+      int e = t + 1;
+      while (!(flags & TNF_NO_XCD_MAP) && e < nt && pl.tile[e].prob == pl.tile[t].prob &&
+             pl.tile[e].rows_per_block == pl.tile[t].rows_per_block) ++e;
+      for (int k = t; k < e; ++k) { pl.tile[k].gfirst = (short)t; pl.tile[k].gn = (short)(e - t); }
+      t = e;
+    }
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int G = 0;
+    for (int t = 0; t < nt; t += pl.tile[t].gn) {
+      const int T = pl.tile[t].gn, C = pl.tile[t + 1].blk_start - pl.tile[t].blk_start;
+      int rot = 0, size = C;
+      if (T == 1) {
+        for (int i = 0; i < C; ++i) ++load[(G + i) & 7];
+      } else {
+        const int w = C & 7;
+        for (int x = 0; x < 8; ++x) load[x] += T * (C >> 3);
+        if (w) {   // the rotation whose occupied lanes are the least loaded XCDs so far
+          int best = 1 << 30;
+          for (int r = 0; r < 8; ++r) {
+            int m = 0, sum = 0;
+            for (int cl = 0; cl < w; ++cl) { const int l = load[(G + ((cl + r) & 7)) & 7]; m = l > m ? l : m; sum += l; }
+            if (m * 4096 + sum < best) { best = m * 4096 + sum; rot = r; }
+          }
+          for (int cl = 0; cl < w; ++cl) load[(G + ((cl + rot) & 7)) & 7] += T;
+        }
+        size = ((C + 7) >> 3) * 8 * T;
+      }
+      for (int k = t; k < t + T; ++k) { pl.tile[k].grid_start = G; pl.tile[k].rot = (short)rot; }
+      G += size;
+    }
+    pl.tile[nt].grid_start = G;
+    pl.grid_blocks = G;
+    int m = 0;
+    for (int x = 0; x < 8; ++x) m = load[x] > m ? load[x] : m;
+    return m;
+  };
   if (g.rows_per_block > 0) {
     bool any_blk = false;
     for (int i = 0; i < g.n_problems; ++i) any_blk = any_blk || (g.prob[i].flags & (NUDF_TN_A_BLK | NUDF_TN_B_BLK));
@@ -1747,12 +1887,13 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
       return -1;
     }
     for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = g.rows_per_block;
+    layout();
   } else {
     // exactly one resident wave of workgroups (2 per CU x 256 CUs; NUDF_TNG_BLOCKS: tuning hook), at least 8 k-steps
     // per workgroup.  Tile t costs cost[t] MFMA units per k-step: find the smallest per-workgroup budget T for which
     // sum_t ceil(cost[t] * nkt / T) fits, i.e. every workgroup does (nearly) the same number of MFMAs.
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target = e ? atoi(e) : 512; }
+    static int target0 = -1;
+    if (target0 < 0) { const char* e = getenv("NUDF_TNG_BLOCKS"); target0 = e ? atoi(e) : 512; }
     const int max_chunks = nkt / 8 > 0 ? nkt / 8 : 1;
     if (pl.wide) {
       // one resident wave of WIDE workgroups: a pair (or an unpaired tile) per CU, every tile the same number of chunks
@@ -1762,39 +1903,40 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
       if (n < 1) n = 1;
       if (n > max_chunks) n = max_chunks;
       for (int t = 0; t < nt; ++t) chunks_of[t] = n;
+      for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = ((nkt + chunks_of[t] - 1) / chunks_of[t]) * BK;
+      layout();
     } else {
-    auto count = [&](double T, bool store) {
-      long total = 0;
-      for (int t = 0; t < nt; ++t) {
-        // 16-bit operands: the k-step is bound by the loads / LDS traffic of the (always full-size) operand tiles, not by
-        // the live MFMAs -- every tile costs the same
-        const double c = ((flags & TNF_UNIFORM_CHUNKS) || g.prec != 0) ? 4.0 : cost[t];
-        long n = (long)((c * (double)nkt + T - 1e-9) / T);
-        if (n < 1) n = 1;
-        if (n > max_chunks) n = max_chunks;
-        if (store) chunks_of[t] = (int)n;
-        total += n;
-      }
-      return total;
-    };
-    double lo = 0.0, hi = 4.0 * nkt;                   // hi: one chunk per tile (always fits: nt <= 64 <= target)
-    if (count(hi, false) <= target) {
-      for (int it = 0; it < 60; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (count(mid, false) <= target) hi = mid; else lo = mid;
+      // (the XCD-aware order keeps whole chunks of a tile group on one XCD, so the XCDs' shares are not exactly equal: when one
+      // XCD would receive more live workgroups than it has slots -- a second round on its CUs -- the total is lowered)
+      for (int target = target0;; target -= 8) {
+        auto count = [&](double T, bool store) {
+          long total = 0;
+          for (int t = 0; t < nt; ++t) {
+            // 16-bit operands: the k-step is bound by the loads / LDS traffic of the (always full-size) operand tiles, not by
+            // the live MFMAs -- every tile costs the same
+            const double c = ((flags & TNF_UNIFORM_CHUNKS) || g.prec != 0) ? 4.0 : cost[t];
+            long n = (long)((c * (double)nkt + T - 1e-9) / T);
+            if (n < 1) n = 1;
+            if (n > max_chunks) n = max_chunks;
+            if (store) chunks_of[t] = (int)n;
+            total += n;
+          }
+          return total;
+        };
+        double lo = 0.0, hi = 4.0 * nkt;                   // hi: one chunk per tile (always fits: nt <= 64 <= target)
+        if (count(hi, false) <= target) {
+          for (int it = 0; it < 60; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (count(mid, false) <= target) hi = mid; else lo = mid;
+          }
+        }
+        count(hi, true);
+        for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = ((nkt + chunks_of[t] - 1) / chunks_of[t]) * BK;
+        const int most = layout();
+        if (most <= target0 / 8 || target - 8 < nt || target - 8 < target0 / 2) break;
       }
     }
-    count(hi, true);
-    }
-    for (int t = 0; t < nt; ++t) pl.tile[t].rows_per_block = ((nkt + chunks_of[t] - 1) / chunks_of[t]) * BK;
   }
-  int blocks = 0;
-  for (int t = 0; t < nt; ++t) {
-    pl.tile[t].blk_start = blocks;
-    blocks += (g.M + pl.tile[t].rows_per_block - 1) / pl.tile[t].rows_per_block;
-  }
-  pl.tile[nt].blk_start = blocks;
-  pl.tile[nt].gfirst = (short)nt; pl.tile[nt].gn = 1;
   pl.n_units = 0;
   pl.unit_chunks = nt > 0 ? pl.tile[1].blk_start - pl.tile[0].blk_start : 1;
   if (pl.wide) {
@@ -1802,12 +1944,6 @@ static int tn_plan(const NudfGemmTNGroup& g, TnPlan& pl) {
       if (pl.tile[t + 1].blk_start - pl.tile[t].blk_start != pl.unit_chunks) pl.wide = 0;   // (cannot happen: uniform chunks)
       if (pl.partner[t] != -2) pl.unit_tile[pl.n_units++] = (short)t;
     }
-  }
-  for (int t = 0; t < nt;) {   // tile groups: same problem, same chunking
-    int e = t + 1;
-    while (e < nt && pl.tile[e].prob == pl.tile[t].prob && pl.tile[e].rows_per_block == pl.tile[t].rows_per_block) ++e;
-    for (int k = t; k < e; ++k) { pl.tile[k].gfirst = (short)t; pl.tile[k].gn = (short)(e - t); }
-    t = e;
   }
   return blocks;
 }
@@ -1820,19 +1956,22 @@ extern "C" int64_t nudf_gemm_tn_grouped_workspace(const NudfGemmTNGroup* args) {
 }
 
 // host mirror of the kernels' blockIdx -> (tile, chunk) decode, for tests of the plan: out[4 b ..] = {problem, tile row *
-// 256 + tile column, row chunk, workspace slot} of workgroup b; returns the number of workgroups (<= capacity written)
+// 256 + tile column, row chunk, workspace slot} of workgroup b (-1 x 4: a hole of the XCD-aware order); returns the number of
+// workgroups LAUNCHED (<= capacity written)
 extern "C" int nudf_gemm_tn_grouped_plan(const NudfGemmTNGroup* args, int32_t* out, int capacity) {
   TnPlan pl;
   const int blocks = tn_plan(*args, pl);
-  for (int b = 0; b < blocks && b < capacity; ++b) {
+  if (blocks <= 0) return blocks;
+  for (int b = 0; b < pl.grid_blocks && b < capacity; ++b) {
     int t, chunk;
     tn_decode_block(pl, b, t, chunk);
+    if (t < 0) { out[4 * b] = out[4 * b + 1] = out[4 * b + 2] = out[4 * b + 3] = -1; continue; }   // a hole: exits at once
     out[4 * b] = pl.tile[t].prob;
     out[4 * b + 1] = pl.tile[t].ti * 256 + pl.tile[t].tj;
     out[4 * b + 2] = chunk;
     out[4 * b + 3] = pl.tile[t].blk_start + chunk;
   }
-  return blocks;
+  return pl.grid_blocks;
 }
 
 extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
@@ -1880,9 +2019,9 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
     if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;
   if (split3 && pl.wide)
     hipLaunchKernelGGL(gemm_tn3w_group_kernel, dim3(pl.n_units * pl.unit_chunks), dim3(512), 0, (hipStream_t)stream, pl);
-  else if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
-  else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
-  else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  else if (split3) hipLaunchKernelGGL(gemm_tn3_group_kernel, dim3(pl.grid_blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  else if (packed16) hipLaunchKernelGGL(gemm_tn16_group_kernel, dim3(pl.grid_blocks), dim3(256), 0, (hipStream_t)stream, pl);
+  else hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(pl.grid_blocks), dim3(256), 0, (hipStream_t)stream, pl);
   NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
   if (pl.ws && !(pl.flags & TNF_NO_EPILOGUE)) {
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(pl.n_tiles * 17), dim3(256), 0, (hipStream_t)stream, pl);
