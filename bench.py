@@ -95,6 +95,96 @@ def _cpu_info():
     return model, firsts
 
 
+class _PowerSampler:
+    """socket power / shader clock while the timed step replays (amdgpu hwmon: power1_average | power1_input in uW, freq1_input in
+    Hz, power1_cap; rocm-smi --csv when sysfs has none).  Round 5 found the step running against the package power limit
+    (profiles/r05_tn_power.txt): the clock the kernels see is part of the measurement."""
+
+    def __init__(self, period=0.02, device=0):
+        import glob
+        self.period, self.samples, self._stop, self._th = period, [], False, None
+        self.cards = []
+        want = None
+        try:                                       # the card of THIS process's device (a node's other GPUs are visible in sysfs)
+            pr = torch.cuda.get_device_properties(device)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pci = os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(h))))
+            if want and not pci.startswith(want):
+                continue
+            pw = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            if pw:
+                self.cards.append({"power": pw, "freq": os.path.join(h, "freq1_input"), "cap": os.path.join(h, "power1_cap"), "pci": pci})
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _smi(self):
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
+            rows = [r for r in out.strip().splitlines() if r.startswith("card")]
+            hdr = [r for r in out.strip().splitlines() if r.startswith("device")][0].split(",")
+            best = None
+            for r in rows:
+                d = dict(zip(hdr, r.split(",")))
+                w = float([v for k, v in d.items() if "Power (W)" in k][0])
+                mhz = float(d.get("sclk clock speed:", "(0Mhz)").strip("()").lower().replace("mhz", ""))
+                if best is None or w > best[0]:
+                    best = (w, mhz)
+            return best
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            if self.cards:
+                best = None
+                for c in self.cards:
+                    w, f = self._read(c["power"]), self._read(c["freq"])
+                    if w is not None and (best is None or w > best[0]):
+                        best = (w / 1e6, (f or 0.0) / 1e6)
+                if best:
+                    self.samples.append(best)
+                time.sleep(self.period)
+            else:
+                b = self._smi()
+                if b:
+                    self.samples.append(b)
+
+    def __enter__(self):
+        import threading
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        self._th.join(timeout=10)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        s = self.samples[len(self.samples) // 4:] or self.samples            # drop the ramp
+        cap = None
+        for c in self.cards:
+            v = self._read(c["cap"])
+            cap = v / 1e6 if v else cap
+        return {"avg_w": sum(x[0] for x in s) / len(s), "max_w": max(x[0] for x in s), "cap_w": cap,
+                "sclk_mhz_avg": sum(x[1] for x in s) / len(s), "sclk_mhz_min": min(x[1] for x in s), "samples": len(s),
+                "source": ("amdgpu hwmon of %s (power1_average|input, freq1_input)" % ",".join(c["pci"] for c in self.cards))
+                if self.cards else "rocm-smi --showpower --showclocks",
+                "what": "this rank's card while the timed step replays for ~1 s AFTER the timed windows (not inside them); the "
+                        "dense bf16 peak of `roofline` assumes 2400 MHz"}
+
+
 def _vs_reference_fixture(workload, n_rays, rays, rend, dev):
     """the same comparison against outputs the REFERENCE ITSELF produced (build container, CPU) on the timed inputs:
     tests/golden/ref_bench_cfg2_full.npz, written by tests/golden/make_golden_full.py bench_cfg2 -- bench.py's own ray
@@ -299,6 +389,7 @@ def main():
                     help="weak (default): --rays-per-gpu rays on every rank; strong: --global-rays rays in total, "
                          "global / N per rank (default for the dtu_scan118_4096x128 workload, BASELINE configs[3])")
     ap.add_argument("--global-rays", type=int, default=0, help="strong scaling: rays of the whole job (default: the workload's)")
+    ap.add_argument("--no-power", action="store_true", help="skip the ~1 s power / shader-clock sampling window after the timed region")
     ap.add_argument("--windows", type=int, default=5,
                     help="timed windows of --steps steps each; ms_per_step is the median window (box-to-box and "
                          "window-to-window spread of a 0.1 s region is ~3 %%)")
@@ -464,6 +555,19 @@ def main():
         "gradient_message_floats": (tr.bucket.last_message_floats if world > 1 else None),
     }
 
+    # ---- socket power and shader clock under the same replayed step (outside the timed windows; every rank steps, rank 0 samples)
+    if not args.no_power:
+        try:
+            n_pw = max(args.steps, int(1.0 / max(dt / args.steps, 1e-4)))       # (dt is the max over ranks: the same everywhere)
+            if rank == 0:
+                with _PowerSampler(device=dev.index or 0) as ps:
+                    timed_window(run_step, n_pw)
+                result["power"] = ps.summary()
+            else:
+                timed_window(run_step, n_pw)
+        except Exception as ex:                               # never fatal: the line is still valid without it
+            result["power"] = {"error": repr(ex)}
+
     # ---- forward only ("also forward-only ray-samples/s"): the same batch rendered without autograd, all
     # ranks (the ray-sharded render holds a collective), same bracketing
     with torch.no_grad():
@@ -595,6 +699,14 @@ def main():
         inst = instrumented(args.precision)
     if rank == 0 and inst is not None:
         result["roofline"], result["kernels"] = inst
+        pw = result.get("power") or {}
+        if pw.get("sclk_mhz_avg") and result["roofline"].get("bound") == "mfma":
+            # the step runs against the package power limit: the matrix pipe's peak at the clock the card held
+            r = result["roofline"]
+            r["at_sampled_clock"] = {"sclk_mhz": pw["sclk_mhz_avg"], "peak": r["peak"] * pw["sclk_mhz_avg"] / 2400.0,
+                                     "frac": r["achieved"] / (r["peak"] * pw["sclk_mhz_avg"] / 2400.0),
+                                     "what": "peak scaled from 2400 MHz to the step-average shader clock of `power` (the heavy "
+                                             "launches run below that average)"}
         # ---- fused composite kernel alone (HBM roof) ----
         try:
             result["roofline_composite"] = composite_roofline(dev, rays_per_gpu, s_core)
