@@ -700,6 +700,14 @@ def main():
     if rank == 0 and inst is not None:
         result["roofline"], result["kernels"] = inst
         pw = result.get("power") or {}
+        if result["roofline"].get("bound") == "mfma" and result["roofline"].get("unit") == "TFLOP/s" and args.precision != "fp32":
+            # what the matrix pipe ALONE sustains on this card at its 1400 W package limit (a loop of nothing but
+            # v_mfma_f32_32x32x16_bf16, two waves per SIMD; by operand bit activity) -- a recorded measurement, not re-run here
+            r = result["roofline"]
+            r["sustained_peak_recorded"] = {"tflops_range": [1311.0, 1721.0], "frac_range": [r["achieved"] / 1721.0, r["achieved"] / 1311.0],
+                                            "source": "profiles/r05_mfma_bf16_power.txt (scripts/ubench/mfma_bf16_power.hip)",
+                                            "what": "`peak` above is the nominal 2500 TFLOP/s at 2400 MHz, which the power limit does "
+                                                    "not let a saturated pipe hold (1.2-1.6 GHz)"}
         if pw.get("sclk_mhz_avg") and result["roofline"].get("bound") == "mfma":
             # the step runs against the package power limit: the matrix pipe's peak at the clock the card held
             r = result["roofline"]

@@ -29,6 +29,7 @@ class FusedAdam(torch.optim.Optimizer):
         # bias corrections).  None: they travel by value (eager steps).
         self.dyn_base = None
         self._plan = None         # the last step's filled launch descriptors (reused while every address stays put)
+        self.plan_hits = 0        # steps that reused them (tests)
         self._order = []          # parameters of the last step() in launch order
         self.state_epoch = 0      # bumped whenever the state tensors are replaced (load_state_dict): a captured step
                                   # holds raw pointers to exp_avg / exp_avg_sq (train.GraphedStep drops its captures)
@@ -89,6 +90,7 @@ class FusedAdam(torch.optim.Optimizer):
                     t.g = g.data_ptr()
                     t.neg_step_size, t.bc2_sqrt = v
             if ok:
+                self.plan_hits += 1
                 for a in plan["launches"]:
                     self._fill_groups(a)
                     call("nudf_adam_step", a)

@@ -36,12 +36,29 @@ def test_fused_adam_matches_torch_adam():
     torch.cuda.synchronize()
     for a, b in zip(ref_p, new_p):
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), a.shape
+    # repeat steps reuse the filled launch descriptors (round 5): every step but the first and the one the frozen parameter joined
+    assert new.plan_hits == 10, new.plan_hits
+    # ... and a state reload (new state tensors) must drop them: one more step after load_state_dict on both sides
+    new.load_state_dict(new.state_dict())
+    ref.load_state_dict(ref.state_dict())
+    for a, b in zip(ref_p, new_p):
+        gr = torch.randn(a.shape, generator=g).to(dev) * 1e-2
+        a.grad, b.grad = gr.clone(), gr.clone()
+    ref.step()
+    new.step()
+    assert new.plan_hits == 10
+    new.step()
+    ref.step()
+    assert new.plan_hits == 11
+    torch.cuda.synchronize()
+    for a, b in zip(ref_p, new_p):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), a.shape
     # state interchange with torch.optim.Adam checkpoints
     sd = new.state_dict()
     ref2 = torch.optim.Adam(groups([p.detach().clone().requires_grad_(True) for p in new_p]), lr=5e-4)
     ref2.load_state_dict(sd)
-    assert int(ref2.state[ref2.param_groups[0]["params"][0]]["step"]) == 12
-    assert int(ref2.state[ref2.param_groups[1]["params"][0]]["step"]) == 8
+    assert int(ref2.state[ref2.param_groups[0]["params"][0]]["step"]) == 14
+    assert int(ref2.state[ref2.param_groups[1]["params"][0]]["step"]) == 10
 
 
 def test_fused_adam_invalidates_packed_weight_cache():
