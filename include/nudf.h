@@ -144,9 +144,10 @@ int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);
 /* floats of workspace this group needs (0 for an empty group, < 0 on an invalid one) */
 int64_t nudf_gemm_tn_grouped_workspace(const NudfGemmTNGroup* args);
 /* the launch plan, for tests (host code only): out[4 b ..] = {problem, tile row * 256 + tile column, row chunk, workspace
- * slot} of workgroup b; returns the number of workgroups (at most `capacity` are written), < 0 on an invalid group.
- * Workgroups b and b' with b % 8 == b' % 8 run on the same XCD: the tiles of a problem that read the same row chunk are
- * given the same b % 8 (while the chunk count allows). */
+ * slot} of workgroup b, or {-1, -1, -1, -1} for a HOLE (a workgroup that exits at once); returns the number of workgroups
+ * LAUNCHED (at most `capacity` are written), < 0 on an invalid group.  Workgroups b and b' with b % 8 == b' % 8 run on the
+ * same XCD: the tiles of a problem that read the same row chunk are given the same b % 8 -- every chunk, the holes are what
+ * that costs -- and no XCD receives more live workgroups than it holds at once (64). */
 int nudf_gemm_tn_grouped_plan(const NudfGemmTNGroup* args, int32_t* out, int capacity);
 /* tuning / measurement bits, returns the old value: 2 = drop the epilogue (TIMING ONLY: results are discarded), 4 = skip
  * the bias sums, 8 = ignore the workspace (atomics), 16 = equal row chunks for every tile instead of the cost-weighted
