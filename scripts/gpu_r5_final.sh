@@ -33,7 +33,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + "/pmc_busy/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         n = row["Kernel_Name"]
-        if "mlp_chain" in n or "gemm_tn_group" in n:
+        if "mlp_chain" in n or "gemm_tn" in n:
             agg[n.split("(")[0][:48]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(O + "/pmc_mfma_busy.txt", "w") as out:
     out.write("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (bench.py --steps 4 --warmup 2 --graph 0), per dispatch means;\n"

@@ -77,3 +77,32 @@ def test_launch_is_deterministic_and_independent_of_the_xcd_order():
                 assert torch.equal(c0, c1) and torch.equal(d0, d1)
     finally:
         mlp.set_precision(old)
+
+
+def test_operands_past_2_gib_take_the_flat_path_for_the_early_chunks():
+    """the steady state of the bf16x3 kernel reads through BUFFER descriptors (32-bit byte counts): a row chunk whose operand
+    tail is >= 2 GiB must stay on the flat-address staging (same values), later chunks of the same launch use the descriptors."""
+    from neuraludf_amd import mlp
+    dev = torch.device("cuda:0")
+    old = mlp.PRECISION
+    mlp.set_precision("bf16x3")
+    try:
+        M, N = 2_200_000, 256                      # 2 200 000 x 256 x 4 B = 2.25 GB per operand
+        g = torch.Generator(device=dev).manual_seed(3)
+        A = torch.randn(M, N, device=dev, generator=g)
+        B = torch.randn(M, N, device=dev, generator=g) * 0.05
+        C = torch.zeros(N, N, device=dev)
+        db = torch.zeros(N, device=dev)
+        mlp.gemm_tn_grouped([(A, N, B, N, C, db)], M, assign=True)
+        torch.cuda.synchronize()
+        ref = torch.zeros(N, N, device=dev, dtype=torch.float64)
+        refb = torch.zeros(N, device=dev, dtype=torch.float64)
+        for r0 in range(0, M, 200_000):
+            a = A[r0:r0 + 200_000].double()
+            ref += a.t() @ B[r0:r0 + 200_000].double()
+            refb += a.sum(0)
+        scale = float(ref.abs().max())
+        assert float((C.double() - ref).abs().max()) <= 2e-5 * scale
+        assert float((db.double() - refb).abs().max()) <= 2e-5 * float(refb.abs().max() + 1.0)
+    finally:
+        mlp.set_precision(old)
