@@ -1167,9 +1167,12 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
   // row clamp, a 64-bit multiply-add and a 64-bit shift-add per element (4 VALU operations per 4-byte load, 128 per thread and
   // step -- as many as the split), and hipcc, recycling those address registers, put an s_waitcnt vmcnt(0) in front of every
   // step's requests: the "two steps ahead" prefetch waited for the previous step's rows first.  Here a step's rows start at a
-  // wave-uniform base (SGPR pairs formed by the scalar unit) and a thread's only address register is its column offset: a
-  // load is ONE instruction (global_load_dword v, v_col, s[row base]), no vector address arithmetic, nothing to wait for; full
-  // steps also need no row-validity selects in the split.  Same values, same order: C and dbias are unchanged bit for bit.
+  // wave-uniform offset formed by the scalar unit and a thread's only address register is its column offset: a load is ONE
+  // instruction (buffer_load_dword v, v_col, s[descriptor], s_row offen; NUDF_TN3_BUFLOAD), no vector address arithmetic, nothing
+  // to wait for; full steps also need no row-validity selects in the split.  (The first form of this loop used flat loads from
+  // `base + r * ld`: hipcc kept those bases in VECTOR registers -- a chain of 30 v_lshl_add_u64 per step, still 39 % fewer VALU
+  // operations than the generic staging; the descriptor form is the one without any.)  Same values, same order: C and dbias are
+  // unchanged bit for bit.
   int kt0 = 0;
 #if NUDF_TN3_STAMPS     // tuning build (scripts/tn3_phases.py): shader-clock ticks of waves 0 / 3 per segment of the pipelined steps
   long long tk_load = 0, tk_mma = 0, tk_bar1 = 0, tk_store = 0, tk_bar2 = 0;

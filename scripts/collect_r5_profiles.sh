@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 F=gpurun_out/r5final; P=profiles
 last() { python3 -c "import sys;ls=[l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')];print(ls[-1])" "$1"; }
-if [ -f $F/bench_rerun_2.json ]; then last $F/bench_rerun_2.json > $P/r05_bench_final.json; last $F/bench_rerun_1.json > $P/r05_bench_final_run1.json; else last $F/bench.json > $P/r05_bench_final.json; fi
+last $F/bench.json > $P/r05_bench_final.json
 last $F/bench_eager.json > $P/r05_bench_final_eager.json
 last $F/bench_256.json > $P/r05_bench_256rays.json
 last $F/bench_fp32_exact.json > $P/r05_bench_fp32_exact.json
