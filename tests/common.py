@@ -130,3 +130,79 @@ def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, to
             assert float((w_hip[r, :m] - w_ref[r, :m]).abs().max()) <= tol if m > 0 else True
             ties.append((r, m, k, float(tc[r, m])))
     return ~rays, ties
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+# gradient parity: TRUE relative error per tensor ("gradients of the loss w.r.t. every parameter to 1e-3 rel")
+# --------------------------------------------------------------------------------------------------------------------- #
+def grel(a, b):
+    """max|a - b| / max|b| -- no floor at 1: a mean-reduced loss leaves most gradient tensors far below 1, where a clamp
+    would turn the bound into an absolute one (an all-zero gradient would pass)."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def grel2(a, b):
+    """||a - b||_2 / ||b||_2 -- one cancelling element cannot hide a tensor, one large element cannot carry it."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+_EREF = None
+
+
+def eref(case):
+    """tests/golden/ref_eref.json (make_golden_eref.py): per gradient tensor of a reference fixture, the fp32 REFERENCE's own
+    distance from the float64 evaluation of the same loss on the same inputs."""
+    global _EREF
+    if _EREF is None:
+        import json
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_eref.json")) as f:
+            _EREF = json.load(f)
+    return _EREF[case]["tensors"]
+
+
+def param_grads_vs_reference(mods, fx, case, nets=("udf", "color", "var", "beta"), gtol=1e-3, absent_must_be_zero=True,
+                             slack=None):
+    """Every parameter gradient of `mods` against the reference's (`fx['grad_<net>_<name>']`, produced by loss.backward()
+    in the reference, /root/reference/exp_runner_blending.py:367-375), TRUE relative per tensor in the max norm AND in the
+    2-norm:   err < max(gtol, 3 * e_ref32)   where e_ref32 is the fp32 reference's own distance from float64 for that tensor
+    and norm (`eref(case)`).  `slack`: {key: bar} for documented discontinuities (a trimmed loss dropping a whole ray).
+    Returns a report: worst (key, inf, l2, bar) per network, tensor / float counts, and for tensors of <= 4 elements the
+    error against the float64 value itself."""
+    er = eref(case)
+    rep = {"n": 0, "floats": 0, "worst": {}, "vs64": {}}
+    for net in nets:
+        worst = None
+        for pn, p in mods[net].named_parameters():
+            key = f"grad_{net}_{pn}"
+            if key not in fx:
+                if absent_must_be_zero:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, key
+                continue
+            assert p.grad is not None, key
+            e = er[key]
+            ri, r2 = grel(p.grad, fx[key]), grel2(p.grad, fx[key])
+            bi = max(gtol, 3.0 * e["inf"], (slack or {}).get(key, 0.0))
+            b2 = max(gtol, 3.0 * e["l2"], (slack or {}).get(key, 0.0))
+            rep["n"] += 1
+            rep["floats"] += p.grad.numel()
+            if worst is None or ri / bi > worst[1] / worst[3]:
+                worst = (key, ri, r2, bi)
+            if "g64" in e:
+                g64 = torch.tensor(e["g64"], dtype=torch.float64).reshape(p.grad.shape)
+                rep["vs64"][key] = (grel(p.grad, g64), e["inf"])
+            assert ri < bi, (key, "max-norm relative", ri, "bar", bi, "reference fp32 vs fp64", e["inf"], "|g|max", e["ninf"])
+            assert r2 < b2, (key, "2-norm relative", r2, "bar", b2, "reference fp32 vs fp64", e["l2"])
+        if worst is not None:
+            rep["worst"][net] = worst
+    return rep
+
+
+def grad_report(rep):
+    w = "; ".join(f"{net}: {k} inf {ri:.2e} l2 {r2:.2e} (bar {b:.1e})" for net, (k, ri, r2, b) in rep["worst"].items())
+    v = "; ".join(f"{k} vs float64 {a:.2e} (reference fp32 vs float64 {b:.2e})" for k, (a, b) in rep["vs64"].items())
+    return f"{rep['n']} parameter-gradient tensors ({rep['floats']} floats), TRUE relative worst per network -- {w}.  {v}"

@@ -17,7 +17,8 @@ import numpy as np
 import pytest
 import torch
 
-from common import build_modules, perturb_, state_dicts, checksum, oracle_nets, weights_vs_reference_up_to_ties
+from common import (build_modules, perturb_, state_dicts, checksum, oracle_nets, weights_vs_reference_up_to_ties,
+                    param_grads_vs_reference, grad_report)
 from oracle import udf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -89,21 +90,9 @@ def test_cfg2_render_core_and_all_parameter_gradients_vs_reference(dev, setup, t
     # ... which is why its INPUT is held to an absolute bound beside it (measured 1.6e-6 = a few fp32 ulp of a udf ~ 1)
     assert float((out["udf"].detach().cpu() - torch.from_numpy(fx["out_udf"])).abs().max()) < 4e-6
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
-    worst, n = ("", 0.0), 0
-    for net in ("udf", "color", "var", "beta"):
-        for pn, p in mods[net].named_parameters():
-            key = f"grad_{net}_{pn}"
-            if key not in fx:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, key
-                continue
-            assert p.grad is not None, key
-            r = rel(p.grad, fx[key])
-            n += 1
-            if r > worst[1]:
-                worst = (key, r)
-            assert r < GTOL, (key, r)
-    assert n >= 50
-    print(f"cfg2 full size (tile {tile}): {n} parameter gradients vs the reference, worst {worst[0]} {worst[1]:.2e}")
+    rep = param_grads_vs_reference(mods, fx, "cfg2", gtol=GTOL)
+    assert rep["n"] >= 50
+    print(f"cfg2 full size (tile {tile}): {grad_report(rep)}")
 
 
 def test_shipped_dtu_sampling_with_background_nerf_vs_reference(dev):
@@ -135,22 +124,9 @@ def test_shipped_dtu_sampling_with_background_nerf_vs_reference(dev):
         assert rel(out[k], fx["out_" + k]) < (2e-3 if k == "sparse_error" else VTOL), k
     assert float((out["udf"].detach().cpu() - torch.from_numpy(fx["out_udf"])).abs().max()) < 4e-6   # sparse_error's input
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
-    worst, n, floats = ("", 0.0), 0, 0
-    for net in ("udf", "color", "var", "beta", "nerf"):
-        for pn, p in mods[net].named_parameters():
-            key = f"grad_{net}_{pn}"
-            if key not in fx:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, key
-                continue
-            assert p.grad is not None, key
-            r = rel(p.grad, fx[key])
-            n += 1
-            floats += p.grad.numel()
-            if r > worst[1]:
-                worst = (key, r)
-            assert r < GTOL, (key, r)
-    assert n >= 80 and floats == 1291482
-    print(f"shipped DTU sampling, full size: {n} parameter gradients ({floats} floats) vs the reference, worst {worst[0]} {worst[1]:.2e}")
+    rep = param_grads_vs_reference(mods, fx, "dtu_shipped", nets=("udf", "color", "var", "beta", "nerf"), gtol=GTOL)
+    assert rep["n"] >= 80 and rep["floats"] == 1291482
+    print(f"shipped DTU sampling, full size: {grad_report(rep)}")
 
 
 def test_cfg5_shape_fp32_vs_reference(dev):
@@ -185,23 +161,13 @@ def test_cfg5_shape_fp32_vs_reference(dev):
         assert rel(out[k], fx["out_" + k]) < (2e-3 if k == "sparse_error" else VTOL), k
     assert rel(out["depth"].detach().cpu()[ok], torch.from_numpy(fx["out_depth"])[ok]) < VTOL
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
-    worst, n = ("", 0.0), 0
-    for net in ("udf", "color", "var", "beta"):
-        for pn, p in mods[net].named_parameters():
-            key = f"grad_{net}_{pn}"
-            if key not in fx:
-                continue
-            r = rel(p.grad, fx[key])
-            n += 1
-            if r > worst[1]:
-                worst = (key, r)
-            assert r < GTOL, (key, r)
-    assert n >= 50
-    print(f"cfg5 shape (fp32, P = 262 144): rays with a true_cos tie (ray, tie sample, first differing weight, true_cos) {ties} of 1024; {n} parameter "
-          f"gradients vs the reference, worst {worst[0]} {worst[1]:.2e}")
+    rep = param_grads_vs_reference(mods, fx, "cfg5_shape", gtol=GTOL, absent_must_be_zero=False)
+    assert rep["n"] >= 50
+    print(f"cfg5 shape (fp32, P = 262 144): rays with a true_cos tie (ray, tie sample, first differing weight, true_cos) {ties} of 1024; "
+          f"{grad_report(rep)}")
 
 
-def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays):
+def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays, case):
     from common import smooth_images
     from neuraludf_amd import synth
     from neuraludf_amd.loss.loss import ColorLoss
@@ -256,21 +222,12 @@ def _cfg3_blending_vs_reference(dev, fixture, scene_kind, n_rays):
         assert r < (1.5e-4 if k in ("color_pixel", "patch_colors") else VTOL), (k, r)     # worst measured 7e-5
     for k in ("loss", "color_base_loss", "color_loss", "color_pixel_loss", "color_patch_loss"):
         assert abs(float(cl[k]) - float(fx["closs_" + k])) < 2e-4 * max(1.0, abs(float(fx["closs_" + k]))), k
-    worst, n = ("", 0.0), 0
-    for net in ("udf", "color", "var", "beta"):
-        for pn, p in mods[net].named_parameters():
-            key = f"grad_{net}_{pn}"
-            if key not in fx:
-                continue
-            r = rel(p.grad, fx[key])
-            n += 1
-            if r > worst[1]:
-                worst = (key, r)
-            assert r < 2e-3, (key, r)          # the trimmed patch loss drops / keeps whole rays: one flipped ray is ~1e-3
-    assert n >= 50
+    # the trimmed patch loss (loss/loss.py:79-84) drops / keeps WHOLE rays: one ray on the other side of the trimming
+    # quantile moves the colour network's gradients by ~1e-3 of their norm -- the bar of this case is 2e-3
+    rep = param_grads_vs_reference(mods, fx, case, gtol=2e-3, absent_must_be_zero=False)
+    assert rep["n"] >= 50
     print(f"cfg3 mix + blending, {n_rays} rays, scene '{scene_kind}' ({scene.H} x {scene.W}): rays with a flipped alpha selection "
-          f"{n_flip}, patch-mask agreement {agree:.4f}, "
-          f"worst value {worst_v[0]} {worst_v[1]:.2e}, {n} parameter gradients vs the reference, worst {worst[0]} {worst[1]:.2e}")
+          f"{n_flip}, patch-mask agreement {agree:.4f}, worst value {worst_v[0]} {worst_v[1]:.2e}; {grad_report(rep)}")
 
 
 def test_cfg3_mix_sampling_and_blending_vs_reference(dev):
@@ -278,7 +235,7 @@ def test_cfg3_mix_sampling_and_blending_vs_reference(dev):
     pixel + patch blending over 8 source views with 7 x 7 patches and the full ColorLoss (L1 terms + trimmed SSIM patch
     loss) -- on the reference's own sample positions (fixture ref_cfg3_blend_full.npz, make_golden_full.py cfg3_blend):
     outputs incl. the blended pixel / patch colours, the loss terms, and all parameter gradients."""
-    _cfg3_blending_vs_reference(dev, "ref_cfg3_blend_full.npz", "tiny", 512)
+    _cfg3_blending_vs_reference(dev, "ref_cfg3_blend_full.npz", "tiny", 512, "cfg3_blend")
 
 
 def test_cfg3_garment_geometry_1024_rays_vs_reference(dev):
@@ -287,7 +244,7 @@ def test_cfg3_garment_geometry_1024_rays_vs_reference(dev):
     and the bilinear taps at pixel coordinates ~1e3 -- against the reference's own run (fixture ref_cfg3_garment_full.npz,
     make_golden_full.py cfg3_garment; the 100 MB of source images are regenerated from the seed), same tolerances as the
     512-ray / 96 x 128 case above."""
-    _cfg3_blending_vs_reference(dev, "ref_cfg3_garment_full.npz", "garment", 1024)
+    _cfg3_blending_vs_reference(dev, "ref_cfg3_garment_full.npz", "garment", 1024, "cfg3_garment")
 
 
 def test_cfg2_end_to_end_matching_rays_and_first_divergence(dev, setup):
@@ -499,18 +456,8 @@ def test_bench_inputs_vs_reference_fixture(dev):
         assert rel(out[k], fx["out_" + k]) < VTOL, k
     assert rel(out["depth"].detach().cpu()[ok], torch.from_numpy(fx["out_depth"])[ok]) < VTOL
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * max(1.0, abs(float(fx["loss"])))
-    worst, n = ("", 0.0), 0
-    for net in ("udf", "color", "var", "beta"):
-        for pn, p in mods[net].named_parameters():
-            key = f"grad_{net}_{pn}"
-            if key not in fx or p.grad is None:
-                continue
-            r = rel(p.grad, fx[key])
-            n += 1
-            if r > worst[1]:
-                worst = (key, r)
-            assert r < GTOL, (key, r)
-    assert n >= 50
+    rep = param_grads_vs_reference(mods, fx, "bench_cfg2", gtol=GTOL, absent_must_be_zero=False)
+    assert rep["n"] >= 50
     with torch.no_grad():
         e2e = rend.render(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], cos_anneal_ratio=1.0, perturb_overwrite=0,
                           flip_saturation=1.0)
@@ -524,6 +471,6 @@ def test_bench_inputs_vs_reference_fixture(dev):
     c_good = rel(e2e["color"][good.to(dev)], torch.from_numpy(fx["out_color"])[good])
     assert c_close < VTOL, c_close
     assert c_good < 1.5 * VTOL, c_good
-    print(f"bench inputs vs the reference: {n} parameter gradients, worst {worst[0]} {worst[1]:.2e}; rays with a true_cos "
+    print(f"bench inputs vs the reference: {grad_report(rep)}; rays with a true_cos "
           f"tie {ties}; end to end {int(close.sum())} / 512 rays with samples within 1e-5 (colour {c_close:.1e}), "
           f"{int(good.sum())} within 1e-4 (colour {c_good:.1e})")
