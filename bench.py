@@ -5,6 +5,7 @@ path (render + colour/eikonal loss + backward + Adam) on synthetic DTU-scan24-sh
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: bench.py starts the N ranks itself through torch.distributed.run)
 
 Workload (BASELINE.json configs[1]): 512 rays x 128 samples per GPU (64 coarse + 64 hierarchical in
 4 rounds, no outside samples); arithmetic: fp32 EMULATED on the bf16 matrix pipe (`--precision bf16x3`, the default; `fp32`
@@ -21,7 +22,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                   fp32 product): executed flops = 6 x 2 M N K against the dense bf16 peak 2.5 PFLOP/s, with the
                   fp32-equivalent rate beside the 157.3 TFLOP/s of the fp32 MFMA pipe (`--precision fp32`: the exact
                   v_mfma_f32_32x32x2_f32 kernels against 157.3); traffic = HBM bytes per launch from the committed rocprofv3
-                  PMC passes over this command (profiles/r04_traffic_mlp_chain_bf16x3.json).
+                  PMC passes over this command (profiles/r06_traffic_mlp_chain_<mode>.json, see `traffic_stale`).
   roofline_composite -- the fused sample+composite kernels against the 8 TB/s HBM roof
                   (48 B/sample + 68 B/ray forward, 84 B/sample + 68 B/ray backward).
   cpu_baseline -- the reference's own classes (oracle/_ref/reference_tree, kind "reference"; the oracle's port when that
@@ -378,6 +379,22 @@ def cpu_baseline(workload, seconds_budget=25.0, dev=None, precision="fp32", n_ra
     return res, psnr
 
 
+def _self_launch(n):
+    """re-run this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`;
+    -> the launcher's exit code.  The children inherit stdout / stderr, so rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,6 +425,16 @@ def main():
                          "mixed16 = BASELINE config 5 (16-bit MFMA operands, fp32 accumulate) -- never the headline")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU through
+    # torch.distributed.run on 127.0.0.1) and relay them -- rank 0 of the child job prints the JSON line.  Under a launcher
+    # (WORLD_SIZE set) the two must agree: a job that silently ran another number of ranks than it was asked for is an error.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(_self_launch(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"error": "--gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"])}))
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -668,6 +695,10 @@ def main():
                        "algorithmic_mb": by / 1e6, "gbs": by / t / 1e9, "frac_hbm": by / t / 1e9 / HBM_PEAK_GBS,
                        "binding": bind, "frac_of_binding_roof": max(t_mfma, t_hbm) / t})
         roof["per_kernel"] = pk
+        # every launch's algorithmic bytes (each operand / output array once), summed over the step: the saved state of the
+        # double backward is what the step moves (SURVEY 8(d) budgets no HBM bytes for the MLP class)
+        roof["hbm_gb_per_step"] = sum(e["algorithmic_mb"] for e in pk) / 1e3
+        roof["bytes_per_core_sample"] = sum(e["algorithmic_mb"] for e in pk) * 1e6 / (rays_per_gpu * s_core)
         # `bound` of the class = the roof that binds most of its launch time; the per-launch `binding` is the precise statement
         roof["bound"] = "hbm" if by_bind["hbm"] > by_bind["mfma"] else "mfma"
         roof["class_ms_by_binding_roof"] = {k: v * 1e3 for k, v in by_bind.items()}
@@ -678,6 +709,8 @@ def main():
         roof["traffic"] = pmc_traffic(dom, args.workload, precision)
         roof["traffic_source"] = getattr(pmc_traffic, "source", None) if roof["traffic"] else None
         if roof["traffic"]:
+            roof["traffic_stale"] = bool(getattr(pmc_traffic, "stale", True))
+            roof["traffic_recorded_on_source_digest"] = getattr(pmc_traffic, "recorded_on", None)
             roof["traffic_note"] = ("PMC passes are recorded beforehand over this command (rocprofv3 cannot wrap the timed "
                                     "process from inside); the file is keyed on workload + precision + round")
         if precision != "fp32" and roof["traffic"]:
@@ -780,13 +813,13 @@ def pmc_traffic(kernel, workload, precision="fp32"):
     timed process from inside, so the counters are collected beforehand; corrected as MI355X_MICROARCH.md
     prescribes and as calibrated in DESIGN.md section 5: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
     if (workload, precision) == ("dtu_scan24_512x128", "bf16x3"):
-        names = ["r%02d_traffic_%s_bf16x3.json" % (r, kernel) for r in (5, 4)]
+        names = ["r%02d_traffic_%s_bf16x3.json" % (r, kernel) for r in (6, 5, 4)]
     elif (workload, precision) == ("dtu_scan24_512x128", "fp32"):
         names = ["r%02d_traffic_%s.json" % (r, kernel) for r in (3, 2, 1)]
     elif (workload, precision) == ("dtu_scan24_1024x256", "mixed16"):
-        names = ["r%02d_traffic_%s_cfg5_mixed16.json" % (r, kernel) for r in (5, 3, 2)]
+        names = ["r%02d_traffic_%s_cfg5_mixed16.json" % (r, kernel) for r in (6, 5, 3, 2)]
     elif (workload, precision) == ("garment_blend_1024x128", "bf16x3"):
-        names = ["r05_traffic_%s_garment_bf16x3.json" % kernel]
+        names = ["r%02d_traffic_%s_garment_bf16x3.json" % (r, kernel) for r in (6, 5)]
     else:
         return None
     path = next((q for q in (os.path.join(ROOT, "profiles", nm) for nm in names) if os.path.exists(q)), None)
@@ -795,9 +828,14 @@ def pmc_traffic(kernel, workload, precision="fp32"):
     pmc_traffic.source = os.path.relpath(path, ROOT) + " (rocprofv3 PMC passes recorded beforehand, scripts/pmc_traffic.sh)"
     try:
         d = json.load(open(path))
+        from neuraludf_amd import build as _b
+        rec = d.get("_recorded_on") or {}
+        # recorded on other kernel sources than the ones this tree holds (or before round 6, when files carried no digest)
+        pmc_traffic.stale = rec.get("source_digest") != _b.source_digest(kernel)
+        pmc_traffic.recorded_on = rec.get("source_digest")
         f = w = n = 0
         for name, c in d.items():
-            if kernel not in name:
+            if kernel not in name or name.startswith("_"):
                 continue
             f += sum(c["FETCH_SIZE"]["list_KB"]) * c["FETCH_SIZE"]["n"] / max(1, len(c["FETCH_SIZE"]["list_KB"]))
             w += sum(c["WRITE_SIZE"]["list_KB"]) * c["WRITE_SIZE"]["n"] / max(1, len(c["WRITE_SIZE"]["list_KB"]))

@@ -26,7 +26,9 @@ const char* nudf_last_error(void);
  * term of render_core (:543-544) -- each a `.cpu()` sync in the middle of a step.  Here the caller hands the library ONE
  * int32 of device memory (zeroed by the caller); nudf_upsample ORs NUDF_STATUS_NONFINITE_SAMPLES into it when a new sample
  * is not finite, nudf_composite_fwd NUDF_STATUS_NONFINITE_RENDER when a ray's composited outputs (weight sum, depth, the two
- * colours) or one of the three renderer scalars / their parameters (inv_s, beta, gamma) are not, and nudf_step_loss_fwd
+ * colours) or one of the three renderer scalars / their parameters (inv_s, beta, gamma) are not, and nudf_step_loss_fwd /
+ * nudf_blend_loss_fwd (the fused single-process loss launches -- ONLY those: a ray-sharded job forms its loss from all-reduced
+ * sums outside the library, and its host loop looks at that scalar itself, neuraludf_amd/train.py Trainer.check_finite)
  * NUDF_STATUS_NONFINITE_LOSS when the step's total loss is not.  (The per-sample alphas and weights themselves cannot leave
  * [0, 1]: the reference's clips are hardware min / max here, which drop a NaN operand -- a NaN network output or parameter
  * therefore shows up in the colours, the scalars and the loss, which is where the bits look.)  Nothing on the device reads the word

@@ -19,6 +19,26 @@ SOURCES = ["nudf_api.hip", "gemm_f32_mfma.hip", "gemm_tn_f32_mfma.hip", "rays_em
            "blend.hip", "optim.hip", "mlp_chain.hip", "mlp_chain_rows.hip", "raybatch.hip"]
 
 
+# the sources that decide what a kernel class reads and writes (bench.py `roofline.traffic_stale`: a PMC traffic file under
+# profiles/ is only as good as the kernel it was recorded on)
+KERNEL_SOURCES = {
+    "mlp_chain": ["csrc/mlp_chain.hip", "csrc/mlp_chain_rows.hip", "csrc/mlp_chain_shared.h", "csrc/nudf_common.h",
+                  "../include/nudf.h", "mlp.py"],
+    "gemm_tn": ["csrc/gemm_tn_f32_mfma.hip", "csrc/nudf_common.h", "../include/nudf.h", "mlp.py"],
+    "composite": ["csrc/composite.hip", "csrc/nudf_common.h", "../include/nudf.h"],
+}
+
+
+def source_digest(kernel: str) -> str:
+    """sha256 (first 16 hex digits) over the source files of a kernel class, in a fixed order"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES.get(kernel, sorted(os.path.join("csrc", f) for f in os.listdir(CSRC))):
+        with open(os.path.join(HERE, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -98,4 +118,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--digest" in sys.argv:
+        print(source_digest(sys.argv[sys.argv.index("--digest") + 1]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

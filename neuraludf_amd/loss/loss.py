@@ -420,12 +420,20 @@ class ColorLoss(nn.Module):
                 and color.shape == gt_color.shape == color_base.shape == color_pixel.shape
                 and patch_colors.shape == gt_patch_colors.shape and not self.patch_func.data_parallel)
 
+    def prefill_constants(self, device):
+        """the device-resident constants this loss caches on first use (the SSIM Gaussian window), created now: called by
+        train.GraphedStep before a capture, inside which the host-to-device copy would be illegal"""
+        from .patch_metric import _win_cache, gaussian_window
+        key = (self.h_patch_size, str(device))
+        if key not in _win_cache:
+            _win_cache[key] = gaussian_window(self.h_patch_size).to(device)
+        return _win_cache[key]
+
     def blend_step_loss(self, color_base, color, gt_color, color_pixel, patch_colors, gt_patch_colors, patch_mask_raw,
                         weight_sum, sums, n_rays, w_dev):
-        from .patch_metric import PATCH_TYPES, _win_cache, gaussian_window
+        from .patch_metric import PATCH_TYPES, _win_cache
         key = (self.h_patch_size, str(color.device))
-        if key not in _win_cache:
-            _win_cache[key] = gaussian_window(self.h_patch_size).to(color.device)
+        self.prefill_constants(color.device)
         return _BlendStepLossFn.apply(color_base, color, color_pixel, gt_color, patch_colors, gt_patch_colors, patch_mask_raw,
                                       weight_sum, sums, n_rays, w_dev, _win_cache[key], PATCH_TYPES[self.patch_func.type], 0.3)
 

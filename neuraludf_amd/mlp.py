@@ -358,7 +358,8 @@ class ChainBuilder:
         else:
             mode = {"fp32": 0, "mixed16": 1, "bf16x3": 2}[PRECISION]
             t32 = self.c.tile_rows == 32 or (self.c.tile_rows != 64 and P <= 256 * 64)
-            if mode == 1 and not t32 and os.environ.get("NUDF_CHAIN_T16", "1") != "0":
+            roww = any(self.c.step[i].row_w for i in range(self.n))
+            if mode == 1 and not t32 and not roww and _chain_t16_now():
                 precs = {int(self.c.step[i].prec) for i in range(self.n)}
                 if len(precs) == 1 and precs <= {1, 2}:
                     mode = 4 if "TANGENT" in e else 3      # the 16-bit-tile kernel (one operand type in every step)
@@ -367,6 +368,15 @@ class ChainBuilder:
                  else "relu-backward" if e & {"MULMASK", "ADDMASK"} else "udf-forward" if "SOFTPLUS" in e
                  else "relu-forward")
         return "%s %s P=%d" % (kern, sweep, P)
+
+
+def _chain_t16_now():
+    """the library's CURRENT 16-bit-tile setting (env NUDF_CHAIN_T16 at load, nudf_set_chain_t16 afterwards): the setter
+    returns the old value, so set-and-restore reads it (host side only; used by the profiling labels)"""
+    L = _lib.lib()
+    old = int(L.nudf_set_chain_t16(1))
+    L.nudf_set_chain_t16(old)
+    return bool(old)
 
 
 # scratch of the weight-gradient GEMMs' deterministic two-pass reduction (every workgroup's partial tile, ~33 MB at the

@@ -178,7 +178,11 @@ def blend_and_composite(hps, pts, logits, weights, grad, rays_d, color_maps, w2c
         # (the same three roundings per element -- + 1, / 2, * (size - 1) -- on both columns at once: 4 launches, not 8)
         key = (W, H, str(rays_uv.device))
         if key not in _uv_scale:
-            _uv_scale[key] = torch.tensor([float(W - 1), float(H - 1)], dtype=torch.float32, device="cpu").to(rays_uv.device)
+            # device-side fills (no pageable host-to-device copy: the first use may sit inside a HIP-graph capture)
+            sc = torch.empty(2, dtype=torch.float32, device=rays_uv.device)
+            sc[0:1].fill_(float(W - 1))
+            sc[1:2].fill_(float(H - 1))
+            _uv_scale[key] = sc
         rays_uv.copy_((rays_uv + 1) / 2. * _uv_scale[key])
         ref_cam, src_cam = patch_cams if patch_cams is not None else patch_cameras(intrinsics[0], intrinsics, query_c2w,
                                                                                    torch.inverse(w2cs))

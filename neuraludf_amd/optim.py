@@ -77,7 +77,12 @@ class FusedAdam(torch.optim.Optimizer):
                 state = self.state
                 for (pp, gi, t), pa, st_step in zip(plan["entries"], plan["addr"], plan["steps"]):
                     g = pp.grad
-                    if g is None or pp.data_ptr() != pa or not g.is_contiguous() or state[pp]["step"] is not st_step:
+                    st = state[pp]
+                    # the descriptor holds raw addresses of the parameter AND of both moment tensors: a state tensor replaced
+                    # behind the optimizer's back (opt.state[p]["exp_avg"] = ..., module.to()) must not be written through
+                    if (g is None or pp.data_ptr() != pa or not g.is_contiguous() or st["step"] is not st_step
+                            or st["exp_avg"].data_ptr() != t.m or st["exp_avg_sq"].data_ptr() != t.v
+                            or g.dtype != torch.float32 or not g.is_cuda):
                         ok = False
                         break
                     k = (gi, float(st_step))
@@ -137,6 +142,8 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 g = p.grad
+                if g.dtype != torch.float32 or not g.is_cuda or p.dtype != torch.float32:
+                    raise NudfError("FusedAdam needs fp32 device parameters and gradients")
                 if not g.is_contiguous():
                     g = g.contiguous()
                     keep.append(g)

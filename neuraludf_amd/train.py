@@ -206,6 +206,11 @@ class GraphedStep:
         tr.renderer.sched_scalars = sc.dev[sc.SCHED:sc.SCHED + 2]
         tr.optimizer.dyn_base = sc.dev.data_ptr() + 4 * sc.ADAM
         tr.loss_weights().bind(sc.dev[sc.LOSSW:sc.LOSSW + LW_COUNT])
+        # constants the step caches on first use are created HERE, outside the capture (a pageable host-to-device copy is not
+        # capturable): normally the eager steps before the capture made them already; a (W, H) or patch size first seen by the
+        # captured step itself would otherwise abort the capture
+        if blend is not None:
+            tr.color_loss.prefill_constants(dev)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         # Python's cyclic collector stays OFF while the stream is capturing: a collection pass in there may free objects of
@@ -446,8 +451,31 @@ class Trainer:
         # the only sync of the loop) -- a run that went non-finite stops within that many iterations instead of silently
         # writing black images
         if self.status_every and iter_step % self.status_every == 0:
-            self.renderer.check_finite()
+            self.check_finite(loss)
         return loss, out, s
+
+    def check_finite(self, loss=None):
+        """renderer.check_finite(), agreed on by all ranks of a ray-sharded job: the status word is rank-local (a NaN on one
+        rank's rays), and a rank that raised alone would leave the others waiting in the next all-reduce until the RCCL
+        timeout.  The words are OR-ed (all-reduce MAX per bit) on the check iterations, then every rank raises together.
+        Which bits exist: the composite and up-sampling launches report on every path; the LOSS bit is set by the fused
+        single-process loss kernels (nudf_step_loss_fwd, nudf_blend_loss_fwd) only -- the ray-sharded loss is formed from
+        all-reduced sums by torch ops and is looked at here instead."""
+        if not self.data_parallel:
+            return self.renderer.check_finite()
+        import torch.distributed as dist
+        bits = self.renderer.status(clear=True)
+        if loss is not None and not bool(torch.isfinite(loss.detach()).all()):
+            from neuraludf_amd import _lib as _l
+            bits |= _l.STATUS_NONFINITE_LOSS
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dev = self.renderer._device()
+            t = torch.tensor([float((bits >> b) & 1) for b in range(3)], device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bits = sum(int(v) << b for b, v in enumerate(t.tolist()))
+        if bits:
+            from neuraludf_amd import _lib
+            raise FloatingPointError("NeuralUDF renderer (some rank of the ray-sharded job): " + _lib.status_text(bits))
 
     def _trainability_toggles(self, out, iter_step):
         """exp_runner_blending.py:352-358, evaluated on this iteration's render output like there: once the variance has

@@ -9,10 +9,14 @@ cd /tmp
 for set in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$set -o p -- "$@" > $OUT/$set.log 2>&1
 done
-python - "$K" "$OUT" <<'PY'
-import csv, glob, sys, collections, json
-K, OUT = sys.argv[1], sys.argv[2]
-res = {}
+python - "$K" "$OUT" "$R" <<'PY'
+import csv, glob, sys, collections, json, subprocess, hashlib
+K, OUT, R = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, R)
+from neuraludf_amd import build as _b
+# what the counters were recorded ON: bench.py compares the digest with the tree it runs from (`roofline.traffic_stale`)
+res = {"_recorded_on": {"kernel": K, "source_digest": _b.source_digest(K), "sources": _b.KERNEL_SOURCES.get(K),
+                        "so_sha256": hashlib.sha256(open(_b.LIB, "rb").read()).hexdigest()}}
 for f in sorted(glob.glob(OUT + "/*/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):

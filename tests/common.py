@@ -91,7 +91,7 @@ def smooth_images(v, h, w, seed=0):
     return imgs
 
 
-def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, tol=1e-4, tie=2e-5, max_rays=3):
+def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, tol=1e-4, tie=2e-5, max_rays=3, wrel=1e-4):
     """Compositing weights of ALL rays against the reference's, where the reference's own arithmetic is discontinuous:
     `vis_mask = (true_cos < 0.01)` (/root/reference/models/udf_renderer_blending.py:399-405) is a hard selection that
     switches a factor of the running visibility product between `1 - alpha_occ` and 1, i.e. the alpha of every LATER
@@ -109,6 +109,11 @@ def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, to
     rays = bad.any(dim=1)
     n = int(rays.sum())
     assert n <= max_rays, f"{n} rays differ from the reference's weights by > {tol}"
+    # ... and on the rays without such a difference the bound is RELATIVE to the largest weight present (weights of 128-256
+    # samples per ray are far below 1: `tol` alone would be loose there)
+    if n < w_hip.shape[0]:
+        wr = float((w_hip[~rays] - w_ref[~rays]).abs().max() / w_ref[~rays].abs().max().clamp(min=1e-12))
+        assert wr < wrel, f"weights on the tie-free rays: {wr:.2e} of the largest reference weight (bar {wrel})"
     ties = []
     if n:
         old = rend.diagnostics

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import build_modules, perturb_, state_dicts, oracle_nets
+from common import build_modules, perturb_, state_dicts, oracle_nets, grel
 from neuraludf_amd import synth
 from oracle import udf_oracle as O
 
@@ -80,10 +80,10 @@ def test_blend_stagewise(dev, with_bg):
     assert rel(pc, pc_ref) < 1e-4
     assert rel(pmk, pm_ref) < 1e-4
     ((cp * D(k1)).sum() + (pc * D(k2)).sum()).backward()
-    assert rel(lgd.grad, lg.grad) < 1e-3
-    assert rel(wd.grad, wr.grad) < 1e-3
+    assert grel(lgd.grad, lg.grad) < 1e-3
+    assert grel(wd.grad, wr.grad) < 1e-3
     if with_bg:
-        assert rel(bgd.grad, bgr.grad) < 1e-3
+        assert grel(bgd.grad, bgr.grad) < 1e-3
 
 
 def test_blend_image_layouts_agree(dev):
@@ -138,7 +138,7 @@ def test_ssim_patch_loss(dev):
         for k in ref:
             assert abs(float(out[k]) - float(ref[k])) < 1e-5 * max(1.0, abs(float(ref[k]))), k
         out["loss"].backward()
-        assert rel(pd.grad, pr.grad) < 1e-4
+        assert grel(pd.grad, pr.grad) < 1e-4
 
 
 @pytest.mark.parametrize("kind", ["l1", "ssd", "ncc"])
@@ -162,7 +162,7 @@ def test_patch_loss_types_l1_ssd_ncc(dev, kind):
         pd = pred.to(dev).requires_grad_(True)
         out = ColorPatchLoss(kind, hps)(pd, gt.to(dev), mask.clone().to(dev))
         out.backward()
-        assert rel(pd.grad, pr.grad) < 1e-4, (kind, hps)
+        assert grel(pd.grad, pr.grad) < 1e-4, (kind, hps)
     with pytest.raises(ValueError):
         ColorPatchLoss("huber", 3)
 

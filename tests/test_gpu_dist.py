@@ -137,6 +137,31 @@ def test_bench_two_rank_flow():
     assert "cpu_baseline" not in d
 
 
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """plain `python bench.py --gpus 2` (no torch.distributed.run in front, WORLD_SIZE unset): bench.py starts the two ranks
+    itself and relays rank 0's line -- it must not silently run one rank and print n_gpus 1.  And under a launcher whose
+    WORLD_SIZE disagrees with --gpus it exits non-zero with a JSON error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"NUDF_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rays-per-gpu", "64", "--windows", "2", "--no-power"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_rays"] == 128 and d["value"] > 0
+    assert d["collectives_per_step"] == {"all_reduce": 2.0, "all_gather": 0.0}
+    # a launcher that started another number of ranks than --gpus asks for: an error, not a mislabelled line
+    r = _run([os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], {"NUDF_DIST_BACKEND": "gloo"})
+    assert r.returncode != 0
+    err = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(err) == 1 and "error" in json.loads(err[0]), r.stdout[-1000:]
+
+
 def test_bench_two_rank_strong_scaling_flow():
     """`bench.py --scaling strong` ("global N fixed per config, rays sharded"; BASELINE configs[3] is 4096 global
     rays): 2 ranks on this GPU over the gloo test backend share a FIXED global batch -- the line says so, counts the global
