@@ -47,8 +47,11 @@ MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 (MI355X_MICROARCH.md)
 # parts; hi hi, hi mid, mid hi, hi lo, lo hi, mid mid; fp32 accumulate) -- the flops a launch EXECUTES on the bf16 pipe
 X3_PRODUCTS = 6
 DTYPE = {"fp32": "f32",
-         "bf16x3": "f32 emulated on the bf16 matrix pipe: operands split exactly into 3 bf16 parts, 6 bf16 MFMA products per "
-                   "f32 product, f32 accumulate (fp32-level accuracy, tests/test_gpu_bf16x3.py); f32 state, epilogues, optimizer",
+         "bf16x3": "f32 emulated on the 16-bit matrix pipe, f32 accumulate, f32 state / epilogues / optimizer: backward sweeps "
+                   "(tangent, adjoint, ReLU backward) and weight-gradient GEMMs bf16x3 (operands split exactly into 3 bf16 parts, "
+                   "6 bf16 MFMA products per f32 product); forward-order sweeps (UDF value, input gradient, colour / NeRF forward) "
+                   "f16x2 (x = hi + 2^-11 lo in fp16, 3 fp16 MFMA products, correction terms in their own accumulator); "
+                   "fp32-level accuracy against float64 in both (tests/test_gpu_bf16x3.py)",
          "mixed16": "f16/bf16 MFMA operands, f32 accumulate, bf16 saved state (config 5 mode)"}
 HBM_PEAK_GBS = 8000.0
 
@@ -565,7 +568,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None,
         "window_ms": [w / args.steps * 1e3 for w in wins], "windows": n_win,
-        "dtype": DTYPE[args.precision],
+        "dtype": (DTYPE[args.precision] if not (args.precision == "bf16x3" and mlp.FWD_F16X2 == "0") else
+                  "f32 emulated on the bf16 matrix pipe: operands split exactly into 3 bf16 parts, 6 bf16 MFMA products per f32 "
+                  "product on every sweep (NUDF_FWD_F16X2=0), f32 accumulate; f32 state, epilogues, optimizer"),
         "data": "synthetic",
         "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
@@ -624,39 +629,46 @@ def main():
         prof, mlp.PROFILE = mlp.PROFILE, None
         if rank != 0:
             return None
+        # flops the launches EXECUTE on the pipe they run on: algorithmic (2 M N K) for the fp32 and 16-bit modes; in the
+        # bf16x3 mode six bf16 MFMA products per fp32 product on the backward sweeps and the weight-gradient GEMMs (when they
+        # take split operands), THREE fp16 products on the forward-order sweeps that run the f16x2 split (mlp.FWD_F16X2) --
+        # every chain launch reports its own executed flops (mlp.MFMA_PRODUCTS by step), the GEMM class the factor below
+        x3 = precision == "bf16x3"
+        cls_factor = lambda k: (X3_PRODUCTS if x3 and (k != "gemm_tn" or mlp.TN_SPLIT) else 1)
         agg, per = {}, {}
-        for name, flops, s_ev, e_ev, detail, nbytes in prof:
+        for name, flops, s_ev, e_ev, detail, nbytes, xflops in prof:
             dur = s_ev.elapsed_time(e_ev) * 1e-3
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+            xf = (xflops if xflops is not None else flops * cls_factor(name)) if flops > 0 else 0.0
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += dur
-            b = per.setdefault(detail, [name, 0, 0.0, 0.0, 0.0])
+            a[3] += xf
+            b = per.setdefault(detail, [name, 0, 0.0, 0.0, 0.0, 0.0])
             b[1] += 1
             b[2] += flops
             b[3] += dur
             b[4] += nbytes
+            b[5] += xf
         mfma_cls = {k: v for k, v in agg.items() if v[1] > 0}          # (the HBM-bound classes carry units <= 0 there)
         dom = max(mfma_cls, key=lambda k: mfma_cls[k][2])
-        n, fl, sec = agg[dom]
-        # flops the launches EXECUTE on the pipe they run on: algorithmic (2 M N K) for the fp32 and 16-bit modes, six bf16
-        # products per fp32 product in the bf16x3 mode (weight-gradient GEMMs only when they take split operands)
-        x3 = precision == "bf16x3"
-        factor = {k: (X3_PRODUCTS if x3 and (k != "gemm_tn" or mlp.TN_SPLIT) else 1) for k in agg}
+        n, fl, sec, xfl = agg[dom]
+        factor = {k: (v[3] / v[1] if v[1] > 0 else 1) for k, v in agg.items()}      # executed / algorithmic, per class
         peak = MFMA_F32_PEAK_TFLOPS if precision == "fp32" else MFMA_F16_PEAK_TFLOPS
-        roof = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": factor[dom] * fl / sec / 1e12,
-                "peak": peak, "unit": "TFLOP/s", "frac": factor[dom] * fl / sec / 1e12 / peak,
+        roof = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": xfl / sec / 1e12,
+                "peak": peak, "unit": "TFLOP/s", "frac": xfl / sec / 1e12 / peak,
                 "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
                 "algorithmic_gflop_per_step": fl / 1e9, "executed_flops_per_algorithmic_flop": factor[dom],
                 # the convention of `achieved` / `frac`, in one key
-                "flops": ("executed on the bf16 matrix pipe (6 x the algorithmic 2 M N K of SURVEY 8(d))" if x3 else
-                          "algorithmic 2 M N K"),
+                "flops": ("executed on the 16-bit matrix pipe: 6 bf16 products per fp32 product on the backward sweeps (bf16x3), "
+                          "3 fp16 products on the forward-order sweeps (f16x2) -- %.2f x the algorithmic 2 M N K of SURVEY 8(d) "
+                          "over the class" % factor[dom] if x3 else "algorithmic 2 M N K"),
                 "frac_algorithmic_vs_fp32_pipe": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS}
         if x3:
             roof["what"] = (
-                "achieved = EXECUTED bf16 MFMA flops (6 x the algorithmic fp32 flops 2 M N K) / summed HIP-event time of the "
-                "class, against the dense bf16 peak; fp32_equivalent = the algorithmic flops per second, next to the 157.3 "
-                "TFLOP/s of the fp32 MFMA pipe this mode replaces")
+                "achieved = EXECUTED 16-bit MFMA flops (per launch: 6 x or 3 x its algorithmic fp32 flops 2 M N K) / summed "
+                "HIP-event time of the class, against the dense 16-bit peak; fp32_equivalent = the algorithmic flops per second, "
+                "next to the 157.3 TFLOP/s of the fp32 MFMA pipe this mode replaces")
             roof["fp32_equivalent"] = {"achieved": fl / sec / 1e12, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                                        "ratio": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
         cls_bytes = sum(b[4] for b in per.values() if b[0] == dom)
@@ -676,7 +688,7 @@ def main():
         # names the larger of the two floors, i.e. the roof that launch could at best run into.  HBM-bound classes
         # (composite, upsample, the blending gathers): algorithmic bytes against 8 TB/s and their unit rate.
         pk, by_bind = [], {"mfma": 0.0, "hbm": 0.0}
-        for detail, (name, cnt, f, t, by) in sorted(per.items(), key=lambda kv: -kv[1][3]):
+        for detail, (name, cnt, f, t, by, fxx) in sorted(per.items(), key=lambda kv: -kv[1][3]):
             if f <= 0:
                 unit = {"patch_blend": "taps", "pixel_blend": "taps"}.get(name, "samples")
                 pk.append({"kernel": detail, "class": name, "launches": cnt, "us": t * 1e6, "algorithmic_mb": by / 1e6,
@@ -684,7 +696,7 @@ def main():
                            "frac_of_binding_roof": by / t / 1e9 / HBM_PEAK_GBS, unit: -f, unit + "_per_s": -f / t})
                 continue
             # executed flops against the peak of the pipe the launch runs on (bf16x3 / mixed16: the dense 16-bit peak)
-            fx = f * factor.get(name, 1)
+            fx = fxx
             t_mfma, t_hbm = fx / (peak * 1e12), by / (HBM_PEAK_GBS * 1e9)
             bind = "hbm" if t_hbm > t_mfma else "mfma"
             if name == dom:
@@ -703,7 +715,7 @@ def main():
         roof["bound"] = "hbm" if by_bind["hbm"] > by_bind["mfma"] else "mfma"
         roof["class_ms_by_binding_roof"] = {k: v * 1e3 for k, v in by_bind.items()}
         kernels = {k: ({"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3, "tflops": v[1] / v[2] / 1e12,
-                        "executed_tflops": factor[k] * v[1] / v[2] / 1e12} if v[1] > 0 else
+                        "executed_tflops": v[3] / v[2] / 1e12} if v[1] > 0 else
                        {"launches": v[0], "ms": v[2] * 1e3})
                    for k, v in agg.items()}
         roof["traffic"] = pmc_traffic(dom, args.workload, precision)

@@ -544,7 +544,16 @@ typedef struct NudfChainStep {
                                       both operands split exactly into three bf16 parts (x = hi + mid + lo), the six
                                       products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid on v_mfma_f32_32x32x16_bf16
                                       with fp32 accumulation; the dropped terms are <= 2^-23 |x| |y| per product, the size
-                                      of one fp32 rounding (Bp: the three-plane layout of NudfPackFrag.dtype 3)     */
+                                      of one fp32 rounding (Bp: the three-plane layout of NudfPackFrag.dtype 3);
+                                      4 = f16x2: fp32 EMULATED on the fp16 matrix pipe with THREE products -- both operands
+                                      split into two fp16 parts, x = hi + 2^-11 lo (hi = fp16(x), lo = fp16((x - hi) 2^11):
+                                      11 + 11 significant bits, the low part pre-scaled into fp16's normal range),
+                                      acc0 += hi hi', acc1 += hi lo' + lo hi' on v_mfma_f32_32x32x16_f16, result
+                                      acc0 + 2^-11 acc1 (the correction terms in their own fp32 accumulator); dropped:
+                                      lo lo' <= 2^-22 |x| |y|.  For operands inside fp16's range (|x| < 65504; below
+                                      6e-5 the split keeps an ABSOLUTE resolution of ~3e-11): the forward-order sweeps
+                                      (encodings, activations, weight-normed weights), not the adjoints of the backward
+                                      (Bp: the two-plane layout of NudfPackFrag.dtype 4)                                */
   int32_t act_write;               /* 1: the outputs become the next step's activation tile          */
   int32_t act_col0;                /* ... at tile columns [act_col0, act_col0 + N)                   */
   int32_t pe_tail_col;             /* >= 0: afterwards write PE(x)*pe_tail_scale at these tile columns ...       */
@@ -640,7 +649,9 @@ typedef struct NudfPackFrag {
                                       v_mfma_f32_32x32x16_*: dst16[((g*NT + T)*64 + lane)*8 + j] =
                                       B[16g + 8(lane>>5) + j][32T + (lane&31)], round-to-nearest-even;
                                       3: bf16x3 split, three planes hi / mid / lo of that layout stored back to back per
-                                      (g, T): dst16[(((g*NT + T)*3 + plane)*64 + lane)*8 + j]  (3x the 16-bit size)   */
+                                      (g, T): dst16[(((g*NT + T)*3 + plane)*64 + lane)*8 + j]  (3x the 16-bit size);
+                                      4: f16x2 split, two fp16 planes hi = fp16(w), lo = fp16((w - hi) 2^11):
+                                      dst16[(((g*NT + T)*2 + plane)*64 + lane)*8 + j]  (2x the 16-bit size)            */
 } NudfPackFrag;
 typedef struct NudfPackLayer {
   const float* v; const float* g;  /* weight_v [out,in], weight_g [out] (NULL: plain Linear)                    */

@@ -499,6 +499,127 @@ __device__ __forceinline__ void ch_mma16x3(const float* __restrict__ arow, const
   if (g < G16) mfmas(pa[0], b[0]);   // odd number of 16-wide k steps
 }
 
+// f16x2 K loop (NudfChainStep.prec == 4): the fp32 product emulated on the fp16 matrix pipe with THREE products instead of
+// bf16x3's six (round 6: the matrix-heavy launches run against the 1 400 W package limit -- the lever is MFMA products per
+// fp32 product, not cycles).  x = hi + 2^-11 lo with hi = fp16(x), lo = fp16((x - hi) 2^11): fp16 carries 11 significant bits,
+// the remainder x - hi is exact in fp32 and at most half an ulp of hi, and scaled by 2^11 it sits in fp16's normal range
+// whenever hi does -- 22 bits + the sign of the remainder.  acc0 += hi hi' (exact products), acc1 += hi lo' + lo hi' (the
+// correction terms, in their OWN fp32 accumulator so that their scale never meets acc0's rounding), result acc0 + 2^-11 acc1
+// (Ootomo & Yokota's form); dropped: lo lo' <= 2^-22 |x| |y|.  Range: fp16's (|x| < 65504; below 6e-5 the parts go
+// denormal and the split keeps an absolute resolution of ~3e-11) -- the forward-order sweeps' operands (encodings in [-1, 1],
+// softplus / ReLU activations, weight-normed weights), not the 1e-6 ... 1e-9 adjoints of the backward sweeps, which stay
+// on bf16x3.  Weights: two fragment planes per (k step, column tile) from the pack kernel (NudfPackFrag.dtype 4), 4 B per
+// weight instead of 6.  Same geometry as ch_mma16x3: lane (i, h) contracts k = 16 g + 8 h .. + 7; per k step a wave issues
+// 3 NRT NCT MFMAs (384 matrix cycles for 2 x 2 tiles), 2 NCT weight loads, 2 NRT LDS reads and 2.5-4 VALU operations per
+// activation element (one packed conversion gives both high parts, the remainders are fp32 subtractions of the widened parts,
+// scaled, and converted once more).
+typedef _Float16 ch_f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ch_split2_pair(float x0, float x1, unsigned& p0, unsigned& p1) {
+  const ch_f16x2v hv = __builtin_convertvector(ch_f32x2v{x0, x1}, ch_f16x2v);
+  p0 = __builtin_bit_cast(unsigned, hv);
+  const float r0 = (x0 - (float)hv[0]) * 2048.0f;
+  const float r1 = (x1 - (float)hv[1]) * 2048.0f;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(ch_f32x2v{r0, r1}, ch_f16x2v));
+}
+__device__ __forceinline__ void ch_split2(const f32x4& lo4, const f32x4& hi4, f16x8& p0, f16x8& p1) {
+  uint4 a, b;
+  ch_split2_pair(lo4[0], lo4[1], a.x, b.x);
+  ch_split2_pair(lo4[2], lo4[3], a.y, b.y);
+  ch_split2_pair(hi4[0], hi4[1], a.z, b.z);
+  ch_split2_pair(hi4[2], hi4[3], a.w, b.w);
+  p0 = __builtin_bit_cast(f16x8, a);
+  p1 = __builtin_bit_cast(f16x8, b);
+}
+template <int NRT, int NCT, bool PIPE>
+__device__ __forceinline__ void ch_mma16x2(const float* __restrict__ arow, const uint4* __restrict__ bptr, size_t bstride2,
+                                           int G16, f32x16 (&acc)[2][2]) {
+  // bptr: this lane's uint4 of plane 0 (hi) of column tile ct0 in k step 0; the lo plane 64 uint4 on, column tiles 128, k
+  // steps bstride2 = 2 * NT * 64.
+  f32x4 raw[NRT][2];
+  f16x8 pa[2][NRT][2];
+  uint4 b[2][NCT][2];
+  f32x16 acc1[NRT][NCT];
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.0f;
+  auto lda = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+      raw[i][0] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16);
+      raw[i][1] = *reinterpret_cast<const f32x4*>(arow + i * 32 * CH_LD + g * 16 + 4);
+    }
+  };
+  auto ldb = [&](uint4 (&bb)[NCT][2], int g) {
+    const uint4* bq = bptr + (size_t)g * bstride2;
+#pragma unroll
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bb[j][pl] = bq[j * 128 + pl * 64];
+  };
+  auto split = [&](f16x8 (&q)[NRT][2]) {
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) ch_split2(raw[i][0], raw[i][1], q[i][0], q[i][1]);
+  };
+  auto mfmas = [&](const f16x8 (&q)[NRT][2], const uint4 (&bb)[NCT][2]) {
+    // the two correction products first (their accumulator), then hi hi'
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < NRT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+          const f16x8 av = (t == 1) ? q[i][1] : q[i][0];
+          const f16x8 bv = __builtin_bit_cast(f16x8, (t == 0) ? bb[j][1] : bb[j][0]);
+          if (t < 2) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc1[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[i][j], 0, 0, 0);
+        }
+  };
+  auto pattern = [&]() {
+    if constexpr (PIPE) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NRT, 0);     // the next step's LDS reads ...
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * NCT, 0);     // ... and weight loads first
+#pragma unroll
+      for (int m = 0; m < 3 * NRT * NCT; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (32 * NRT + 3 * NRT * NCT - 1) / (3 * NRT * NCT), 0);
+      }
+    }
+  };
+  const int gl = G16 - 1;
+  lda(0);
+  ldb(b[0], 0);
+  split(pa[0]);
+  int g = 0;
+#pragma unroll 1
+  for (; g + 2 <= G16; g += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    lda(min(g + 1, gl));
+    ldb(b[1], min(g + 1, gl));
+    if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);
+    mfmas(pa[0], b[0]);
+    split(pa[1]);
+    pattern();
+    __builtin_amdgcn_sched_barrier(0);
+    lda(min(g + 2, gl));
+    ldb(b[0], min(g + 2, gl));
+    if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);
+    mfmas(pa[1], b[1]);
+    split(pa[0]);
+    pattern();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (g < G16) mfmas(pa[0], b[0]);   // odd number of 16-wide k steps
+#pragma unroll
+  for (int i = 0; i < NRT; ++i)
+#pragma unroll
+    for (int j = 0; j < NCT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_fmaf(acc1[i][j][r], 1.0f / 2048.0f, acc[i][j][r]);
+}
+
 // 16-bit stored state, 4-point packed (ch_p4_off): the 16 accumulator rows of a lane are 4 groups of 4 consecutive
 // points = 4 accesses of 8 bytes.  q0 = the lane's first point quad (tile row 0 + 4 h) / 4, groups are 2 quads apart.
 typedef __bf16 ch_bf16x2 __attribute__((ext_vector_type(2)));
@@ -890,7 +1011,7 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
     }
   }
   if constexpr (X3 && CH_USES_X1(EPI)) {
-    if (st.prec == 3 && nrt * nct >= 2) {
+    if (st.prec >= 3 && nrt * nct >= 2) {
       if (nrt == 2 && nct == 2) ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
       else if (nrt == 2) ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
       else ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
@@ -1152,7 +1273,17 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
           const int col = (ct0 + j) * 32 + ln;
           pf.vo[i][j] = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) * (unsigned)st.ldx1 + (unsigned)((col < st.N) ? col : 0);
         }
-      if (X3 && st.prec == 3) {
+      if (X3 && st.prec == 4) {
+        const float* arow16 = act_f + (rt0 * 32 + ln) * CH_LD + 8 * h;
+        const uint4* bp2 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 128 + lane;
+        const size_t bstride2 = (size_t)NT * 128;
+        const int G16 = st.K >> 4;
+        constexpr bool PIPE2 = (NUDF_X3_PIPE == 1) || (NUDF_X3_PIPE == 2 && TM == 32);
+        if (nrt == 2 && nct == 2) ch_mma16x2<2, 2, PIPE2>(arow16, bp2, bstride2, G16, acc);
+        else if (nrt == 2) ch_mma16x2<2, 1, PIPE2>(arow16, bp2, bstride2, G16, acc);
+        else if (nct == 2) ch_mma16x2<1, 2, PIPE2>(arow16, bp2, bstride2, G16, acc);
+        else ch_mma16x2<1, 1, PIPE2>(arow16, bp2, bstride2, G16, acc);
+      } else if (X3 && st.prec == 3) {
         const float* arow16 = act_f + (rt0 * 32 + ln) * CH_LD + 8 * h;
         const uint4* bp3 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 192 + lane;
         const size_t bstride3 = (size_t)NT * 192;
@@ -1285,7 +1416,7 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   for (int i = 0; i < p.n_steps && !bad; ++i) {
     const NudfChainStep& s = p.step[i];
     bad = (s.K & 15) || s.K <= 0 || s.K > 288 || s.N <= 0 || s.N > 256 || (((uintptr_t)s.Bp) & 15) ||
-          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 3 ||
+          (s.act_write && s.act_col0 + ((s.N + 31) / 32) * 32 > 288) || s.prec < 0 || s.prec > 4 ||
           ((s.layout & NUDF_CH_STATE16) && s.epi != NUDF_CH_SOFTPLUS && s.epi != NUDF_CH_MULSP &&
            s.epi != NUDF_CH_TANGENT && s.epi != NUDF_CH_BWD) ||
           ((s.layout & NUDF_CH_P4_X1) && s.epi != NUDF_CH_MULMASK && s.epi != NUDF_CH_ADDMASK) ||
@@ -1299,12 +1430,12 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   bool any16 = false, any3 = false;
   for (int i = 0; i < p.n_steps; ++i) {
-    any3 = any3 || p.step[i].prec == 3;
-    any16 = any16 || (p.step[i].prec != 0 && p.step[i].prec != 3) ||
+    any3 = any3 || p.step[i].prec >= 3;        // the split modes (bf16x3, f16x2) share the MODE 2 instantiation
+    any16 = any16 || (p.step[i].prec != 0 && p.step[i].prec < 3) ||
             (p.step[i].layout & (NUDF_CH_STATE16 | NUDF_CH_P4_X1 | NUDF_CH_P4_C1));
   }
   if (any3 && any16) {
-    nudf_set_error("nudf_mlp_chain: bf16x3 steps (prec 3) do not mix with 16-bit steps / 16-bit stored state", hipErrorInvalidValue);
+    nudf_set_error("nudf_mlp_chain: split steps (prec 3 / 4) do not mix with 16-bit steps / 16-bit stored state", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
   }
   // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of

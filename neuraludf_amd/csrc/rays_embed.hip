@@ -492,6 +492,15 @@ __device__ __forceinline__ void frag_store(const NudfPackFrag& f, int o, int c, 
     d16[0] = __builtin_bit_cast(unsigned short, hi);
     d16[512] = __builtin_bit_cast(unsigned short, mid);
     d16[1024] = __builtin_bit_cast(unsigned short, lo);
+  } else if (f.dtype == 4) {
+    // f16x2 split fragments (NudfChainStep.prec 4): hi = fp16(w), lo = fp16((w - hi) 2^11); two planes back to back
+    const int g = k >> 4, r = k & 15;
+    const int lane = 32 * (r >> 3) + (n & 31);
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(f.dst) + ((size_t)(g * NT + (n >> 5)) * 2 * 64 + lane) * 8 + (r & 7);
+    d16[0] = __builtin_bit_cast(unsigned short, hi);
+    d16[512] = __builtin_bit_cast(unsigned short, lo);
   } else {   // 16-bit fragments of v_mfma_f32_32x32x16_{f16,bf16}
     const int g = k >> 4, r = k & 15;
     const int lane = 32 * (r >> 3) + (n & 31);
@@ -535,6 +544,21 @@ __device__ __forceinline__ void wnp_split8(const float (&w)[8], uint4& hi, uint4
              (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
   mid = uint4{(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16),
               (unsigned)m[4] | ((unsigned)m[5] << 16), (unsigned)m[6] | ((unsigned)m[7] << 16)};
+  lo = uint4{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
+             (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
+}
+
+__device__ __forceinline__ void wnp_split8_f16(const float (&w)[8], uint4& hi, uint4& lo) {
+  unsigned short h[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {          // the same two roundings as frag_store's dtype 4
+    const _Float16 a = (_Float16)w[j];
+    const _Float16 b = (_Float16)((w[j] - (float)a) * 2048.0f);
+    h[j] = __builtin_bit_cast(unsigned short, a);
+    q[j] = __builtin_bit_cast(unsigned short, b);
+  }
+  hi = uint4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+             (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
   lo = uint4{(unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16),
              (unsigned)q[4] | ((unsigned)q[5] << 16), (unsigned)q[6] | ((unsigned)q[7] << 16)};
 }
@@ -587,7 +611,9 @@ __global__ __launch_bounds__(WNP_THREADS) void wn_pack_multi_kernel(NudfPackMult
     const NudfPackFrag& f = L.frag[fi];
     const int NT = (f.N + 31) >> 5;
     uint4* d4 = reinterpret_cast<uint4*>(f.dst);
-    if (f.dtype == 3 && f.transpose) {
+    const bool split16 = f.dtype == 3 || f.dtype == 4;      // slot-built split kinds: np planes of 64 uint4 per (g, T)
+    const int np = (f.dtype == 3) ? 3 : 2;
+    if (split16 && f.transpose) {
       // k = c - i0 (8 consecutive columns of a row), n = row - o0
       const int Q = (f.K + 7) >> 3;
       for (int e = tid; e < WNP_ROWS * Q; e += WNP_THREADS) {
@@ -601,11 +627,16 @@ __global__ __launch_bounds__(WNP_THREADS) void wn_pack_multi_kernel(NudfPackMult
           w[j] = (k < f.K) ? panel[r * pw + f.i0 + k] : 0.0f;
         }
         uint4 hi, mid, lo;
-        wnp_split8(w, hi, mid, lo);
-        const size_t slot = ((size_t)((q >> 1) * NT + (n >> 5)) * 3) * 64 + 32 * (q & 1) + (n & 31);
-        d4[slot] = hi; d4[slot + 64] = mid; d4[slot + 128] = lo;
+        const size_t slot = ((size_t)((q >> 1) * NT + (n >> 5)) * np) * 64 + 32 * (q & 1) + (n & 31);
+        if (np == 3) {
+          wnp_split8(w, hi, mid, lo);
+          d4[slot] = hi; d4[slot + 64] = mid; d4[slot + 128] = lo;
+        } else {
+          wnp_split8_f16(w, hi, lo);
+          d4[slot] = hi; d4[slot + 64] = lo;
+        }
       }
-    } else if (f.dtype == 3 && (f.o0 & 7) == 0) {
+    } else if (split16 && (f.o0 & 7) == 0) {
       // k = row - o0 (8 consecutive rows of a column: row0 and o0 are multiples of 8), n = c - i0
       for (int e = tid; e < 4 * f.N; e += WNP_THREADS) {
         const int t = e / f.N, n = e - t * f.N;
@@ -615,9 +646,14 @@ __global__ __launch_bounds__(WNP_THREADS) void wn_pack_multi_kernel(NudfPackMult
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = (k0 + j < f.K) ? panel[(8 * t + j) * pw + f.i0 + n] : 0.0f;
         uint4 hi, mid, lo;
-        wnp_split8(w, hi, mid, lo);
-        const size_t slot = ((size_t)((k0 >> 4) * NT + (n >> 5)) * 3) * 64 + 32 * ((k0 >> 3) & 1) + (n & 31);
-        d4[slot] = hi; d4[slot + 64] = mid; d4[slot + 128] = lo;
+        const size_t slot = ((size_t)((k0 >> 4) * NT + (n >> 5)) * np) * 64 + 32 * ((k0 >> 3) & 1) + (n & 31);
+        if (np == 3) {
+          wnp_split8(w, hi, mid, lo);
+          d4[slot] = hi; d4[slot + 64] = mid; d4[slot + 128] = lo;
+        } else {
+          wnp_split8_f16(w, hi, lo);
+          d4[slot] = hi; d4[slot + 64] = lo;
+        }
       }
     } else {
       for (int e = tid; e < nrows * L.in; e += WNP_THREADS) {
@@ -638,8 +674,8 @@ extern "C" int nudf_weightnorm_pack_multi(const NudfPackMulti* args, void* strea
     blocks += (args->layer[i].out + WNP_ROWS - 1) / WNP_ROWS;
     in_max = max(in_max, args->layer[i].in);
     for (int f = 0; f < args->layer[i].nfrag; ++f)      // (the panel is addressed up to i0 + K - 1 <= in - 1)
-      if (args->layer[i].frag[f].dtype == 3 && (((uintptr_t)args->layer[i].frag[f].dst) & 15)) {
-        nudf_set_error("nudf_weightnorm_pack_multi: bf16x3 fragment buffers must be 16-byte aligned", hipErrorInvalidValue);
+      if ((args->layer[i].frag[f].dtype == 3 || args->layer[i].frag[f].dtype == 4) && (((uintptr_t)args->layer[i].frag[f].dst) & 15)) {
+        nudf_set_error("nudf_weightnorm_pack_multi: split (bf16x3 / f16x2) fragment buffers must be 16-byte aligned", hipErrorInvalidValue);
         return (int)hipErrorInvalidValue;
       }
   }

@@ -160,20 +160,24 @@ def gemm_nn(A, B, M, N, K, epi, C1=None, ldc1=0, C2=None, ldc2=0, C3=None, ldc3=
     call("nudf_gemm_nn", a)
 
 
+# MFMA products a chain step executes per fp32 product, by NudfChainStep.prec (0 fp32, 1 fp16, 2 bf16, 3 bf16x3, 4 f16x2)
+MFMA_PRODUCTS = {0: 1, 1: 1, 2: 1, 3: 6, 4: 3}
+
 # bench.py sets PROFILE = [] for one instrumented step: every GEMM launch is bracketed by HIP events on
 # the launch stream and recorded as (kernel, algorithmic flops, start, end)
 PROFILE = None
 
 
-def _timed(name, flops, fn, detail=None, nbytes=0.0):
+def _timed(name, flops, fn, detail=None, nbytes=0.0, xflops=None):
     """`detail`: which instantiation / sweep the launch is (bench.py's roofline.per_kernel); `nbytes`: the launch's
-    ALGORITHMIC HBM bytes (stored-state arrays it must read and write once), for the HBM side of its roofline."""
+    ALGORITHMIC HBM bytes (stored-state arrays it must read and write once), for the HBM side of its roofline; `xflops`: the
+    flops the launch EXECUTES on the matrix pipe (split modes: 6 or 3 MFMA products per fp32 product; None: the class's factor)."""
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
     s.record()
     fn()
     e.record()
-    PROFILE.append((name, flops, s, e, detail or name, nbytes))
+    PROFILE.append((name, flops, s, e, detail or name, nbytes, xflops))
 
 
 def call_timed(cls, detail, nbytes, name, *args, units=0.0):
@@ -242,6 +246,7 @@ class ChainBuilder:
         self.c.x_div = 1
         self.n = 0
         self.flops = 0.0
+        self.xflops = 0.0
         self.nbytes = 0.0          # algorithmic HBM bytes: every stored-state operand / output of every step, once
         self.epis = []
         self.blocked = False
@@ -322,7 +327,9 @@ class ChainBuilder:
         s.act_write, s.act_col0, s.pe_tail_col, s.pe_tail_scale = act_write, act_col0, pe_tail_col, pe_tail_scale
         s.scale, s.xscale = scale, xscale
         self.n += 1
-        self.flops += 2.0 * self.c.P * getattr(Bp, "k_true", K) * getattr(Bp, "n_true", N)
+        fl = 2.0 * self.c.P * getattr(Bp, "k_true", K) * getattr(Bp, "n_true", N)
+        self.flops += fl
+        self.xflops += fl * MFMA_PRODUCTS[int(s.prec)]
         if PROFILE is not None:
             n_true = getattr(Bp, "n_true", N)
             for t in (X1, X2, C1, C2, pe_dst):
@@ -336,7 +343,7 @@ class ChainBuilder:
         if CHAIN_DEBUG is not None:
             self.c.dbg = ptr(CHAIN_DEBUG)
         if PROFILE is not None:
-            _timed("mlp_chain", self.flops, lambda: call("nudf_mlp_chain", self.c), self._label(), self.nbytes)
+            _timed("mlp_chain", self.flops, lambda: call("nudf_mlp_chain", self.c), self._label(), self.nbytes, self.xflops)
         else:
             call("nudf_mlp_chain", self.c)
         self.keep = []
@@ -560,7 +567,15 @@ class PackedLinear:
 # infinite activation or weight comes out as NaN where the fp32 kernels propagate inf; both are non-finite, and the status
 # word (include/nudf.h: nudf_set_status_flag) reports either.  NUDF_PRECISION=fp32 selects the exact kernels.
 PRECISION = os.environ.get("NUDF_PRECISION", "bf16x3")
-_PREC = {"f32": 0, "f16": 1, "bf16": 2, "bf16x3": 3}
+_PREC = {"f32": 0, "f16": 1, "bf16": 2, "bf16x3": 3, "f16x2": 4}
+# bf16x3 mode, forward-order sweeps (UDF value, input gradient, colour / NeRF forward: encodings, softplus / ReLU activations,
+# seed-scaled weight rows and weight-normed weights -- all inside fp16's range): the fp32 product on THREE fp16 MFMA products
+# instead of six bf16 ones (NudfChainStep.prec = 4: x = hi + 2^-11 lo, the correction terms in their own accumulator).
+# The backward sweeps (tangent, adjoint, ReLU backward: 1e-6 ... 1e-9 adjoints, below fp16's normal range) and the
+# weight-gradient GEMMs stay on bf16x3.  Accuracy against float64 equals the exact fp32 kernels' (tests/test_gpu_bf16x3.py,
+# scripts/numerics/f16x2_emulation.py).  NUDF_FWD_F16X2=0 keeps bf16x3 everywhere (A/B); "grad" additionally keeps the
+# input-gradient reverse sweep on bf16x3.
+FWD_F16X2 = os.environ.get("NUDF_FWD_F16X2", "1")
 TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too
 
 
@@ -610,13 +625,26 @@ def set_precision(name):
     PRECISION = name
 
 
+def set_fwd_split(name):
+    """the forward-order sweeps of the bf16x3 mode: "1" (default) = f16x2 on value / colour / NeRF forward AND the
+    input-gradient sweep, "grad" = f16x2 on the forward sweeps only, "0" = bf16x3 everywhere.  -> the old setting."""
+    global FWD_F16X2
+    if str(name) not in ("0", "1", "grad"):
+        raise ValueError("forward split must be '0', '1' or 'grad'")
+    old, FWD_F16X2 = FWD_F16X2, str(name)
+    return old
+
+
 def _sweep_dtype(sweep):
-    """operand dtype of a sweep: 'fwd' (value / input-gradient / colour forward) or 'bwd' (tangent / adjoint)."""
+    """operand dtype of a sweep: 'fwd' (value / colour / NeRF forward), 'grad' (the input-gradient reverse sweep of the
+    forward pass: adjoints of the UDF VALUE, O(weights) in size) or 'bwd' (tangent / adjoint / ReLU backward of the loss)."""
     if PRECISION == "fp32":
         return "f32"
     if PRECISION == "bf16x3":
+        if FWD_F16X2 != "0" and (sweep == "fwd" or (sweep == "grad" and FWD_F16X2 != "grad")):
+            return "f16x2"
         return "bf16x3"
-    return "f16" if sweep == "fwd" else "bf16"
+    return "f16" if sweep in ("fwd", "grad") else "bf16"
 
 
 def _kind(base, sweep):
@@ -691,7 +719,7 @@ def pack_group(layers, kinds=None):
                 f = pl._frags.get(kind)
                 if f is None:
                     nfl = k8(K) // 8 * ((N + 31) // 32) * 256          # fp32 fragments; 16-bit ones take half
-                    f = torch.zeros({0: nfl, 3: 3 * (nfl // 2)}.get(dtype, nfl // 2), device=dev, dtype=torch.float32)
+                    f = torch.zeros({0: nfl, 3: 3 * (nfl // 2), 4: nfl}.get(dtype, nfl // 2), device=dev, dtype=torch.float32)
                     f.k_true, f.n_true, f.prec = K, N, dtype
                     pl._frags[kind] = f
                 F = L.frag[fi]
@@ -858,12 +886,12 @@ class UDFEngine:
             if l == self.L:      # the abs-head column (udf itself): fp32, or fp16 in the 16-bit mode (HEAD16)
                 ks = [_head_kind(), _kind("fwd_feat", "fwd"), _kind("bwd_feat", "bwd")]
             elif l in self.skip:
-                ks = [_kind("fwd", "fwd"), _kind("bwd", "fwd"), _kind("bwd_hid:%d" % self.layers[l - 1].out, "bwd")]
+                ks = [_kind("fwd", "fwd"), _kind("bwd", "grad"), _kind("bwd_hid:%d" % self.layers[l - 1].out, "bwd")]
                 if PRECISION != "fp32":
                     ks.append(_kind("fwd", "bwd"))
             else:
                 # forward value + tangent sweep use W^T ("fwd"), input-gradient + adjoint sweeps use W ("bwd")
-                ks = [_kind("fwd", "fwd"), _kind("bwd", "fwd")]
+                ks = [_kind("fwd", "fwd"), _kind("bwd", "grad")]
                 if PRECISION != "fp32":
                     ks += [_kind("fwd", "bwd"), _kind("bwd", "bwd")]
             kinds.append(tuple(ks))
@@ -936,14 +964,14 @@ class UDFEngine:
             pl = self.layers[l]
             if l in self.skip:
                 demb_skip = torch.empty(pad_rows(P), Epad, device=dev)
-                cb.step("MULSP", pl.frag(_kind("bwd", "fwd")), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], C2=demb_skip,
+                cb.step("MULSP", pl.frag(_kind("bwd", "grad")), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1], C2=demb_skip,
                         iparam=self.layers[l - 1].out, scale=self.inv_sqrt2, xscale=self._xs(l - 1))
             else:
-                cb.step("MULSP", pl.frag(_kind("bwd", "fwd")), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1],
+                cb.step("MULSP", pl.frag(_kind("bwd", "grad")), k8(pl.out), pl.inp, X1=X[l], C1=DA[l - 1],
                         xscale=self._xs(l - 1))
         demb0 = torch.empty(pad_rows(P), Epad, device=dev)
         pl0 = self.layers[0]
-        cb.step("NONE", pl0.frag(_kind("bwd", "fwd")), k8(pl0.out), pl0.inp, C1=demb0, act_write=0)
+        cb.step("NONE", pl0.frag(_kind("bwd", "grad")), k8(pl0.out), pl0.inp, C1=demb0, act_write=0)
         cb.launch()
         g = torch.empty(P, 3, device=dev)
         call("nudf_posenc_vjp", ptr(x), 3, net.d_in, net.multires, float(net.scale), P,

@@ -91,7 +91,8 @@ def smooth_images(v, h, w, seed=0):
     return imgs
 
 
-def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, tol=1e-4, tie=2e-5, max_rays=3, wrel=1e-4):
+def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, tol=1e-4, tie=2e-5, max_rays=3, wrel=1e-4,
+                                    udf_tie=1e-6):
     """Compositing weights of ALL rays against the reference's, where the reference's own arithmetic is discontinuous:
     `vis_mask = (true_cos < 0.01)` (/root/reference/models/udf_renderer_blending.py:399-405) is a hard selection that
     switches a factor of the running visibility product between `1 - alpha_occ` and 1, i.e. the alpha of every LATER
@@ -120,16 +121,22 @@ def weights_vs_reference_up_to_ties(rend, render_again, w_hip, w_ref, n_core, to
         rend.diagnostics = True
         try:
             with torch.no_grad():
-                tc = render_again()["true_cos"].detach().float().cpu().reshape(w_hip.shape[0], -1)
+                again = render_again()
+                tc = again["true_cos"].detach().float().cpu().reshape(w_hip.shape[0], -1)
+                ud = again["udf"].detach().float().cpu().reshape(w_hip.shape[0], -1)
         finally:
             rend.diagnostics = old
         for r in rays.nonzero().flatten().tolist():
             k = int(bad[r].float().argmax())                       # first differing weight
             upto = min(k, n_core - 1)
-            near = ((tc[r, :upto + 1] - 0.01).abs() < tie).nonzero().flatten().tolist()
+            # the second hard selection of the reference: udf = |v| (fields.py:184-190), so d udf / d x carries sign(v), and
+            # with it true_cos, flip_sign and the choice between alpha_plus and alpha_minus.  A sample ON the surface
+            # (|v| within the rounding noise of a 256-term fp32 sum, `udf_tie`) has an implementation-defined sign.
+            near = (((tc[r, :upto + 1] - 0.01).abs() < tie) | (ud[r, :upto + 1] < udf_tie)).nonzero().flatten().tolist()
             assert near, (f"ray {r}: weights differ from sample {k} on (max {float((w_hip[r] - w_ref[r]).abs().max()):.2e}) but no "
-                          f"true_cos within {tie} of the 0.01 threshold at or before it: "
-                          f"{[round(float(x), 6) for x in tc[r, max(0, upto - 3):upto + 1]]}")
+                          f"true_cos within {tie} of the 0.01 threshold and no udf below {udf_tie} at or before it: true_cos "
+                          f"{[round(float(x), 6) for x in tc[r, max(0, upto - 3):upto + 1]]} udf "
+                          f"{[float(x) for x in ud[r, max(0, upto - 3):upto + 1]]}")
             m = near[0]
             # everything in front of the tie agrees (by definition of k >= m this is every sample < m)
             assert float((w_hip[r, :m] - w_ref[r, :m]).abs().max()) <= tol if m > 0 else True

@@ -50,8 +50,11 @@ def test_chain_outputs_against_float64(dev):
         ref = O.udf_forward(n64.udf, x.double())
     gref = O.udf_gradient(n64.udf, x.double(), create_graph=False)
     res = {}
-    for mode in ("fp32", "bf16x3"):
-        mlp.set_precision(mode)
+    # "bf16x3": six bf16 products on every sweep (mlp.FWD_F16X2 = "0"); "f16x2": the library default -- the forward sweep
+    # and the input-gradient sweep on THREE fp16 products (NudfChainStep.prec 4)
+    for mode, prec, fwd in (("fp32", "fp32", "1"), ("bf16x3", "bf16x3", "0"), ("f16x2", "bf16x3", "1")):
+        mlp.set_precision(prec)
+        mlp.set_fwd_split(fwd)
         eng.invalidate() if hasattr(eng, "invalidate") else None
         xd = x.to(dev)
         st = eng.forward(xd, need_grad_state=True, feat_ld=288)
@@ -60,9 +63,10 @@ def test_chain_outputs_against_float64(dev):
         res[mode] = dict(udf=_err(st["udf"][:P].reshape(-1), ref[:, 0]), feat=_err(st["feat"][:P, :256], ref[:, 1:]),
                          grad=_err(gr[:P], gref))
     print("max error / max|ref| against float64:", res)
-    for k in ("udf", "feat", "grad"):
-        assert res["bf16x3"][k] <= 1.5 * res["fp32"][k] + 1e-8, (k, res)
-        assert res["bf16x3"][k] < 2e-5, (k, res)
+    for mode in ("bf16x3", "f16x2"):
+        for k in ("udf", "feat", "grad"):
+            assert res[mode][k] <= 1.5 * res["fp32"][k] + 1e-8, (mode, k, res)
+            assert res[mode][k] < 2e-5, (mode, k, res)
 
 
 def test_full_backward_parameter_gradients_match_exact_fp32(dev):
@@ -71,11 +75,16 @@ def test_full_backward_parameter_gradients_match_exact_fp32(dev):
     import chain_sweeps as CS
     from neuraludf_amd import mlp
     outs = {}
-    for mode in ("fp32", "bf16x3"):
-        mlp.set_precision(mode)
+    for mode, prec, fwd in (("fp32", "fp32", "1"), ("bf16x3", "bf16x3", "0"), ("f16x2", "bf16x3", "1")):
+        mlp.set_precision(prec)
+        mlp.set_fwd_split(fwd)
         outs[mode] = {k: v.detach().float().clone() for k, v in CS.sweeps(dev, 8192, 0, seed=3).items()}
         torch.cuda.synchronize()
-    a, b = outs["fp32"], outs["bf16x3"]
+    _compare_with_exact_fp32(outs["fp32"], outs["bf16x3"], "bf16x3 everywhere")
+    _compare_with_exact_fp32(outs["fp32"], outs["f16x2"], "f16x2 forward-order sweeps + bf16x3 backward sweeps (the default)")
+
+
+def _compare_with_exact_fp32(a, b, what):
     assert set(a) == set(b)
     # The UDF network is smooth (softplus): max-norm.  The colour net and the NeRF are ReLU networks: a pre-activation within
     # an ulp of zero takes the other branch in one of the two modes (a handful of the ~10^7 unit evaluations here), which
@@ -98,7 +107,7 @@ def test_full_backward_parameter_gradients_match_exact_fp32(dev):
             worst = (k, e)
         # (3e-3: the bound tests/test_gpu_chain_rows.py holds the exact-fp32 kernels to AGAINST EACH OTHER on these tensors)
         assert e < (3e-5 if k in smooth else 3e-3), (k, e)
-    print("largest relative difference bf16x3 vs exact fp32:", worst)
+    print(f"largest relative difference {what} vs exact fp32:", worst)
 
 
 @pytest.mark.parametrize("M", [333, 4096])
@@ -205,6 +214,40 @@ def test_packed_weight_planes_sum_to_the_weight_bit_for_bit(dev):
     ref = ref.reshape(G16, 2, 8, NT, 32).permute(0, 3, 1, 4, 2).reshape(G16, NT, 64, 8)
     assert torch.equal(total, ref)
     assert float(w[:, :, 1].abs().max()) > 0 and float(w[:, :, 2].abs().max()) > 0
+
+
+def test_packed_f16x2_planes_reproduce_the_weight(dev):
+    """NudfPackFrag.dtype 4: the two fp16 planes of a fragment-ordered weight copy are hi = fp16(w) and lo = fp16((w - hi) 2^11)
+    -- recomputed here with torch's fp16 rounding, bit for bit -- and hi + 2^-11 lo is within 2^-22 |w| of the fp32 weight."""
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = perturb_(build_modules(fields, seed=0))
+    udf = mods["udf"].to(dev)
+    mlp.set_precision("bf16x3")
+    mlp.set_fwd_split("1")
+    eng = udf.engine()
+    x = torch.rand(64, 3, device=dev)
+    eng.forward(x, need_grad_state=False, udf_only=True)            # packs the weights
+    for li, kind, tr in ((2, "fwd@f16x2", True), (3, "bwd@f16x2", False)):
+        pl = eng.layers[li]
+        if kind not in pl._frags:
+            st = eng.forward(x, need_grad_state=True, feat_ld=288)
+            eng.gradient(x, st)
+        f2 = pl._frags[kind]
+        K, N = (pl.inp, pl.out) if tr else (pl.out, pl.inp)
+        NT, G16 = (N + 31) // 32, mlp.k8(K) // 16
+        planes = f2.view(torch.float16).reshape(G16, NT, 2, 64, 8)
+        B = (pl.Wt[:K, :N] if tr else pl.W[:K, :N]).contiguous()
+        ref = torch.zeros(G16 * 16, NT * 32, device=dev)
+        ref[:K, :N] = B
+        ref = ref.reshape(G16, 2, 8, NT, 32).permute(0, 3, 1, 4, 2).reshape(G16, NT, 64, 8)
+        hi = ref.half()
+        lo = ((ref - hi.float()) * 2048.0).half()
+        assert torch.equal(planes[:, :, 0], hi), kind
+        assert torch.equal(planes[:, :, 1], lo), kind
+        back = planes[:, :, 0].double() + planes[:, :, 1].double() / 2048.0
+        assert float((back - ref.double()).abs().max()) <= 2.0 ** -22 * float(ref.abs().max()), kind
+        assert float(planes[:, :, 1].float().abs().max()) > 0
 
 
 def test_non_finite_values_stay_non_finite(dev):
