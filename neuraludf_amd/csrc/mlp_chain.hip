@@ -560,8 +560,19 @@ __device__ __forceinline__ void ch_mma16x2(const float* __restrict__ arow, const
       for (int pl = 0; pl < 2; ++pl) bb[j][pl] = bq[j * 128 + pl * 64];
   };
   auto split = [&](f16x8 (&q)[NRT][2]) {
+#ifdef NUDF_X2_PROBE_NOSPLIT     // timing probe only (wrong results): the operands are the raw LDS words -- what a K loop costs
+#pragma unroll                   // whose tile already holds the two fp16 parts (the split done once, by the producing epilogue)
+    for (int i = 0; i < NRT; ++i) {
+      uint4 u0 = __builtin_bit_cast(uint4, raw[i][0]), u1 = __builtin_bit_cast(uint4, raw[i][1]);
+      u0.x &= 0x33ff33ffu; u0.y &= 0x33ff33ffu; u0.z &= 0x33ff33ffu; u0.w &= 0x33ff33ffu;      // finite, |.| < 0.25
+      u1.x &= 0x33ff33ffu; u1.y &= 0x33ff33ffu; u1.z &= 0x33ff33ffu; u1.w &= 0x33ff33ffu;
+      q[i][0] = __builtin_bit_cast(f16x8, u0);
+      q[i][1] = __builtin_bit_cast(f16x8, u1);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NRT; ++i) ch_split2(raw[i][0], raw[i][1], q[i][0], q[i][1]);
+#endif
   };
   auto mfmas = [&](const f16x8 (&q)[NRT][2], const uint4 (&bb)[NCT][2]) {
     // the two correction products first (their accumulator), then hi hi'
