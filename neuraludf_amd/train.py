@@ -7,6 +7,8 @@ from __future__ import annotations
 import contextlib
 import io
 
+import os
+
 import torch
 
 from . import dist as nudf_dist
@@ -65,6 +67,9 @@ class StepScalars:
         ev = torch.cuda.Event()
         ev.record()
         self.events[i] = ev
+
+
+SINGLE_THREAD_BACKWARD = os.environ.get("NUDF_HOST_FAST", "1") != "0"
 
 
 class GraphedStep:
@@ -412,7 +417,12 @@ class Trainer:
         one = self._one.get(loss.device)
         if one is None or one.dtype != loss.dtype:
             one = self._one[loss.device] = torch.ones((), device=loss.device, dtype=loss.dtype)
-        loss.backward(gradient=one)
+        # the backward functions of this step are ~35 kernel launches of Python each: on autograd's device thread they cost the
+        # hand-over and the interpreter lock they fight the main thread for (measured, scripts/host_profile.py: 2.7 ms of
+        # enqueueing per step with the engine's worker thread, 2.1 ms on the calling thread); one device, one stream --
+        # nothing runs concurrently either way
+        with torch.autograd.set_multithreading_enabled(not SINGLE_THREAD_BACKWARD):
+            loss.backward(gradient=one)
         if self.data_parallel:
             self.bucket.all_reduce()
         self.optimizer.step()

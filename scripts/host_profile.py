@@ -27,12 +27,13 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("host enqueue %.3f ms/step, with final sync %.3f ms/step" % ((t1 - t0) / 30 * 1e3, (t2 - t0) / 30 * 1e3))
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(30):
-    tr.step(batch)
-pr.disable()
-torch.cuda.synchronize()
-s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
-print(s.getvalue()[:9000])
+if "--profile" in sys.argv:
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(30):
+        tr.step(batch)
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+    print(s.getvalue()[:8000])
