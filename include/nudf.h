@@ -570,6 +570,15 @@ typedef struct NudfChainStep {
      C1 / C2 may be NULL then. */
   const float* row_w;
   float* row_sums;
+  /* NUDF_CH_BWD steps only (workgroup-shared kernel, split / 16-bit modes): a THIRD stored operand.  With X3 = NULL the step
+     adds X2 = EX[l-1], the second-order term the tangent sweep stored (EX = (R W^T) * DA * softplus'' / softplus').  With X3 set
+     the term is formed here instead, from arrays that exist anyway -- X2 = R[l] (the tangent sweep's activations, which the
+     second-order weight gradient reads) and X3 = DA[l-1] (the input-gradient sweep's adjoints):
+         EX = X2 * X3 * 100 (1 - s) / (s * scale),   s = softplus'(.) recovered from X1 as everywhere, 0 where s = 0
+     (R = (R W^T) s scale, so R / (s scale) is the pre-activation tangent again).  The tangent sweep then neither reads DA nor
+     writes EX: two of its four arrays per layer (fields.py:219-231 with create_graph=True is the reference's form of all of this). */
+  const float* X3;
+  int32_t ldx3;
 } NudfChainStep;
 /* Blocked layout of a [P, ld] buffer (P padded to 32 rows, ld % 4 == 0): element (r, c) lives at
  *   (r / 32) * 32 * ld + (c / 4) * 128 + (r % 32) * 4 + (c % 4)

@@ -151,7 +151,8 @@ class ChainStep(C.Structure):
                 ("r1_row", c_fp), ("r1_col", c_fp), ("K", i32), ("N", i32), ("epi", i32), ("iparam", i32),
                 ("ldx1", i32), ("ldx2", i32), ("ldc1", i32), ("ldc2", i32), ("ldr1", i32), ("prec", i32), ("act_write", i32),
                 ("act_col0", i32), ("pe_tail_col", i32), ("ld_pe", i32), ("pe_dst", c_fp), ("pe_tail_scale", f32),
-                ("scale", f32), ("xscale", f32), ("layout", i32), ("row_w", c_fp), ("row_sums", c_fp)]
+                ("scale", f32), ("xscale", f32), ("layout", i32), ("row_w", c_fp), ("row_sums", c_fp), ("X3", c_fp),
+                ("ldx3", i32)]
 
 
 class Chain(C.Structure):

@@ -667,11 +667,12 @@ __device__ __forceinline__ void ch_p4_store(float* C, int ld, unsigned q0, unsig
 // T16: the activation tile is the 16-bit one of the MODE 3 kernel (`act` points at halfwords, row stride CH_LD16; tile_bf: it
 // holds bf16, else fp16) -- the new activations are rounded ONCE here, on their way into the tile, instead of in the K loop of
 // each of the four waves that read them (same values: the next step's MFMAs see the same operands)
-template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false, bool T16 = false>
+struct ChNoX3 {};
+template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false, bool T16 = false, bool HX3 = false, class X3V = ChNoX3>
 __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
                                                  const float* x2in = nullptr, const float* bias_pre = nullptr,
-                                                 bool tile_bf = false) {
+                                                 bool tile_bf = false, const X3V& x3in = X3V()) {
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -723,6 +724,28 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
     }
   }
+  // NUDF_CH_BWD with a third stored operand (NudfChainStep.X3): x2 = R[l], x3 = DA[l-1] -- the second-order term is formed
+  // below instead of read.  Fetched by the caller one tile ahead (x3in) or here.
+  // (HX3 is a template flag: the two-operand BWD path keeps its register allocation)
+  constexpr bool has_x3 = HX3 && EPI == NUDF_CH_BWD;
+  float x3[16];
+  if constexpr (has_x3) {
+    if constexpr (!std::is_same<X3V, ChNoX3>::value) {      // fetched by the caller one tile ahead (a register array)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x3[r] = x3in[r];
+    } else {
+      const unsigned vo = grow0 * (unsigned)st.ldx3 + colc;
+      if (S16) {
+        uint2 w[4];
+        ch_p4_load(st.X3, st.ldx3, (grow0 >> 2), colc, w);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ch_p4_widen(w[g], x3 + 4 * g);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x3[r] = (st.X3 + (size_t)CH_KOFF(r) * st.ldx3)[vo];
+      }
+    }
+  }
   float out2[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -765,7 +788,15 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
         out[r] = v[r] * sg * st.scale;
         out2[r] = v[r] * x2[r] * 100.0f * om;
       } else {  // NUDF_CH_BWD
-        out[r] = v[r] * st.scale * sg + x2[r];
+        if constexpr (has_x3) {
+          // EX = (R / (s scale)) DA 100 (1 - s): R = (R W^T) s scale is divided back into the pre-activation tangent.  Where
+          // s underflows to 0 both R and DA are exact zeros (each carries the factor s): the clamped reciprocal keeps the
+          // product at 0 without a select (selects around transcendentals become per-element branches).
+          const float f = 100.0f * om * __builtin_amdgcn_rcpf(fmaxf(sg * st.scale, 1e-30f));
+          out[r] = v[r] * st.scale * sg + x2[r] * x3[r] * f;
+        } else {
+          out[r] = v[r] * st.scale * sg + x2[r];
+        }
       }
     }
   }
@@ -906,12 +937,12 @@ __device__ __forceinline__ void ch_epilogue_seq(const NudfChainStep& st, float* 
 #ifndef NUDF_SEQ16
 #define NUDF_SEQ16 1     // A/B build switch (scripts/build_variants.sh): 0 = per-tile loop for the 16-bit stored state
 #endif
-template <int EPI, int NRT, int NCT, bool T16 = false>
+template <int EPI, int NRT, int NCT, bool T16 = false, bool X3 = false>
 __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
                                                   int ln, f32x16 (&acc)[2][2], const float (&bpre)[2], bool tile_bf = false) {
-  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
-  uint2 r1[2][4], r2[2][4];      // raw 4-point packs of tile t and t + 1
-  auto issue = [&](uint2 (&a1)[4], uint2 (&a2)[4], int i, int j) {
+  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI), U3 = (EPI == NUDF_CH_BWD) && X3;
+  uint2 r1[2][4], r2[2][4], r3[2][4];      // raw 4-point packs of tile t and t + 1
+  auto issue = [&](uint2 (&a1)[4], uint2 (&a2)[4], uint2 (&a3)[4], int i, int j) {
     const int col = (ct0 + j) * 32 + ln;
     const unsigned colc = (unsigned)((col < st.N) ? col : 0);
     const unsigned q0 = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h) >> 2;
@@ -924,17 +955,19 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
         for (int g = 0; g < 4; ++g) a2[g] = uint2{0u, 0u};
       }
     }
+    if (U3) ch_p4_load(st.X3, st.ldx3, q0, colc, a3);
   };
   constexpr int NTL = NRT * NCT;
-  issue(r1[0], r2[0], 0, 0);
+  issue(r1[0], r2[0], r3[0], 0, 0);
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
-    if (t + 1 < NTL) issue(r1[(t + 1) & 1], r2[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
-    float x1[16], x2[16];
+    if (t + 1 < NTL) issue(r1[(t + 1) & 1], r2[(t + 1) & 1], r3[(t + 1) & 1], (t + 1) / NCT, (t + 1) % NCT);
+    float x1[16], x2[16], x3[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (U1) ch_p4_widen(r1[t & 1][g], x1 + 4 * g);
       if (U2) ch_p4_widen(r2[t & 1][g], x2 + 4 * g);
+      if (U3) ch_p4_widen(r3[t & 1][g], x3 + 4 * g);
     }
     if (!U1) {
 #pragma unroll
@@ -944,8 +977,12 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 #pragma unroll
       for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
     }
-    ch_epilogue_tile<EPI, true, true, false, T16>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1,
-                                                  false, x2, &bpre[t % NCT], tile_bf);
+    if constexpr (U3)
+      ch_epilogue_tile<EPI, true, true, false, T16, true, float[16]>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln,
+                                                                     acc[t / NCT][t % NCT], x1, false, x2, &bpre[t % NCT], tile_bf, x3);
+    else
+      ch_epilogue_tile<EPI, true, true, false, T16>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], x1,
+                                                    false, x2, &bpre[t % NCT], tile_bf);
   }
 }
 
@@ -954,12 +991,14 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 #endif
 // bf16x3 mode (fp32 stored state, no operand prefetch under the K loop: the split needs those registers): BOTH stored
 // operands of tile t + 1 are requested before tile t is computed and stored, as in ch_epilogue_seq16.
-template <int EPI, int NRT, int NCT>
+template <int EPI, int NRT, int NCT, bool X3 = false>
 __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
                                                   int ln, f32x16 (&acc)[2][2], const float (&bpre)[2]) {
-  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI);
-  float xa[NUDF_X3_EPI_AHEAD + 1][16], xb[NUDF_X3_EPI_AHEAD + 1][16];
-  auto issue = [&](float (&a1)[16], float (&a2)[16], int i, int j) {
+  constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI), U3 = (EPI == NUDF_CH_BWD) && X3;
+  // (three stored operands: one tile ahead -- the same 96 registers as two operands two tiles ahead)
+  constexpr int AHEAD = U3 ? 1 : NUDF_X3_EPI_AHEAD;
+  float xa[AHEAD + 1][16], xb[AHEAD + 1][16], xc[U3 ? AHEAD + 1 : 1][16];
+  auto issue = [&](float (&a1)[16], float (&a2)[16], float (&a3)[16], int i, int j) {
     const int col = (ct0 + j) * 32 + ln;
     const unsigned colc = (unsigned)((col < st.N) ? col : 0);
     const unsigned row0 = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h);
@@ -989,20 +1028,94 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
         for (int r = 0; r < 16; ++r) a2[r] = 0.0f;
       }
     }
+    if (U3) {
+      const unsigned vo = row0 * (unsigned)st.ldx3 + colc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a3[r] = (st.X3 + (size_t)CH_KOFF(r) * st.ldx3)[vo];
+    }
   };
   constexpr int NTL = NRT * NCT;
   // Stored operands requested AHEAD tiles in advance (ring of AHEAD + 1 register sets).  The K loop's operand registers
   // are dead here (this mode prefetches nothing under the K loop), so there is room for more than the one tile of the
   // fp32 kernels: per-wave timelines showed the tangent epilogue at 32 k cycles per layer against 25 k for the K loop --
   // one exposed HBM round trip per tile.  (All four tiles up front = 128 registers: 33 spilled.)
-  constexpr int AH = (NUDF_X3_EPI_AHEAD < NTL) ? NUDF_X3_EPI_AHEAD : NTL - 1;
+  constexpr int AH = (AHEAD < NTL) ? AHEAD : NTL - 1;
 #pragma unroll
-  for (int t = 0; t < AH; ++t) issue(xa[t % (AH + 1)], xb[t % (AH + 1)], t / NCT, t % NCT);
+  for (int t = 0; t < AH; ++t) issue(xa[t % (AH + 1)], xb[t % (AH + 1)], xc[U3 ? t % (AH + 1) : 0], t / NCT, t % NCT);
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
-    if (t + AH < NTL) issue(xa[(t + AH) % (AH + 1)], xb[(t + AH) % (AH + 1)], (t + AH) / NCT, (t + AH) % NCT);
-    ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
-                                xb[t % (AH + 1)], &bpre[t % NCT]);
+    if (t + AH < NTL)
+      issue(xa[(t + AH) % (AH + 1)], xb[(t + AH) % (AH + 1)], xc[U3 ? (t + AH) % (AH + 1) : 0], (t + AH) / NCT, (t + AH) % NCT);
+    if constexpr (U3)
+      ch_epilogue_tile<EPI, true, false, false, false, true, float[16]>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln,
+                                                                        acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
+                                                                        xb[t % (AH + 1)], &bpre[t % NCT], false, xc[t % (AH + 1)]);
+    else
+      ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
+                                  xb[t % (AH + 1)], &bpre[t % NCT]);
+  }
+}
+
+// NUDF_CH_BWD with THREE stored operands (NudfChainStep.X3: X1 = X[l], X2 = R[l], X3 = DA[l-1]; fp32 state, split modes), the
+// wave's tiles as EIGHT-row halves: the three operands of half-tile u + 1 are requested before half-tile u is computed and
+// stored -- 2 x 3 x 8 = 48 registers in flight instead of the 96 of whole tiles (which spilled 22 registers into a K loop
+// whose every scratch access waits vmcnt(0)).  out = (acc + bias [+ rank-1 term]) scale s + X2 X3 100 (1 - s) / (s scale).
+template <int NRT, int NCT>
+__device__ __forceinline__ void ch_epilogue_bwd3(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h, int ln,
+                                                 f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+  constexpr int NU = NRT * NCT * 2;
+  float xa[2][8], xb[2][8], xc[2][8];
+  auto coords = [&](int u, unsigned& row0, int& col, unsigned& colc) {
+    const int t = u >> 1, i = t / NCT, j = t % NCT;
+    col = (ct0 + j) * 32 + ln;
+    colc = (unsigned)((col < st.N) ? col : 0);
+    row0 = (unsigned)(m0 + (rt0 + i) * 32 + 4 * h + 16 * (u & 1));     // accumulator registers 8 (u & 1) .. + 7
+  };
+  auto issue = [&](float (&a1)[8], float (&a2)[8], float (&a3)[8], int u) {
+    unsigned row0, colc;
+    int col;
+    coords(u, row0, col, colc);
+    const unsigned v1 = row0 * (unsigned)st.ldx1 + colc, v2 = row0 * (unsigned)st.ldx2 + colc, v3 = row0 * (unsigned)st.ldx3 + colc;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a1[r] = (st.X1 + (size_t)CH_KOFF(r) * st.ldx1)[v1];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a2[r] = (st.X2 + (size_t)CH_KOFF(r) * st.ldx2)[v2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a3[r] = (st.X3 + (size_t)CH_KOFF(r) * st.ldx3)[v3];
+  };
+  issue(xa[0], xb[0], xc[0], 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (u + 1 < NU) issue(xa[(u + 1) & 1], xb[(u + 1) & 1], xc[(u + 1) & 1], u + 1);
+    const int t = u >> 1, i = t / NCT, j = t % NCT, hf = u & 1;
+    unsigned row0, colc;
+    int col;
+    coords(u, row0, col, colc);
+    const bool col_ok = col < st.N;
+    const float bias = bpre[j];
+    float r1c = 0.0f;
+    if (st.r1_row) r1c = st.r1_col[colc];
+    float out[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = acc[i][j][8 * hf + r] + bias;
+      if (st.r1_row) v += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[row0 * (unsigned)st.ldr1] * r1c;
+      const float x = 100.0f * st.xscale * xa[u & 1][r];
+      const float om = __builtin_amdgcn_exp2f(x * -1.44269504f);
+      const float sg = 1.0f - om;
+      const float f = 100.0f * om * __builtin_amdgcn_rcpf(fmaxf(sg * st.scale, 1e-30f));
+      out[r] = v * st.scale * sg + xb[u & 1][r] * xc[u & 1][r] * f;
+    }
+    if (col_ok && st.C1) {
+      const unsigned vo = row0 * (unsigned)st.ldc1 + (unsigned)col;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+    }
+    if (st.act_write) {
+      float* ap = act + ((rt0 + i) * 32 + 4 * h + 16 * hf) * CH_LD + st.act_col0 + col;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
+    }
   }
 }
 
@@ -1021,6 +1134,15 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
       return;
     }
   }
+  if constexpr (X3 && EPI == NUDF_CH_BWD) {
+    if (st.X3) {      // second-order term formed from R and DA (NudfChainStep.X3): three stored operands, fp32 state
+      if (nrt == 2 && nct == 2) ch_epilogue_bwd3<2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else if (nrt == 2) ch_epilogue_bwd3<2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else if (nct == 2) ch_epilogue_bwd3<1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else ch_epilogue_bwd3<1, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      return;
+    }
+  }
   if constexpr (X3 && CH_USES_X1(EPI)) {
     if (st.prec >= 3 && nrt * nct >= 2) {
       if (nrt == 2 && nct == 2) ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
@@ -1031,6 +1153,13 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
   }
   if constexpr (ANY16 && (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
     if (NUDF_SEQ16 && (st.layout & NUDF_CH_STATE16) && nrt == 2) {
+      if constexpr (EPI == NUDF_CH_BWD && MODE != 3) {     // (the dispatcher sends three-operand chains to MODE 4)
+        if (st.X3) {
+          if (nct == 2) ch_epilogue_seq16<EPI, 2, 2, T16, true>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
+          else ch_epilogue_seq16<EPI, 2, 1, T16, true>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
+          return;
+        }
+      }
       if (nct == 2) ch_epilogue_seq16<EPI, 2, 2, T16>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
       else ch_epilogue_seq16<EPI, 2, 1, T16>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
       return;
@@ -1076,7 +1205,21 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
     }
     if constexpr (ANY16 && (EPI == NUDF_CH_SOFTPLUS || EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
       if (st.layout & NUDF_CH_STATE16) {
+        if constexpr (EPI == NUDF_CH_BWD && MODE != 3) {
+          if (st.X3) {       // (ragged blocks of a wave: the three-operand form loads its operands inside the tile)
+            ch_epilogue_tile<EPI, false, true, false, T16, true>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true, nullptr, &bpre[j],
+                                                                 tile_bf);
+            continue;
+          }
+        }
         ch_epilogue_tile<EPI, false, true, false, T16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true, nullptr, &bpre[j], tile_bf);
+        continue;
+      }
+    }
+    if constexpr (EPI == NUDF_CH_BWD && MODE == 1) {       // (fp32 state inside a 16-bit chain)
+      if (st.X3) {
+        ch_epilogue_tile<EPI, false, false, false, T16, true>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, true, nullptr, &bpre[j],
+                                                              tile_bf);
         continue;
       }
     }
@@ -1432,7 +1575,9 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
            s.epi != NUDF_CH_TANGENT && s.epi != NUDF_CH_BWD) ||
           ((s.layout & NUDF_CH_P4_X1) && s.epi != NUDF_CH_MULMASK && s.epi != NUDF_CH_ADDMASK) ||
           ((s.layout & NUDF_CH_P4_C1) && s.epi != NUDF_CH_RELU && s.epi != NUDF_CH_MULMASK && s.epi != NUDF_CH_ADDMASK) ||
-          ((s.layout & (NUDF_CH_P4_X1 | NUDF_CH_P4_C1)) && s.prec == 0);
+          ((s.layout & (NUDF_CH_P4_X1 | NUDF_CH_P4_C1)) && s.prec == 0) ||
+          (s.X3 && (s.epi != NUDF_CH_BWD || s.prec == 0 || !s.X2 || !s.X1 || p.tile_rows == 66 || p.tile_rows == 128 ||
+                    p.tile_rows == 130));
   }
   if (bad) {
     nudf_set_error("nudf_mlp_chain: K%16, K<=288, N<=256, x_div>=1, 16-byte aligned packed weights required", hipErrorInvalidValue);
@@ -1504,7 +1649,7 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   bool t16_tangent = false;
   for (int i = 0; i < p.n_steps && t16; ++i) {
     t16 = (p.step[i].prec == 1 || p.step[i].prec == 2) && p.step[i].prec == p.step[0].prec;
-    t16_tangent = t16_tangent || p.step[i].epi == NUDF_CH_TANGENT;
+    t16_tangent = t16_tangent || p.step[i].epi == NUDF_CH_TANGENT || p.step[i].X3 != nullptr;   // (MODE 4: room for 3 operands)
   }
   // small launches: 32-point tiles fill the 256 CUs sooner (up-sampling rounds are 5-8 k points)
   if (p.tile_rows == 32 || (p.tile_rows != 64 && p.P <= 256 * 64)) {

@@ -372,7 +372,7 @@ class ChainBuilder:
 
     def _do_step(self, epi, Bp, K, N, bias=None, bias_off=0, X1=None, X2=None, C1=None, C2=None, ldc1=0, ldc2=0, r1_row=None,
              ldr1=1, r1_col=None, iparam=0, act_write=1, act_col0=0, pe_tail_col=-1, pe_tail_scale=0.0, pe_dst=None,
-             scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x2_off=0, row_w=None, row_sums=None):
+             scale=1.0, xscale=1.0, c1_off=0, c2_off=0, x2_off=0, row_w=None, row_sums=None, X3=None):
         if self.n >= CH_MAX_STEPS:
             raise _lib.NudfError("too many chain steps")
         s = self.c.step[self.n]
@@ -381,6 +381,9 @@ class ChainBuilder:
         s.pe_dst, s.ld_pe = self._p(pe_dst), (pe_dst.shape[1] if pe_dst is not None else 0)
         s.ldx1 = X1.shape[1] if X1 is not None else 0
         s.ldx2 = X2.shape[1] if X2 is not None else 0
+        s.X3, s.ldx3 = self._p(X3), (X3.shape[1] if X3 is not None else 0)       # BWD: second-order term formed in the epilogue
+        if X3 is not None and (epi != "BWD" or X1 is None or X2 is None or _isblk(X3)):
+            raise _lib.NudfError("X3: the third stored operand of a BWD step (X1 = activations, X2 = R, X3 = DA), row-major")
         s.ldc1 = ldc1 or (C1.shape[1] if (C1 is not None and C1.dim() == 2) else 0)
         s.ldc2 = ldc2 or (C2.shape[1] if (C2 is not None and C2.dim() == 2) else 0)
         s.r1_row, s.ldr1, s.r1_col = self._p(r1_row), ldr1, self._p(r1_col)
@@ -388,7 +391,7 @@ class ChainBuilder:
         s.K, s.N, s.epi, s.iparam = K, N, CH[epi], iparam
         s.prec = getattr(Bp, "prec", 0)
         # 16-bit stored state (config-5 mode): X1, X2, C1, the TANGENT mirror C2 and pe_dst of a step are bf16 TOGETHER
-        state = [t for t in (X1, X2, C1, C2 if epi == "TANGENT" else None, pe_dst) if t is not None]
+        state = [t for t in (X1, X2, X3, C1, C2 if epi == "TANGENT" else None, pe_dst) if t is not None]
         if epi in ("RELU", "MULMASK", "ADDMASK") and (_is16(X1) or _is16(C1)):
             # the ReLU family (colour net): bf16 per array -- X2 (d VIN), the C2 mirror and pe_dst (VIN) stay fp32
             if any(_is16(t) for t in (X2, C2, pe_dst)) or not all(_isp4(t) for t in (X1, C1) if _is16(t)) or s.prec == 0 \
@@ -414,7 +417,7 @@ class ChainBuilder:
         self.xflops += fl * MFMA_PRODUCTS[int(s.prec)]
         if PROFILE is not None:
             n_true = getattr(Bp, "n_true", N)
-            for t in (X1, X2, C1, C2, pe_dst):
+            for t in (X1, X2, X3, C1, C2, pe_dst):
                 if t is not None:
                     self.nbytes += float(self.c.P) * (min(n_true, t.shape[1]) if t.dim() == 2 else 1) * t.element_size()
             self.epis.append(epi)
@@ -483,9 +486,11 @@ class ChainBuilder:
             if mode == 1 and not t32 and not roww and _chain_t16_now():
                 precs = {int(self.c.step[i].prec) for i in range(self.n)}
                 if len(precs) == 1 and precs <= {1, 2}:
-                    mode = 4 if "TANGENT" in e else 3      # the 16-bit-tile kernel (one operand type in every step)
+                    x3 = any(self.c.step[i].X3 for i in range(self.n))
+                    mode = 4 if ("TANGENT" in e or x3) else 3      # the 16-bit-tile kernel (one operand type in every step)
             kern = "mlp_chain_kernel<%d, %d>" % (32 if t32 else 64, mode)
-        sweep = ("tangent" if "TANGENT" in e else "adjoint" if "BWD" in e else "input-gradient" if "MULSP" in e
+        sweep = ("tangent" if ("TANGENT" in e or ("MULSP" in e and self.init == "POSENC")) else "adjoint" if "BWD" in e
+                 else "input-gradient" if "MULSP" in e
                  else "relu-backward" if e & {"MULMASK", "ADDMASK"} else "udf-forward" if "SOFTPLUS" in e
                  else "relu-forward")
         return "%s %s P=%d" % (kern, sweep, P)
@@ -698,6 +703,9 @@ _PREC = {"f32": 0, "f16": 1, "bf16": 2, "bf16x3": 3, "f16x2": 4}
 # scripts/numerics/f16x2_emulation.py).  NUDF_FWD_F16X2=0 keeps bf16x3 everywhere (A/B); "grad" additionally keeps the
 # input-gradient reverse sweep on bf16x3.
 FWD_F16X2 = os.environ.get("NUDF_FWD_F16X2", "1")
+# the adjoint sweep forms the second-order term from R and DA instead of reading an EX array the tangent sweep stored
+# (NudfChainStep.X3; UDFEngine._backward_chain): 0 = the stored form (A/B)
+EX_FLY = os.environ.get("NUDF_EX_FLY", "1") != "0"
 TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too
 
 
@@ -1193,22 +1201,33 @@ class UDFEngine:
         grads = alloc_grads(layers, zero=not assign)
         second = d_g is not None and DA is not None
         R = EX = None
+        # EX_FLY: the second-order term EX[l] = (R[l] W^T) * DA[l] * softplus'' / softplus' is not stored by the tangent sweep
+        # and re-read by the adjoint sweep -- the adjoint sweep forms it from R[l + 1] and DA[l], arrays that exist anyway
+        # (NudfChainStep.X3).  The tangent sweep is then MULSP steps: one array in (X), one out (R) per layer instead of
+        # two and two.  Split / 16-bit modes on the workgroup-shared kernel (the fp32 kernels keep the stored form).
+        ex_fly = second and EX_FLY and PRECISION != "fp32" and not _isblk(X[L]) and CHAIN_TILE in (0, 32, 64)
         if second:
             sd, blk = X[L].dtype, _isblk(X[L])
             R = ([_buf(P, layers[0].inp, dev, zero=False)] +
                  [_buf(P, pl.inp, dev, zero=False, dtype=sd, blocked=blk) for pl in layers[1:]])
-            EX = [_buf(P, layers[l].out, dev, zero=False, dtype=sd, blocked=blk) for l in range(L)]
+            EX = None if ex_fly else [_buf(P, layers[l].out, dev, zero=False, dtype=sd, blocked=blk) for l in range(L)]
             cb = ChainBuilder(P, "POSENC", k8(self.E), site=("udf_tangent", id(self)))
             cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
             cb.init_store(R[0])
             for l in range(L):
                 pl = layers[l]
                 nxt_skip = (l + 1) in self.skip
-                cb.step("TANGENT", pl.frag(_kind("fwd", "bwd")), k8(pl.inp), pl.out, X1=X[l + 1], X2=DA[l], C1=R[l + 1],
-                        C2=EX[l],
-                        scale=self.inv_sqrt2 if nxt_skip else 1.0, xscale=self._xs(l),
-                        pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
-                        pe_dst=R[l + 1] if nxt_skip else None)
+                if ex_fly:
+                    cb.step("MULSP", pl.frag(_kind("fwd", "bwd")), k8(pl.inp), pl.out, X1=X[l + 1], C1=R[l + 1],
+                            scale=self.inv_sqrt2 if nxt_skip else 1.0, xscale=self._xs(l),
+                            pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
+                            pe_dst=R[l + 1] if nxt_skip else None)
+                else:
+                    cb.step("TANGENT", pl.frag(_kind("fwd", "bwd")), k8(pl.inp), pl.out, X1=X[l + 1], X2=DA[l], C1=R[l + 1],
+                            C2=EX[l],
+                            scale=self.inv_sqrt2 if nxt_skip else 1.0, xscale=self._xs(l),
+                            pe_tail_col=self._skip_col(l + 1) if nxt_skip else -1, pe_tail_scale=self.inv_sqrt2,
+                            pe_dst=R[l + 1] if nxt_skip else None)
             cb.launch()
         inv_scale = 1.0 / float(net.scale)
         if second and not head4_path:
@@ -1245,16 +1264,16 @@ class UDFEngine:
         for l in range(L, 0, -1):
             pl = layers[l]
             sc = self.inv_sqrt2 if l in self.skip else 1.0
+            x2 = (R[l] if ex_fly else EX[l - 1]) if second else None
+            x3 = DA[l - 1] if ex_fly else None
             if l == L:
-                cb.step("BWD", pl.frag(_kind("bwd_feat", "bwd")), k8(F), layers[l - 1].out, X1=X[l],
-                        X2=EX[l - 1] if second else None,
+                cb.step("BWD", pl.frag(_kind("bwd_feat", "bwd")), k8(F), layers[l - 1].out, X1=X[l], X2=x2, X3=x3,
                         C1=ABAR[l - 1], r1_row=r1, ldr1=ldr1, r1_col=pl.W, scale=sc,
                         xscale=self._xs(l - 1))
             else:
                 n_hid = layers[l - 1].out           # the skip layer's embedding columns carry no parameter gradient
                 cb.step("BWD", pl.frag(_kind("bwd" if n_hid == pl.inp else "bwd_hid:%d" % n_hid, "bwd")), k8(pl.out),
-                        n_hid, X1=X[l],
-                        X2=EX[l - 1] if second else None, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
+                        n_hid, X1=X[l], X2=x2, X3=x3, C1=ABAR[l - 1], scale=sc, xscale=self._xs(l - 1))
         cb.launch()
         if grouped:
             # two grouped launches (adjoint pairs, then the second-order pairs accumulating into the same dW): each
