@@ -1300,6 +1300,37 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
   } else if (p.init == NUDF_CH_INIT_SEED) {
     // da[r, c] = sign[r] * w_row0[c] * inv_scale * softplus'(.)   (reverse-sweep seed, fields.py:219-231)
     const int C = p.k0;
+    if ((p.init_state16 & 3) == 3 && p.G0) {
+      // 16-bit stored state on both sides (4-point packed, ch_p4_off): a work item is FOUR consecutive points of one column --
+      // one 8-byte load of the stored activations, one 8-byte store of the seed (lanes = consecutive columns: 512 contiguous
+      // bytes per wave instruction).  The element-wise form below moved the same 134 MB at config 5's size as 2-byte accesses
+      // 8 bytes apart -- a quarter of every 32-byte sector used -- and cost the input-gradient sweep ~250 us against the
+      // tangent sweep's identical steps (round 6, profiles/r06_bench_cfg5_1024x256_mixed16.json).  Buffers are row-padded to
+      // the tile (nudf.h), so the quads of a ragged last tile exist; points >= P compute on clamped rows as everywhere.
+      const uint2* A4 = reinterpret_cast<const uint2*>(p.A0);
+      uint2* G4 = reinterpret_cast<uint2*>(p.G0);
+      for (int e = tid; e < (TM / 4) * C; e += CH_THREADS) {
+        const int q = e / C, c = e - q * C;
+        const unsigned gq = (unsigned)(m0 >> 2) + (unsigned)q;
+        float hst[4], val[4];
+        ch_p4_widen(A4[(size_t)gq * p.lda0 + c], hst);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int gr = m0 + 4 * q + k;
+          if (gr > p.P - 1) gr = p.P - 1;
+          float sd, om;
+          ch_sp_derivs(hst[k], p.seed_xscale, sd, om);
+          val[k] = p.seed_sign[gr] * p.seed_wrow[c] * p.seed_scale * sd;
+          const int r = 4 * q + k;
+          if constexpr (T16) sm.act[r * CH_LD16 + c] = tile_bf ? ch_f2bf(val[k]) : ch_f2h(val[k]);
+          else act_f[r * CH_LD + c] = val[k];
+        }
+        uint2 w;
+        w.x = (unsigned)ch_f2bf(val[0]) | ((unsigned)ch_f2bf(val[1]) << 16);
+        w.y = (unsigned)ch_f2bf(val[2]) | ((unsigned)ch_f2bf(val[3]) << 16);
+        G4[(size_t)gq * p.ldg0 + c] = w;
+      }
+    } else
     for (int e = tid; e < TM * C; e += CH_THREADS) {
       const int r = e / C, c = e - r * C;
       int gr = m0 + r;

@@ -706,6 +706,7 @@ FWD_F16X2 = os.environ.get("NUDF_FWD_F16X2", "1")
 # the adjoint sweep forms the second-order term from R and DA instead of reading an EX array the tangent sweep stored
 # (NudfChainStep.X3; UDFEngine._backward_chain): 0 = the stored form (A/B)
 EX_FLY = os.environ.get("NUDF_EX_FLY", "1") != "0"
+MIXED16_GRAD_BF16 = os.environ.get("NUDF_MIXED16_GRAD", "f16") == "bf16"     # experiment: operand type of the input-gradient sweep
 TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too
 
 
@@ -774,6 +775,8 @@ def _sweep_dtype(sweep):
         if FWD_F16X2 != "0" and (sweep == "fwd" or (sweep == "grad" and FWD_F16X2 != "grad")):
             return "f16x2"
         return "bf16x3"
+    if sweep == "grad" and MIXED16_GRAD_BF16:
+        return "bf16"
     return "f16" if sweep in ("fwd", "grad") else "bf16"
 
 
