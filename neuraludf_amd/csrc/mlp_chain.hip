@@ -553,6 +553,9 @@ __device__ __forceinline__ void ch_mma16x2(const float* __restrict__ arow, const
     }
   };
   auto ldb = [&](uint4 (&bb)[NCT][2], int g) {
+#ifdef NUDF_X2_PROBE_B0      // timing probe only (wrong results): every k step re-reads step 0's fragments -- L1 hits
+    g = 0;
+#endif
     const uint4* bq = bptr + (size_t)g * bstride2;
 #pragma unroll
     for (int j = 0; j < NCT; ++j)
@@ -600,6 +603,10 @@ __device__ __forceinline__ void ch_mma16x2(const float* __restrict__ arow, const
     }
   };
   const int gl = G16 - 1;
+  // (Weight fragments TWO k steps ahead -- a k step is 384 matrix cycles per wave against 600-800 of L2 latency, and a probe
+  // that re-reads step 0's fragments, NUDF_X2_PROBE_B0, runs the f16x2 sweeps 7-12 % faster -- was built as a ring of three
+  // fragment sets: 208 live registers next to the two accumulator sets, and hipcc spilled 397 of them.  Not kept.)
+  {
   lda(0);
   ldb(b[0], 0);
   split(pa[0]);
@@ -623,6 +630,7 @@ __device__ __forceinline__ void ch_mma16x2(const float* __restrict__ arow, const
   }
   __builtin_amdgcn_sched_barrier(0);
   if (g < G16) mfmas(pa[0], b[0]);   // odd number of 16-wide k steps
+  }
 #pragma unroll
   for (int i = 0; i < NRT; ++i)
 #pragma unroll
@@ -1463,7 +1471,11 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
         const uint4* bp2 = reinterpret_cast<const uint4*>(st.Bp) + (size_t)ct0 * 128 + lane;
         const size_t bstride2 = (size_t)NT * 128;
         const int G16 = st.K >> 4;
+#ifdef NUDF_X2_PIPE64          // A/B: the split interleaved with the MFMAs on the 64-point tiles as well
+        constexpr bool PIPE2 = true;
+#else
         constexpr bool PIPE2 = (NUDF_X3_PIPE == 1) || (NUDF_X3_PIPE == 2 && TM == 32);
+#endif
         if (nrt == 2 && nct == 2) ch_mma16x2<2, 2, PIPE2>(arow16, bp2, bstride2, G16, acc);
         else if (nrt == 2) ch_mma16x2<2, 1, PIPE2>(arow16, bp2, bstride2, G16, acc);
         else if (nct == 2) ch_mma16x2<1, 2, PIPE2>(arow16, bp2, bstride2, G16, acc);
