@@ -244,6 +244,15 @@ CHAIN_MEMO = os.environ.get("NUDF_CHAIN_MEMO", "1") != "0" and _lib.HOST_FAST
 chain_memo_hits = 0
 
 
+def _memo_token(engine):
+    """identity of a call site's owner in the descriptor memo: an object the engine owns (id() of a collected engine could be
+    reused by another one while its entries are still in the memo; an object held by the key cannot)"""
+    t = engine.__dict__.get("_site_token")
+    if t is None:
+        t = engine.__dict__["_site_token"] = object()
+    return t
+
+
 class ChainBuilder:
     """fills a NudfChain; keeps the tensors it points at alive until the launch is enqueued.
 
@@ -706,7 +715,6 @@ FWD_F16X2 = os.environ.get("NUDF_FWD_F16X2", "1")
 # the adjoint sweep forms the second-order term from R and DA instead of reading an EX array the tangent sweep stored
 # (NudfChainStep.X3; UDFEngine._backward_chain): 0 = the stored form (A/B)
 EX_FLY = os.environ.get("NUDF_EX_FLY", "1") != "0"
-MIXED16_GRAD_BF16 = os.environ.get("NUDF_MIXED16_GRAD", "f16") == "bf16"     # experiment: operand type of the input-gradient sweep
 TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too
 
 
@@ -775,8 +783,6 @@ def _sweep_dtype(sweep):
         if FWD_F16X2 != "0" and (sweep == "fwd" or (sweep == "grad" and FWD_F16X2 != "grad")):
             return "f16x2"
         return "bf16x3"
-    if sweep == "grad" and MIXED16_GRAD_BF16:
-        return "bf16"
     return "f16" if sweep in ("fwd", "grad") else "bf16"
 
 
@@ -1125,7 +1131,7 @@ class UDFEngine:
         blk = _state_blocked(P)
         X = ([_buf(P, self.layers[0].inp, dev, zero=False)] +
              [_buf(P, pl.inp, dev, zero=False, dtype=sd, blocked=blk) for pl in self.layers[1:]]) if need_grad_state else None
-        cb = ChainBuilder(P, "POSENC", k8(self.E), site=("udf_fwd", id(self)))
+        cb = ChainBuilder(P, "POSENC", k8(self.E), site=("udf_fwd", _memo_token(self)))
         cb.posenc(x, net.multires, float(net.scale))
         if need_grad_state:
             cb.init_store(X[0])
@@ -1170,7 +1176,7 @@ class UDFEngine:
         DA = [_buf(P, self.layers[l].out, dev, zero=False, dtype=X[L].dtype, blocked=_isblk(X[L])) for l in range(L)]
         plL = self.layers[L]
         Epad = pad32(self.E)
-        cb = ChainBuilder(P, "SEED", k8(self.layers[L - 1].out), site=("udf_grad", id(self)))
+        cb = ChainBuilder(P, "SEED", k8(self.layers[L - 1].out), site=("udf_grad", _memo_token(self)))
         cb.init_seed(X[L], X[L].shape[1], st["sign"], plL.W, 1.0 / float(net.scale), self._xs(L - 1))
         cb.init_store(DA[L - 1])
         demb_skip = None
@@ -1214,7 +1220,7 @@ class UDFEngine:
             R = ([_buf(P, layers[0].inp, dev, zero=False)] +
                  [_buf(P, pl.inp, dev, zero=False, dtype=sd, blocked=blk) for pl in layers[1:]])
             EX = None if ex_fly else [_buf(P, layers[l].out, dev, zero=False, dtype=sd, blocked=blk) for l in range(L)]
-            cb = ChainBuilder(P, "POSENC", k8(self.E), site=("udf_tangent", id(self)))
+            cb = ChainBuilder(P, "POSENC", k8(self.E), site=("udf_tangent", _memo_token(self)))
             cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
             cb.init_store(R[0])
             for l in range(L):
@@ -1260,7 +1266,7 @@ class UDFEngine:
         for l in range(L):
             ABAR[l] = _buf(P, layers[l].out, dev, zero=False, dtype=X[L].dtype, blocked=_isblk(X[L]))
         # adjoint sweep: the tile starts as d feat (ABAR[L] columns 1..F); column 0 enters as a rank-1 term
-        cb = ChainBuilder(P, "LOAD", k8(F), site=("udf_adjoint", id(self)))
+        cb = ChainBuilder(P, "LOAD", k8(F), site=("udf_adjoint", _memo_token(self)))
         if d_feat is None:
             d_feat, d_feat_ld = torch.zeros(P, k8(F), device=dev), k8(F)
         cb.init_load(d_feat, d_feat_ld)
@@ -1532,7 +1538,7 @@ class ColorEngine:
         sd = _state_dtype()     # hidden activations: bf16 (4-point packed) in the 16-bit mode; CIN / VIN stay fp32
         HB = [CIN] + [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] if keep_state else None
         HV = [VIN] + [_buf(P, H, dev, zero=False, dtype=sd) for _ in range(n - 1)] if keep_state else None
-        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp), tile_rows=COLOR_TILE, site=("col_fwd", id(self)))
+        cb = ChainBuilder(P, "LOAD", k8(self.base[0].inp), tile_rows=COLOR_TILE, site=("col_fwd", _memo_token(self)))
         cb.init_load(CIN, CIN.shape[1])
         cb.posenc(rays_d, self.net.multires_view, 1.0, x_div=S)
         for l in range(n - 1):
@@ -1577,7 +1583,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(Dv[n - 1]), Dv[n - 1].shape[1])
         dVIN = _buf(P, self.view[0].inp, dev, zero=False)
-        cb = ChainBuilder(P, "LOAD", k8(plv.out), tile_rows=COLOR_TILE, site=("col_bwd_view", id(self)))
+        cb = ChainBuilder(P, "LOAD", k8(plv.out), tile_rows=COLOR_TILE, site=("col_bwd_view", _memo_token(self)))
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
@@ -1591,7 +1597,7 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color_base), ptr(d_cb), ptr(dVIN) + 4 * (H + npe), dVIN.shape[1],
              dout, None, 0, 0, P, ptr(Db[n - 1]), Db[n - 1].shape[1])
         dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)
-        cb = ChainBuilder(P, "LOAD", k8(plb.out), tile_rows=COLOR_TILE, site=("col_bwd_base", id(self)))
+        cb = ChainBuilder(P, "LOAD", k8(plb.out), tile_rows=COLOR_TILE, site=("col_bwd_base", _memo_token(self)))
         cb.init_load(Db[n - 1], Db[n - 1].shape[1])
         for i in range(n - 1, 0, -1):
             pl = self.base[i]
@@ -1842,7 +1848,7 @@ class NerfEngine:
         hv = _buf(P, self.views.out, dev, zero=False) if keep_state else None
         sigma = torch.empty(Pp, 1, device=dev)
         rgb = torch.empty(Pp, 3, device=dev)
-        cb = ChainBuilder(P, "LOAD", k8(e), site=("nerf_fwd", id(self)))
+        cb = ChainBuilder(P, "LOAD", k8(e), site=("nerf_fwd", _memo_token(self)))
         cb.init_load(Hin[0], Hin[0].shape[1])
         cb.posenc(rays_d, net.multires_view, 1.0, x_div=S)
         SK = None
@@ -1886,7 +1892,7 @@ class NerfEngine:
         Dv = _buf(P, self.views.out, dev, zero=False)
         dF = _buf(P, W, dev, zero=False)
         Dp = [_buf(P, W, dev, zero=False) for _ in range(D)]
-        cb = ChainBuilder(P, "LOAD", k8(3), site=("nerf_bwd", id(self)))
+        cb = ChainBuilder(P, "LOAD", k8(3), site=("nerf_bwd", _memo_token(self)))
         cb.init_load(Drgb, Drgb.shape[1])
         cb.step("MULMASK", self.rgb.frag(bw), k8(3), self.views.out, X1=hv, C1=Dv)
         cb.step("NONE", self.views.frag(_kind("bwd_hid:%d" % W, "bwd")), k8(self.views.out), W, C1=dF)
