@@ -272,3 +272,28 @@ def test_non_finite_values_stay_non_finite(dev):
         assert not bool(torch.isfinite(st["udf"][:2048]).any()), mode
         assert not bool(torch.isfinite(st["feat"][:2048, :256]).all(dim=1).any()), mode
         assert not bool(torch.isfinite(gr[:2048]).all(dim=1).any()), mode
+
+
+def test_f16x2_operand_beyond_fp16_range_comes_out_non_finite_not_wrong(dev):
+    """The forward-order sweeps' f16x2 split (NudfChainStep.prec 4) holds its operands in fp16's range: an activation above 65 504
+    (here: a hidden layer's bias at 1e5, so softplus passes 1e5 on) has hi = fp16(x) = inf and comes out of the next layer as a
+    NON-FINITE value -- which the renderer's status word reports -- where the exact-fp32 kernels and bf16x3 (fp32's exponent range)
+    return a finite one.  The documented price of three products instead of six (include/nudf.h): never a finite
+    wrong number."""
+    from neuraludf_amd import mlp
+    from neuraludf_amd.models import fields
+    mods = perturb_(build_modules(fields, seed=0))
+    udf = mods["udf"].to(dev)
+    with torch.no_grad():
+        udf.lin2.bias.fill_(1.0e5)
+    eng = udf.engine()
+    x = (torch.rand(2048, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(dev)
+    out = {}
+    for mode, prec, fwd in (("fp32", "fp32", "1"), ("bf16x3", "bf16x3", "0"), ("f16x2", "bf16x3", "1")):
+        mlp.set_precision(prec)
+        mlp.set_fwd_split(fwd)
+        eng.invalidate()
+        out[mode] = eng.forward(x, need_grad_state=False, udf_only=True)["udf"][:2048].clone()
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["fp32"]).all()) and bool(torch.isfinite(out["bf16x3"]).all())
+    assert not bool(torch.isfinite(out["f16x2"]).any())
