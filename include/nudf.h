@@ -125,7 +125,7 @@ typedef struct NudfGemmTNProblem {
 #define NUDF_TN_B_P4 32
 typedef struct NudfGemmTNGroup {
   int32_t n_problems, M, rows_per_block, total_tiles;   /* rows_per_block 0 = choose      */
-  int32_t prec;                                 /* as NudfGemmTN.prec                     */
+  int32_t prec;                                 /* as NudfGemmTN.prec; 4 = f16x2 (see amax_a / amax_b below) */
   NudfGemmTNProblem prob[NUDF_TN_MAX_PROBLEMS];
   float* workspace;                             /* NULL: partial tiles are accumulated with fp32 atomics.  Otherwise a
                                                    16-byte aligned scratch of >= nudf_gemm_tn_grouped_workspace()
@@ -141,6 +141,13 @@ typedef struct NudfGemmTNGroup {
                                                    ordered sum) instead of adding to them -- the first launch into a
                                                    gradient buffer then needs no zero fill.  Elements the group does not
                                                    cover (rows >= NA, columns >= NB) are left untouched.               */
+  /* prec 4 (f16x2: three fp16 MFMA products per fp32 product, NudfChainStep.prec 4) only: device scalars holding max |x| over
+     ALL A operands / ALL B operands of the group (written by the sweeps that produce them, NudfChain.absmax_out), or NULL for a
+     side whose operands lie in fp16's range as they are (activations).  Each side is multiplied by
+     2^(10 - floor(log2 max)) before the split and C by the reciprocals afterwards -- exact; a scaled element beyond +-60 000
+     (a maximum that was not reported) is clamped. */
+  const float* amax_a;
+  const float* amax_b;
 } NudfGemmTNGroup;
 int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream);
 /* floats of workspace this group needs (0 for an empty group, < 0 on an invalid one) */

@@ -47,7 +47,7 @@ class GemmTNProblem(C.Structure):
 class GemmTNGroup(C.Structure):
     _fields_ = [("n_problems", i32), ("M", i32), ("rows_per_block", i32), ("total_tiles", i32), ("prec", i32),
                 ("prob", GemmTNProblem * TN_MAX_PROBLEMS), ("workspace", c_fp), ("workspace_floats", C.c_int64),
-                ("assign", i32)]
+                ("assign", i32), ("amax_a", c_fp), ("amax_b", c_fp)]
 
 
 class BlendLoss(C.Structure):

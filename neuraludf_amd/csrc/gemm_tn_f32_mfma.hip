@@ -83,6 +83,8 @@ struct TnPlan {
                                    // XCDs with 38 one-per-CU workgroups and three with 19 -- two rounds, measured 2x slower)
   float* ws;
   long long* dbg;                  // tuning: per workgroup {start, end} of wall_clock64 (100 MHz), layout, n
+  const float* amax_a;             // f16x2 mode (prec 4): device scalars holding max |A| / max |B| over the group's operands
+  const float* amax_b;             // (NULL: that side is used unscaled)
 };
 
 static_assert(sizeof(TnPlan) <= 4096, "TnPlan is passed by value: kernel arguments are limited to 4 KB");
@@ -1433,6 +1435,246 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
 }
 
 // =======================================================================================================
+// f16x2 mode (NudfGemmTNGroup.prec == 4, round 6): fp32 emulated with THREE fp16 MFMA products per fragment pair instead of
+// bf16x3's six (NudfChainStep.prec 4 has the arithmetic: x = hi + 2^-11 lo in fp16, acc0 += hi hi', acc1 += lo hi' + hi lo',
+// result acc0 + 2^-11 acc1).  The kernel above runs against the 1 400 W package limit; a timing probe that forms three of its
+// six products (wrong results) ran the whole train step 14 % faster (3.74 -> 3.21 ms, 1 068 W at 2 386 MHz).
+// fp16's exponent range is the price: one operand of every weight-gradient problem holds adjoints of the LOSS (1e-6 ... 1e-9).
+// Each side of a group therefore carries a power-of-two scale taken from a device scalar, max |x| over that side's operands
+// (written by the chain sweeps that produce them, NudfChain.absmax_out): sigma = 2^(10 - floor(log2 max)), so the largest
+// element lands in [1024, 2048), elements down to 2^-25 of it keep all 22 bits, and C is multiplied by 1 / (sigma_a sigma_b)
+// on its way out -- exact.  A scaled element beyond +-60 000 (a producer that did not report its maximum) is clamped, not inf.
+// Same tiles, image layout (two planes instead of three: 32 KB), k-steps, workspace slots and reduce as the bf16x3 kernel;
+// the staging is its plain form (split + LDS stores between the barriers): two accumulator sets leave no registers for the
+// interleaved one.
+// =======================================================================================================
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void tn_split2_pair(float x0, float x1, float sc, unsigned& p0, unsigned& p1) {
+  x0 = __builtin_fminf(__builtin_fmaxf(x0 * sc, -60000.0f), 60000.0f);
+  x1 = __builtin_fminf(__builtin_fmaxf(x1 * sc, -60000.0f), 60000.0f);
+  const f16x2_t h = __builtin_convertvector(f32x2{x0, x1}, f16x2_t);
+  p0 = __builtin_bit_cast(unsigned, h);
+  const float r0 = (x0 - (float)h[0]) * 2048.0f, r1 = (x1 - (float)h[1]) * 2048.0f;
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2_t));
+}
+// 2^(10 - floor(log2 m)) and its reciprocal from the operand maximum (1 for NULL, 0, denormal or non-finite maxima)
+__device__ __forceinline__ void tn_scale_of(const float* amax, float& sc, float& inv) {
+  sc = 1.0f; inv = 1.0f;
+  if (!amax) return;
+  const unsigned e = (__builtin_bit_cast(unsigned, *amax) >> 23) & 0xffu;     // biased exponent of the maximum
+  if (e == 0u || e == 255u) return;
+  const int se = 127 + 10 - ((int)e - 127);                                    // biased exponent of sigma
+  if (se < 1 || se > 254) return;
+  sc = __builtin_bit_cast(float, (unsigned)se << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(254 - se) << 23);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn2_group_kernel(TnPlan g) {
+  // image: [operand 2][plane 2][k-pair group 4][column 128][4 dwords], as gemm_tn3_group_kernel's with two planes
+  __shared__ __attribute__((aligned(16))) unsigned smem[4 * T3Q];
+  unsigned* As = smem;
+  unsigned* Bs = smem + 2 * T3Q;
+
+  int t, chunk;
+  tn_decode(g, t, chunk);
+  if (t < 0) return;               // a hole of the XCD-aware order
+  const TnTile tl = g.tile[t];
+  const NudfGemmTNProblem& q = g.prob[tl.prob];
+  const int slot_id = tl.blk_start + chunk;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i0 = tl.ti * BM, j0 = tl.tj * BN;
+  const int mbeg = chunk * tl.rows_per_block;
+  const int mend = min(mbeg + tl.rows_per_block, g.M);
+  const int nk = (mend - mbeg + BK3 - 1) / BK3;
+  const int sc = tid & 127, sg = tid >> 7;          // staging: column of the tile, half of the k-step (rows 16 sg .. + 15)
+  const bool do_bias = (q.dbias != nullptr) && (tl.tj == 0) && !(g.flags & TNF_NO_BIAS);
+  float bias_acc = 0.0f;
+  float sca, inva, scb, invb;
+  tn_scale_of(g.amax_a, sca, inva);
+  tn_scale_of(g.amax_b, scb, invb);
+
+  f32x16 acc[4], acc1[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[s4][r] = 0.0f; acc1[s4][r] = 0.0f; }
+
+  const float* pa = q.A1 + min(i0 + sc, q.lda1 - 1);
+  const float* pb = q.B1 + min(j0 + sc, q.ldb1 - 1);
+  const size_t lda = (size_t)q.lda1, ldb = (size_t)q.ldb1;
+  auto load = [&](const float* p, size_t ld, float (&st)[16], int kt) {
+    const int r0 = mbeg + kt * BK3 + 16 * sg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = p[(size_t)min(r0 + r, g.M - 1) * ld];
+  };
+  // rows >= mend are zeroed (FULL: a step that lies inside the chunk needs no row tests); bias sums from the UNSCALED values
+  auto store = [&](auto FULLc, const float (&st)[16], int kt, unsigned* tile, float scale, bool bias) {
+    constexpr bool FULL = decltype(FULLc)::value;
+    const int r0 = mbeg + kt * BK3 + 16 * sg;
+    u32x4 hq[2], lq[2];
+    float ps[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      const float x0 = (FULL || r0 + 2 * pp < mend) ? st[2 * pp] : 0.0f;
+      const float x1 = (FULL || r0 + 2 * pp + 1 < mend) ? st[2 * pp + 1] : 0.0f;
+      unsigned a, b;
+      tn_split2_pair(x0, x1, scale, a, b);
+      hq[pp >> 2][pp & 3] = a; lq[pp >> 2][pp & 3] = b;
+      ps[pp] = x0 + x1;
+    }
+    if (bias) bias_acc += ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    unsigned* dst = tile + ((2 * sg) * 128 + sc) * 4;
+    *reinterpret_cast<u32x4*>(dst) = hq[0];
+    *reinterpret_cast<u32x4*>(dst + 512) = hq[1];
+    *reinterpret_cast<u32x4*>(dst + T3Q) = lq[0];
+    *reinterpret_cast<u32x4*>(dst + T3Q + 512) = lq[1];
+  };
+  // one k-step: 2 groups of 16 rows; per group 2 + 2 operand sub-tiles x 2 planes (one ds_read_b128 each) and 12 MFMAs
+  auto mma = [&]() {
+    const unsigned* as = As + ((lane >> 5) * 128 + (wave >> 1) * 64 + (lane & 31)) * 4;
+    const unsigned* bs = Bs + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK3 / 16; ++kk) {
+      u32x4 a[2][2], b[2][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          a[s2][pl] = *reinterpret_cast<const u32x4*>(as + pl * T3Q + (2 * kk) * 512 + 128 * s2);
+          b[s2][pl] = *reinterpret_cast<const u32x4*>(bs + pl * T3Q + (2 * kk) * 512 + 128 * s2);
+        }
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {          // lo hi', hi lo' (their own accumulator), hi hi'
+        const int qa = (tt == 0) ? 1 : 0, qb = (tt == 1) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (tt < 2)
+              acc1[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i][qa]),
+                                                                       __builtin_bit_cast(f16x8_t, b[j][qb]), acc1[i * 2 + j], 0, 0, 0);
+            else
+              acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[i][qa]),
+                                                                      __builtin_bit_cast(f16x8_t, b[j][qb]), acc[i * 2 + j], 0, 0, 0);
+          }
+      }
+    }
+  };
+  typedef std::integral_constant<bool, false> Ragged;
+  typedef std::integral_constant<bool, true> Full;
+  float sa[16], sb[16], sa2[16], sb2[16];
+  if (nk > 0) {
+    load(pa, lda, sa, 0);
+    load(pb, ldb, sb, 0);
+    if (nk > 1) {
+      load(pa, lda, sa2, 1);
+      load(pb, ldb, sb2, 1);
+    }
+    store(Ragged{}, sa, 0, As, sca, do_bias);
+    store(Ragged{}, sb, 0, Bs, scb, false);
+  }
+  __syncthreads();
+  auto kstep = [&](int kt, float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+    if (kt + 2 < nk) {
+      load(pa, lda, la, kt + 2);
+      load(pb, ldb, lb, kt + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
+    mma();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // every wave is done reading the image
+    if (kt + 1 < nk) {
+      store(Ragged{}, ua, kt + 1, As, sca, do_bias);
+      store(Ragged{}, ub, kt + 1, Bs, scb, false);
+    }
+    __syncthreads();
+  };
+  // steady state: FULL k-steps, buffer loads with a scalar row offset (gemm_tn3_group_kernel's loop-invariant addressing)
+  int kt0 = 0;
+  {
+    const bool last_ragged = ((mend - mbeg) % BK3) != 0 || mend > g.M;
+    const int n_fast = nk - 2 - (last_ragged ? 1 : 0);          // steps kt with kt + 1 and kt + 2 full and inside the chunk
+    if (n_fast >= 2 && (size_t)(g.M - mbeg) * (size_t)max(q.lda1, q.ldb1) * 4 < ((size_t)1 << 31)) {
+      const int sgu = __builtin_amdgcn_readfirstlane(sg);
+      const unsigned ca = (unsigned)min(i0 + sc, q.lda1 - 1), cbb = (unsigned)min(j0 + sc, q.ldb1 - 1);
+      const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.A1 + (size_t)mbeg * lda), 0,
+                                                                           (int)((size_t)(g.M - mbeg) * lda * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.B1 + (size_t)mbeg * ldb), 0,
+                                                                           (int)((size_t)(g.M - mbeg) * ldb * 4), 0x00020000);
+      const int lda4 = q.lda1 * 4, ldb4 = q.ldb1 * 4;
+      int ba = (2 * BK3 + 16 * sgu) * lda4, bb = (2 * BK3 + 16 * sgu) * ldb4;       // scalar byte offsets of the rows of step kt + 2
+      const int sa_step = BK3 * lda4, sb_step = BK3 * ldb4;
+      auto load_f = [&](__amdgpu_buffer_rsrc_t rs, int so, int ld4, unsigned col, float (&st)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          st[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(col * 4), so + r * ld4, 0));
+      };
+      auto fstep = [&](float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+        load_f(rsa, ba, lda4, ca, la);
+        load_f(rsb, bb, ldb4, cbb, lb);
+        ba += sa_step;
+        bb += sb_step;
+        __builtin_amdgcn_sched_barrier(0);
+        mma();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        store(Full{}, ua, 0, As, sca, do_bias);
+        store(Full{}, ub, 0, Bs, scb, false);
+        __syncthreads();
+      };
+      do {
+        fstep(sa, sb, sa2, sb2);
+        fstep(sa2, sb2, sa, sb);
+        kt0 += 2;
+      } while (kt0 + 1 < n_fast);
+    }
+  }
+  for (int kt = kt0; kt < nk; kt += 2) {
+    kstep(kt, sa, sb, sa2, sb2);
+    if (kt + 1 < nk) kstep(kt + 1, sa2, sb2, sa, sb);
+  }
+
+  if (g.flags & TNF_NO_EPILOGUE) return;
+  float* slot = g.ws ? g.ws + (size_t)slot_id * TN_WS_TILE : nullptr;
+  if (do_bias) {   // the loop's last barrier has passed: the operand image is free
+    float* red = reinterpret_cast<float*>(smem);
+    red[sg * BM + sc] = bias_acc;
+    __syncthreads();
+    if (tid < BM) {
+      const float sum = red[tid] + red[BM + tid];
+      if (slot) slot[BM * BN + tid] = sum;
+      else if (i0 + tid < q.NA) atomicAdd(q.dbias + i0 + tid, sum);
+    }
+  }
+  const float unscale = inva * invb;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s4][r] = __builtin_fmaf(acc1[s4][r], 1.0f / 2048.0f, acc[s4][r]) * unscale;
+    if (slot) {   // accumulator register order, 64 contiguous bytes per lane (tn_reduce_kernel decodes it)
+      float* w = slot + ((wave * 4 + s4) * 64 + lane) * 16;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {acc[s4][4 * qd], acc[s4][4 * qd + 1], acc[s4][4 * qd + 2], acc[s4][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(w + 4 * qd) = v;
+      }
+    } else {
+      const int col = j0 + 32 * tn_jsub(2, wave, s4) + (lane & 31);
+      if (col >= q.NB) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 32 * tn_isub(2, wave, s4) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < q.NA) atomicAdd(q.C + (size_t)row * q.ldc + col, acc[s4][r]);
+      }
+    }
+  }
+}
+
+// =======================================================================================================
 // bf16x3 mode, WIDE form (round 5; OPT-IN through NUDF_TN_FLAGS bit 1024 -- it measured slower): one
 // 8-wave workgroup per CU computes TWO vertically adjacent 128 x 128 tiles of a problem -- a 256 x 128 block: 25 % less
 // operand traffic per flop than two 128 x 128 workgroups (the B panel is staged once) -- from a DOUBLE-BUFFERED split image
@@ -2017,6 +2259,24 @@ extern "C" int nudf_gemm_tn_grouped(const NudfGemmTNGroup* args, void* stream) {
   }
   // bf16x3 mode: the split-image kernel when every operand is fp32 row-major (what the bf16x3 chains store); anything else
   // goes through the generic kernel, which splits on the way OUT of its fp32 image (NUDF_TN_FLAGS & 512 forces that: A/B)
+  // f16x2 mode (prec 4): fp32 row-major operands only (what the split-mode chains store); anything else is an error -- the
+  // caller decides per group (mlp.py) and falls back to prec 3 itself
+  if (pl.prec == 4) {
+    for (int i = 0; i < args->n_problems; ++i)
+      if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) {
+        nudf_set_error("nudf_gemm_tn_grouped: prec 4 (f16x2) takes fp32 row-major operands", hipErrorInvalidValue);
+        return (int)hipErrorInvalidValue;
+      }
+    pl.amax_a = args->amax_a;
+    pl.amax_b = args->amax_b;
+    hipLaunchKernelGGL(gemm_tn2_group_kernel, dim3(pl.grid_blocks), dim3(256), 0, (hipStream_t)stream, pl);
+    NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped");
+    if (pl.ws && !(pl.flags & TNF_NO_EPILOGUE)) {
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(pl.n_tiles * 17), dim3(256), 0, (hipStream_t)stream, pl);
+      NUDF_CHECK_LAUNCH("nudf_gemm_tn_grouped (reduce)");
+    }
+    return 0;
+  }
   bool split3 = pl.prec == 3 && !(pl.flags & TNF_NO_SPLIT_IMAGE);
   for (int i = 0; i < args->n_problems && split3; ++i)
     if (args->prob[i].flags & (NUDF_TN_A16 | NUDF_TN_B16 | NUDF_TN_A_BLK | NUDF_TN_B_BLK | NUDF_TN_A_P4 | NUDF_TN_B_P4)) split3 = false;

@@ -539,15 +539,21 @@ def tn_can_assign():
     return TN_ASSIGN and TN_DETERMINISTIC and not (int(os.environ.get("NUDF_TN_FLAGS", "0")) & (8 | 2))
 
 
-def gemm_tn_grouped(jobs, M, assign=False, rows_per_block=0):
+def gemm_tn_grouped(jobs, M, assign=False, rows_per_block=0, f16x2=False, amax_a=None, amax_b=None):
     """jobs: [(A1 [M, lda], NA, B1 [M, ldb], NB, C [NA_pad, ldc], dbias | None)] -> one launch per <= 12 problems.
     assign: C / dbias are assigned, not accumulated into (every C must then appear in ONE job; see `alloc_grads`).
-    rows_per_block: 0 = the library chooses the row chunks (tests pin them to compare kernels bit for bit)."""
+    rows_per_block: 0 = the library chooses the row chunks (tests pin them to compare kernels bit for bit).
+    f16x2 (bf16x3 mode, fp32 row-major operands): three fp16 MFMA products per fp32 product (NudfGemmTNGroup.prec 4); amax_a /
+    amax_b = one-element device tensors holding max |x| over all A / all B operands of the call (None: that side's operands
+    lie in fp16's range unscaled -- activations)."""
     for base in range(0, len(jobs), _lib.TN_MAX_PROBLEMS):
         chunk = jobs[base:base + _lib.TN_MAX_PROBLEMS]
         g = _lib.GemmTNGroup()
         g.n_problems, g.M, g.rows_per_block = len(chunk), M, rows_per_block
         g.prec = _tn_prec()                            # mixed16: bf16 operands for the weight gradients as well
+        if f16x2 and g.prec == 3 and not any(_is16(t) or _isblk(t) for j in chunk for t in (j[0], j[2])):
+            g.prec = 4
+            g.amax_a, g.amax_b = ptr(amax_a), ptr(amax_b)
         flops = nbytes = 0.0
         for i, (A1, NA, B1, NB, Cm, db) in enumerate(chunk):
             q = g.prob[i]
@@ -563,7 +569,8 @@ def gemm_tn_grouped(jobs, M, assign=False, rows_per_block=0):
         g.assign = 1 if assign else 0
         if PROFILE is not None:
             _timed("gemm_tn", flops, lambda: call("nudf_gemm_tn_grouped", g),
-                   "gemm_tn_group_kernel %d problems M=%d (%.1f GFLOP)" % (len(chunk), M, flops / 1e9), nbytes)
+                   "gemm_tn%s_group_kernel %d problems M=%d (%.1f GFLOP)" % ({3: "3", 4: "2"}.get(int(g.prec), ""), len(chunk), M, flops / 1e9),
+                   nbytes, flops * MFMA_PRODUCTS.get(int(g.prec), 1) if (int(g.prec) != 3 or TN_SPLIT) else flops)
         else:
             call("nudf_gemm_tn_grouped", g)
 

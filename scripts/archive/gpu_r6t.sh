@@ -1,0 +1,17 @@
+#!/bin/bash
+# timing probe: the split-image weight-gradient kernel forming THREE of its six partial products (wrong results): what a 3-product
+# split of the GEMM could be worth at most with the same staging
+set -u
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r6t; rm -rf $O; mkdir -p $O
+cd $R
+for v in base tn3p3 base tn3p3; do
+  L=$R/neuraludf_amd/build/libnudf_$v.so; [ $v = base ] && L=$R/neuraludf_amd/libnudf.so
+  NUDF_LIB=$L timeout 600 python bench.py --no-cpu-baseline --no-fp32-leg --no-forward-only > $O/bench_$v.json 2>> $O/bench.err
+  python - "$O/bench_$v.json" "$v" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+print("%s: %.3f ms  windows %s  power %s W %s MHz  chains %.3f ms  gemm %.3f ms" % (sys.argv[2], d["ms_per_step"], [round(w, 3) for w in d["window_ms"]], round(d["power"].get("avg_w", 0)), round(d["power"].get("sclk_mhz_avg", 0)), d["kernels"]["mlp_chain"]["ms"], d["kernels"]["gemm_tn"]["ms"]) + "  groups " + " / ".join("%.0f" % k["us"] for k in r["per_kernel"] if k["class"] == "gemm_tn"))
+PY
+done

@@ -96,3 +96,49 @@ def test_fast_host_path_trains_bit_identically_and_hits_the_descriptor_memo(dev)
     assert l0 == l1, (l0, l1)
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [333, 8192])
+def test_f16x2_weight_gradient_gemm_against_float64(dev, M):
+    """NudfGemmTNGroup.prec 4 (gemm_tn2_group_kernel): three fp16 MFMA products per fp32 product, each side scaled by a power of
+    two taken from the device scalar max |x| of its operands.  A = loss adjoints (1e-7, columns of mixed scale), B = activations:
+    the error against the float64 contraction is no larger than 1.5x the exact fp32 kernel's (as held for bf16x3), with the
+    maximum reported, and with B unscaled (amax_b = None); a maximum under-reported by 2^12 is clamped: finite and coarse, not
+    inf."""
+    from neuraludf_amd import mlp, _lib
+    g = torch.Generator().manual_seed(11)
+    shapes = [(256, 256), (217, 256), (256, 40), (3, 128), (129, 72), (1, 256)]
+    ops = []
+    for NA, NB in shapes:
+        lda, ldb = (NA + 3) // 4 * 4, (NB + 3) // 4 * 4
+        A = torch.randn(M, lda, generator=g) * torch.exp(torch.randn(1, lda, generator=g)) * 1e-7
+        B = torch.randn(M, ldb, generator=g).abs() * 0.3
+        ops.append((A, B, NA, NB))
+    ref = [((A[:, :NA].double().t() @ B[:, :NB].double()), A[:, :NA].double().sum(0)) for A, B, NA, NB in ops]
+    amax = torch.stack([A.abs().max() for A, _, _, _ in ops]).max().reshape(1).to(dev)
+
+    def run(mode, **kw):
+        mlp.set_precision(mode)
+        jobs = [(A.to(dev), NA, B.to(dev), NB, torch.zeros(mlp.pad32(NA), B.shape[1], device=dev),
+                 torch.zeros(mlp.pad32(NA), device=dev)) for A, B, NA, NB in ops]
+        mlp.gemm_tn_grouped(jobs, M, **kw)
+        torch.cuda.synchronize()
+        return [(_err(j[4][:NA, :NB], r[0]), _err(j[5][:NA], r[1]), bool(torch.isfinite(j[4]).all()))
+                for j, (A, B, NA, NB), r in zip(jobs, ops, ref)]
+
+    e32 = run("fp32")
+    e3 = run("bf16x3")
+    e2 = run("bf16x3", f16x2=True, amax_a=amax)
+    e2b = run("bf16x3", f16x2=True, amax_a=amax, amax_b=torch.tensor([0.3 * 4.0], device=dev))
+    low = run("bf16x3", f16x2=True, amax_a=amax / 4096.0)
+    print("C error vs float64 x 1e-7: exact fp32 / bf16x3 / f16x2 / f16x2 both scaled:",
+          [(round(a[0] * 1e7, 2), round(b[0] * 1e7, 2), round(c[0] * 1e7, 2), round(d[0] * 1e7, 2)) for a, b, c, d in zip(e32, e3, e2, e2b)])
+    for (c32, b32, _), (c3, _, _), (c2, b2, f2), (c2b, _, _), (cl, _, fl) in zip(e32, e3, e2, e2b, low):
+        assert c2 <= 1.5 * c32 + 2e-7 and c2b <= 1.5 * c32 + 2e-7, (c32, c3, c2, c2b)
+        assert b2 <= 3e-6 and f2
+        assert fl and cl < 1.0            # clamped operands: wrong by construction, but finite
+
+
+def _err(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    return float((a - ref).abs().max() / ref.abs().max().clamp(min=1e-300))
