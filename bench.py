@@ -47,12 +47,25 @@ MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 (MI355X_MICROARCH.md)
 # parts; hi hi, hi mid, mid hi, hi lo, lo hi, mid mid; fp32 accumulate) -- the flops a launch EXECUTES on the bf16 pipe
 X3_PRODUCTS = 6
 DTYPE = {"fp32": "f32",
-         "bf16x3": "f32 emulated on the 16-bit matrix pipe, f32 accumulate, f32 state / epilogues / optimizer: backward sweeps "
-                   "(tangent, adjoint, ReLU backward) and weight-gradient GEMMs bf16x3 (operands split exactly into 3 bf16 parts, "
-                   "6 bf16 MFMA products per f32 product); forward-order sweeps (UDF value, input gradient, colour / NeRF forward) "
-                   "f16x2 (x = hi + 2^-11 lo in fp16, 3 fp16 MFMA products, correction terms in their own accumulator); "
-                   "fp32-level accuracy against float64 in both (tests/test_gpu_bf16x3.py)",
          "mixed16": "f16/bf16 MFMA operands, f32 accumulate, bf16 saved state (config 5 mode)"}
+
+
+def dtype_string(precision):
+    """what the arithmetic of this run was, from the switches actually in force (mlp.FWD_F16X2, mlp.TN_F16X2)"""
+    if precision != "bf16x3":
+        return DTYPE[precision]
+    from neuraludf_amd import mlp
+    b3 = "bf16x3 (operands split exactly into 3 bf16 parts, 6 bf16 MFMA products per f32 product)"
+    f2 = "f16x2 (x = hi + 2^-11 lo in fp16, 3 fp16 MFMA products, correction terms in their own accumulator)"
+    fwd = f2 if mlp.FWD_F16X2 != "0" else b3
+    tn = ("f16x2 for the UDF and colour networks (each operand scaled by a power of two from its maximum, tracked on the device "
+          "by the sweep that wrote it), bf16x3 for the background NeRF") if mlp.TN_F16X2 else "bf16x3"
+    return ("f32 emulated on the 16-bit matrix pipe, f32 accumulate, f32 state / epilogues / optimizer.  Backward sweeps (tangent, "
+            f"adjoint, ReLU backward): {b3}.  Forward-order sweeps (UDF value, input gradient, colour / NeRF forward): "
+            f"{fwd if fwd is f2 else 'bf16x3 (NUDF_FWD_F16X2=0)'}.  Weight-gradient GEMMs: {tn}.  fp32-level accuracy against float64 "
+            "in each (tests/test_gpu_bf16x3.py, tests/test_gpu_round6.py)")
+
+
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -568,9 +581,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None,
         "window_ms": [w / args.steps * 1e3 for w in wins], "windows": n_win,
-        "dtype": (DTYPE[args.precision] if not (args.precision == "bf16x3" and mlp.FWD_F16X2 == "0") else
-                  "f32 emulated on the bf16 matrix pipe: operands split exactly into 3 bf16 parts, 6 bf16 MFMA products per f32 "
-                  "product on every sweep (NUDF_FWD_F16X2=0), f32 accumulate; f32 state, epilogues, optimizer"),
+        "dtype": dtype_string(args.precision),
         "data": "synthetic",
         "config": {"workload": args.workload, "rays_per_gpu": rays_per_gpu, "global_rays": rays_per_gpu * world,
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],

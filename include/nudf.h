@@ -635,6 +635,12 @@ typedef struct NudfChain {
   const float* seed_wrow;          /* [k0]                                                           */
   unsigned long long* dbg;         /* NULL, or [blocks*4 waves][64] timeline: hw_id, t0, per step (K loop end,
                                       after barrier 1, epilogue end, after barrier 2) in s_memtime ticks */
+  float* absmax_out;               /* NULL, or ONE device float (zeroed by the caller; split modes of the workgroup-shared kernel):
+                                      the launch raises it (atomic max) to the largest |value| it puts into the stored arrays a
+                                      weight-gradient GEMM will read -- the initial tile (INIT_LOAD values; for the JVP encoding the
+                                      bound 2^(L-1) |v| in_scale), every C1 / pe-free output of its MULSP / BWD / MULMASK / ADDMASK /
+                                      NONE steps, and the rank-1 operand r1_row.  It is what scales that side of an f16x2 GEMM
+                                      (NudfGemmTNGroup.amax_a / amax_b).                                                      */
   NudfChainStep step[NUDF_CH_MAX_STEPS];
 } NudfChain;
 int nudf_mlp_chain(const NudfChain* args, void* stream);

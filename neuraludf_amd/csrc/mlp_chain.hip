@@ -676,11 +676,14 @@ __device__ __forceinline__ void ch_p4_store(float* C, int ld, unsigned q0, unsig
 // holds bf16, else fp16) -- the new activations are rounded ONCE here, on their way into the tile, instead of in the K loop of
 // each of the four waves that read them (same values: the next step's MFMAs see the same operands)
 struct ChNoX3 {};
+// Returns the largest |value| the tile contributes to NudfChain.absmax_out (its C1 output and its rank-1 operand); callers that
+// do not track it drop the result and the compiler drops its computation.
 template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false, bool T16 = false, bool HX3 = false, class X3V = ChNoX3>
-__device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
+__device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
                                                  const float* x2in = nullptr, const float* bias_pre = nullptr,
                                                  bool tile_bf = false, const X3V& x3in = X3V()) {
+  float tmax = 0.0f;
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
   const unsigned colc = col_ok ? col : 0;
@@ -697,7 +700,11 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
     const float r1c = st.r1_col[colc];
     const unsigned vo = grow0 * (unsigned)st.ldr1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo] * r1c;
+    for (int r = 0; r < 16; ++r) {
+      const float rv = (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo];
+      tmax = fmaxf(tmax, fabsf(rv));        // (NudfChain.absmax_out: the rank-1 operand is a GEMM operand too)
+      v[r] += rv * r1c;
+    }
   }
   float x2[16];   // x1 (the stored activation) was prefetched under the fp32 K loop; the short 16-bit loops load it here
   if (CH_USES_X1(EPI) && load_x1) {
@@ -824,7 +831,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
 #pragma unroll
       for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
     }
-    return;
+    return tmax;
   }
 #endif
   // ---- stores ----
@@ -836,7 +843,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
         if (st.C1) st.C1[grow0 + CH_KOFF(r)] = out2[r];
       }
     }
-    return;
+    return tmax;
   }
   if (EPI == NUDF_CH_SIGMOIDN) {
     if (col_ok) {
@@ -858,6 +865,10 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       }
     }
   } else if (col_ok) {
+    if (st.C1) {      // NudfChain.absmax_out: the largest value this launch stores for a weight-gradient GEMM to read
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(fabsf(out[r]), fabsf(out[r + 1])));
+    }
     if (EPI == NUDF_CH_MULSP && st.iparam > 0 && col >= st.iparam) {
       if (st.C2) {
         const unsigned vo = grow0 * (unsigned)st.ldc2 + (col - st.iparam);
@@ -903,6 +914,7 @@ __device__ __forceinline__ void ch_epilogue_tile(const NudfChainStep& st, float*
       for (int r = 0; r < 16; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
     }
   }
+  return tmax;
 }
 
 // Epilogues with a SECOND stored operand (X2: tangent, adjoint, ReLU joins), full-height wave blocks: the tiles as
@@ -1000,8 +1012,9 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 // bf16x3 mode (fp32 stored state, no operand prefetch under the K loop: the split needs those registers): BOTH stored
 // operands of tile t + 1 are requested before tile t is computed and stored, as in ch_epilogue_seq16.
 template <int EPI, int NRT, int NCT, bool X3 = false>
-__device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
+__device__ __forceinline__ float ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
                                                   int ln, f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+  float smax = 0.0f;
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI), U3 = (EPI == NUDF_CH_BWD) && X3;
   // (three stored operands: one tile ahead -- the same 96 registers as two operands two tiles ahead)
   constexpr int AHEAD = U3 ? 1 : NUDF_X3_EPI_AHEAD;
@@ -1055,13 +1068,14 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
     if (t + AH < NTL)
       issue(xa[(t + AH) % (AH + 1)], xb[(t + AH) % (AH + 1)], xc[U3 ? (t + AH) % (AH + 1) : 0], (t + AH) / NCT, (t + AH) % NCT);
     if constexpr (U3)
-      ch_epilogue_tile<EPI, true, false, false, false, true, float[16]>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln,
-                                                                        acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
-                                                                        xb[t % (AH + 1)], &bpre[t % NCT], false, xc[t % (AH + 1)]);
+      smax = fmaxf(smax, ch_epilogue_tile<EPI, true, false, false, false, true, float[16]>(
+                             st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
+                             xb[t % (AH + 1)], &bpre[t % NCT], false, xc[t % (AH + 1)]));
     else
-      ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
-                                  xb[t % (AH + 1)], &bpre[t % NCT]);
+      smax = fmaxf(smax, ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT],
+                                                     xa[t % (AH + 1)], false, xb[t % (AH + 1)], &bpre[t % NCT]));
   }
+  return smax;
 }
 
 // NUDF_CH_BWD with THREE stored operands (NudfChainStep.X3: X1 = X[l], X2 = R[l], X3 = DA[l-1]; fp32 state, split modes), the
@@ -1069,8 +1083,9 @@ __device__ __forceinline__ void ch_epilogue_seq32(const NudfChainStep& st, float
 // stored -- 2 x 3 x 8 = 48 registers in flight instead of the 96 of whole tiles (which spilled 22 registers into a K loop
 // whose every scratch access waits vmcnt(0)).  out = (acc + bias [+ rank-1 term]) scale s + X2 X3 100 (1 - s) / (s scale).
 template <int NRT, int NCT>
-__device__ __forceinline__ void ch_epilogue_bwd3(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h, int ln,
-                                                 f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+__device__ __forceinline__ float ch_epilogue_bwd3(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h, int ln,
+                                                  f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+  float bmax = 0.0f;
   constexpr int NU = NRT * NCT * 2;
   float xa[2][8], xb[2][8], xc[2][8];
   auto coords = [&](int u, unsigned& row0, int& col, unsigned& colc) {
@@ -1107,7 +1122,11 @@ __device__ __forceinline__ void ch_epilogue_bwd3(const NudfChainStep& st, float*
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float v = acc[i][j][8 * hf + r] + bias;
-      if (st.r1_row) v += (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[row0 * (unsigned)st.ldr1] * r1c;
+      if (st.r1_row) {
+        const float rv = (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[row0 * (unsigned)st.ldr1];
+        bmax = fmaxf(bmax, fabsf(rv));
+        v += rv * r1c;
+      }
       const float x = 100.0f * st.xscale * xa[u & 1][r];
       const float om = __builtin_amdgcn_exp2f(x * -1.44269504f);
       const float sg = 1.0f - om;
@@ -1118,6 +1137,8 @@ __device__ __forceinline__ void ch_epilogue_bwd3(const NudfChainStep& st, float*
       const unsigned vo = row0 * (unsigned)st.ldc1 + (unsigned)col;
 #pragma unroll
       for (int r = 0; r < 8; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) bmax = __builtin_fmaxf(bmax, __builtin_fmaxf(fabsf(out[r]), fabsf(out[r + 1])));
     }
     if (st.act_write) {
       float* ap = act + ((rt0 + i) * 32 + 4 * h + 16 * hf) * CH_LD + st.act_col0 + col;
@@ -1125,13 +1146,15 @@ __device__ __forceinline__ void ch_epilogue_bwd3(const NudfChainStep& st, float*
       for (int r = 0; r < 8; ++r) ap[CH_KOFF(r) * CH_LD] = col_ok ? out[r] : 0.0f;
     }
   }
+  return bmax;
 }
 
 // epilogue of one step for this wave's tiles: new activations -> LDS (+ HBM where a later sweep needs them)
 template <int EPI, int MODE>
-__device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
+__device__ __forceinline__ float ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
                                             const float (&px1)[2][2][16], const float (&bpre)[2], bool tile_bf = false) {
+  float emax = 0.0f;
   constexpr bool ANY16 = MODE == 1 || MODE == 3 || MODE == 4, X3 = MODE == 2, T16 = MODE == 3 || MODE == 4;
   constexpr bool PF = CH_USES_X1(EPI);
   if constexpr (CH_USES_X2(EPI) && !T16) {
@@ -1139,24 +1162,22 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
       float(&x1)[2][2][16] = const_cast<float(&)[2][2][16]>(px1);
       if (nct == 2) ch_epilogue_seq<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, x1, bpre);
       else ch_epilogue_seq<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, x1, bpre);
-      return;
+      return emax;
     }
   }
   if constexpr (X3 && EPI == NUDF_CH_BWD) {
     if (st.X3) {      // second-order term formed from R and DA (NudfChainStep.X3): three stored operands, fp32 state
-      if (nrt == 2 && nct == 2) ch_epilogue_bwd3<2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else if (nrt == 2) ch_epilogue_bwd3<2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else if (nct == 2) ch_epilogue_bwd3<1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else ch_epilogue_bwd3<1, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      return;
+      if (nrt == 2 && nct == 2) return ch_epilogue_bwd3<2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else if (nrt == 2) return ch_epilogue_bwd3<2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else if (nct == 2) return ch_epilogue_bwd3<1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else return ch_epilogue_bwd3<1, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
     }
   }
   if constexpr (X3 && CH_USES_X1(EPI)) {
     if (st.prec >= 3 && nrt * nct >= 2) {
-      if (nrt == 2 && nct == 2) ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else if (nrt == 2) ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      return;
+      if (nrt == 2 && nct == 2) return ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else if (nrt == 2) return ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      else return ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
     }
   }
   if constexpr (ANY16 && (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
@@ -1165,12 +1186,12 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
         if (st.X3) {
           if (nct == 2) ch_epilogue_seq16<EPI, 2, 2, T16, true>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
           else ch_epilogue_seq16<EPI, 2, 1, T16, true>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
-          return;
+          return emax;
         }
       }
       if (nct == 2) ch_epilogue_seq16<EPI, 2, 2, T16>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
       else ch_epilogue_seq16<EPI, 2, 1, T16>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tile_bf);
-      return;
+      return emax;
     }
   }
   const int ntiles = nrt * nct;
@@ -1232,9 +1253,10 @@ __device__ __forceinline__ void ch_epilogue(const NudfChain& p, const NudfChainS
       }
     }
     constexpr bool RT16 = ANY16 && (EPI == NUDF_CH_RELU || EPI == NUDF_CH_MULMASK || EPI == NUDF_CH_ADDMASK);
-    ch_epilogue_tile<EPI, false, false, RT16, T16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3, nullptr, &bpre[j],
-                                                   tile_bf);
+    emax = fmaxf(emax, ch_epilogue_tile<EPI, false, false, RT16, T16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3, nullptr,
+                                                                      &bpre[j], tile_bf));
   }
+  return emax;
 }
 
 // ANY16: some step of the chain uses 16-bit MFMA operands (config-5 mode).  The fp32 chains get a kernel without any of
@@ -1271,6 +1293,8 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
   const int wave = tid >> 6;
   const int h = lane >> 5, ln = lane & 31;
   const int m0 = blockIdx.x * TM;
+  // NudfChain.absmax_out (split modes): the largest |value| this thread puts into arrays a weight-gradient GEMM will read
+  float amax = 0.0f;
 
   // ---- tile initialisation ---------------------------------------------------------------------
   if (p.x) {
@@ -1279,6 +1303,9 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
       if (r > p.P - 1) r = p.P - 1;
       sm.xs[e] = p.x[(size_t)(r / p.x_div) * 3 + (e % 3)];   // x_div = samples per ray for per-ray directions
       sm.vs[e] = p.v ? p.v[(size_t)r * 3 + (e % 3)] : 0.0f;
+      // (JVP encoding: every element of the initial tile is (2^k or 1) v in_scale times a sine / cosine, k < pe_L)
+      if (X3 && p.v && p.init == NUDF_CH_INIT_POSENC)
+        amax = fmaxf(amax, fabsf(sm.vs[e] * p.pe_in_scale) * (float)(1 << (p.pe_L > 0 ? p.pe_L - 1 : 0)));
     }
   }
   __syncthreads();
@@ -1289,6 +1316,7 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
       int gr = m0 + r;
       if (gr > p.P - 1) gr = p.P - 1;
       const f32x4 val = *reinterpret_cast<const f32x4*>(p.A0 + (size_t)gr * p.lda0 + c4 * 4);
+      if constexpr (X3) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(val[0]), fabsf(val[1])), fmaxf(fabsf(val[2]), fabsf(val[3]))));
       if constexpr (T16) {
         uint2 w;
         if (tile_bf) {
@@ -1532,16 +1560,16 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
     if (nct > 0) {
       switch (st.epi) {
         case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_NONE: ch_epilogue<NUDF_CH_NONE, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_MULSP: ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_NONE: { const float em = ch_epilogue<NUDF_CH_NONE, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_MULSP: { const float em = ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
         case NUDF_CH_TANGENT:     // (MODE 3 never runs a TANGENT chain: the dispatcher sends those to MODE 4)
           if constexpr (MODE != 3) ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf);
           break;
-        case NUDF_CH_BWD: ch_epilogue<NUDF_CH_BWD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_BWD: { const float em = ch_epilogue<NUDF_CH_BWD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
         case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
         case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_MULMASK: ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_ADDMASK: ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_MULMASK: { const float em = ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_ADDMASK: { const float em = ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
         case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
         default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
       }
@@ -1559,6 +1587,13 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
   }
   if (dbg && lane == 0) dbg[63] = wall_clock64();
+  if constexpr (X3) {
+    if (p.absmax_out) {      // non-negative floats order like their bit patterns: one unsigned atomic max per wave
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+      if (lane == 0 && amax > 0.0f && amax < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(p.absmax_out), __builtin_bit_cast(unsigned, amax));
+    }
+  }
 }
 
 int nudf_chain_rows_class(const NudfChain& p, bool allow_blocked = false);  // mlp_chain_rows.hip

@@ -291,10 +291,16 @@ class ChainBuilder:
     def step(self, *a, **kw):
         self.rec.append((4, a, kw))
 
+    def absmax(self, *a, **kw):
+        """one zeroed device float the launch raises to the largest |value| it stores for a weight-gradient GEMM to read
+        (NudfChain.absmax_out): the scale of that side of an f16x2 GEMM"""
+        self.rec.append((5, a, kw))
+
     # positional parameter names of the recorded calls, and the descriptor field every tensor argument lands in
     _PARAMS = (("x", "L", "in_scale", "tangent", "x_div"), ("G0",), ("A0", "lda0"),
-               ("A0", "lda0", "sign", "wrow", "scale", "xscale"), ("epi", "Bp", "K", "N"))
-    _CHAIN_FIELD = ({"x": "x", "tangent": "v"}, {"G0": "G0"}, {"A0": "A0"}, {"A0": "A0", "sign": "seed_sign", "wrow": "seed_wrow"})
+               ("A0", "lda0", "sign", "wrow", "scale", "xscale"), ("epi", "Bp", "K", "N"), ("t",))
+    _CHAIN_FIELD = ({"x": "x", "tangent": "v"}, {"G0": "G0"}, {"A0": "A0"}, {"A0": "A0", "sign": "seed_sign", "wrow": "seed_wrow"},
+                    None, {"t": "absmax_out"})
 
     def _signature(self):
         """-> (structure, pointers): the record with every tensor replaced by its element count, and the tensors' addresses
@@ -326,7 +332,7 @@ class ChainBuilder:
         self.c = Chain()
         self.c.P, self.c.init, self.c.k0, self.c.tile_rows = self.P, CH_INIT[self.init], self.k0, self.tile_rows
         self.c.x_div = 1
-        fns = (self._do_posenc, self._do_init_store, self._do_init_load, self._do_init_seed, self._do_step)
+        fns = (self._do_posenc, self._do_init_store, self._do_init_load, self._do_init_seed, self._do_step, self._do_absmax)
         T = torch.Tensor
         slots = []
         for kind, a, kw in self.rec:
@@ -364,6 +370,9 @@ class ChainBuilder:
                 if self.c.init != CH_INIT["SEED"]:
                     raise _lib.NudfError("a bf16 / blocked copy of the initial tile exists for the SEED initialisation only")
                 self.c.init_state16 |= 2 if _is16(G0) else 8
+
+    def _do_absmax(self, t):
+        self.c.absmax_out = self._p(t)
 
     def _do_init_load(self, A0, lda0):
         self.c.A0, self.c.lda0 = self._p(A0), lda0
@@ -722,6 +731,10 @@ FWD_F16X2 = os.environ.get("NUDF_FWD_F16X2", "1")
 # the adjoint sweep forms the second-order term from R and DA instead of reading an EX array the tangent sweep stored
 # (NudfChainStep.X3; UDFEngine._backward_chain): 0 = the stored form (A/B)
 EX_FLY = os.environ.get("NUDF_EX_FLY", "1") != "0"
+# bf16x3 mode: the weight-gradient GEMMs of the UDF and colour networks on THREE fp16 products (NudfGemmTNGroup.prec 4,
+# gemm_tn2_group_kernel) -- the side of every problem that holds loss adjoints is scaled by a power of two taken from the
+# maximum the producing sweeps report (NudfChain.absmax_out), the activation side is used as it is.  0 = bf16x3 GEMMs (A/B).
+TN_F16X2 = os.environ.get("NUDF_TN_F16X2", "1") != "0"
 TN_SPLIT = os.environ.get("NUDF_TN_SPLIT", "1") != "0"      # bf16x3 mode: the weight-gradient GEMMs take split operands too
 
 
@@ -1222,6 +1235,10 @@ class UDFEngine:
         # (NudfChainStep.X3).  The tangent sweep is then MULSP steps: one array in (X), one out (R) per layer instead of
         # two and two.  Split / 16-bit modes on the workgroup-shared kernel (the fp32 kernels keep the stored form).
         ex_fly = second and EX_FLY and PRECISION != "fp32" and not _isblk(X[L]) and CHAIN_TILE in (0, 32, 64)
+        # f16x2 weight-gradient GEMMs: [max |adjoint-sweep arrays|, max |tangent-sweep arrays|], raised by the two sweeps
+        tn2 = (TN_F16X2 and PRECISION == "bf16x3" and TN_SPLIT and grouped and head4_path and not _isblk(X[L]) and not _is16(X[L])
+               and CHAIN_TILE in (0, 32, 64))
+        amax = torch.zeros(2, device=dev) if tn2 else None
         if second:
             sd, blk = X[L].dtype, _isblk(X[L])
             R = ([_buf(P, layers[0].inp, dev, zero=False)] +
@@ -1230,6 +1247,8 @@ class UDFEngine:
             cb = ChainBuilder(P, "POSENC", k8(self.E), site=("udf_tangent", _memo_token(self)))
             cb.posenc(x, net.multires, float(net.scale), tangent=d_g.contiguous())
             cb.init_store(R[0])
+            if tn2:
+                cb.absmax(amax[1:2])
             for l in range(L):
                 pl = layers[l]
                 nxt_skip = (l + 1) in self.skip
@@ -1277,6 +1296,8 @@ class UDFEngine:
         if d_feat is None:
             d_feat, d_feat_ld = torch.zeros(P, k8(F), device=dev), k8(F)
         cb.init_load(d_feat, d_feat_ld)
+        if tn2:
+            cb.absmax(amax[0:1])
         for l in range(L, 0, -1):
             pl = layers[l]
             sc = self.inv_sqrt2 if l in self.skip else 1.0
@@ -1305,13 +1326,15 @@ class UDFEngine:
                 jobs.append((head4, 1, X[L], plL.in_pad, dWL[:1], dbL[:1]))
             else:
                 jobs.append((ABAR[L], plL.out, X[L], plL.in_pad, dWL, dbL))
-            gemm_tn_grouped(jobs, P, assign=assign)
+            # (f16x2: the A side -- ABAR, d feat, the head's column-0 operand -- carries the adjoint sweep's maximum, X is used as it is)
+            gemm_tn_grouped(jobs, P, assign=assign, f16x2=tn2, amax_a=amax[0:1] if tn2 else None)
             if second:
                 jobs = [(DA[l], layers[l].out, R[l], layers[l].in_pad, grads[l][0], None) for l in range(L)]
                 if head4_path:
                     # d (row 0 of the head) through the d udf / dx path: sign^T R_L / scale
                     jobs.append((sg4, 1, R[L], plL.in_pad, dWL[:1], None))
-                gemm_tn_grouped(jobs, P)
+                # (f16x2: the B side -- R -- carries the tangent sweep's maximum; DA and sign / scale are used as they are)
+                gemm_tn_grouped(jobs, P, f16x2=tn2, amax_b=amax[1:2] if tn2 else None)
             return unpack_group(layers, grads, claim_grad_slot(self, layers))
         for l, pl in enumerate(layers):
             dW, db = grads[l]
@@ -1590,8 +1613,12 @@ class ColorEngine:
         call("nudf_sigmoid_head_bwd", ptr(color), ptr(d_color), None, 0, dout, ptr(d_logits), max(nb, 1), nb, P,
              ptr(Dv[n - 1]), Dv[n - 1].shape[1])
         dVIN = _buf(P, self.view[0].inp, dev, zero=False)
+        tn2 = TN_F16X2 and PRECISION == "bf16x3" and TN_SPLIT and not _is16(HV[1]) and COLOR_TILE in (0, 32, 64)
+        amax = torch.zeros(1, device=dev) if tn2 else None      # max |Dv, Db| (NudfChain.absmax_out of both reverse sweeps)
         cb = ChainBuilder(P, "LOAD", k8(plv.out), tile_rows=COLOR_TILE, site=("col_bwd_view", _memo_token(self)))
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
+        if tn2:
+            cb.absmax(amax)
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
             cb.step("MULMASK", pl.frag(_kind("bwd", "bwd")), k8(pl.out), pl.inp, X1=HV[i], C1=Dv[i - 1])
@@ -1606,6 +1633,8 @@ class ColorEngine:
         dCIN = torch.empty(pad_rows(P), self.cin_ld, device=dev)
         cb = ChainBuilder(P, "LOAD", k8(plb.out), tile_rows=COLOR_TILE, site=("col_bwd_base", _memo_token(self)))
         cb.init_load(Db[n - 1], Db[n - 1].shape[1])
+        if tn2:
+            cb.absmax(amax)
         for i in range(n - 1, 0, -1):
             pl = self.base[i]
             if i == n - 1:   # the hidden tap's adjoint from the view branch joins before the ReLU mask
@@ -1620,7 +1649,7 @@ class ColorEngine:
             jobs.append((Dv[i], pl.out, HV[i], pl.in_pad, grads[i][0], grads[i][1]))
         for i, pl in enumerate(self.base):
             jobs.append((Db[i], pl.out, HB[i], pl.in_pad, grads[n + i][0], grads[n + i][1]))
-        gemm_tn_grouped(jobs, P, assign=assign)
+        gemm_tn_grouped(jobs, P, assign=assign, f16x2=tn2, amax_a=amax)
         return unpack_group(self.view + self.base, grads, claim_grad_slot(self, self.view + self.base)), dCIN[:P]
 
     def _forward_layers(self, CIN, rays_d, S, P, keep_state=True):

@@ -141,7 +141,8 @@ def test_colour_weight_ramp_at_iteration_10000_replays_live_weights():
     # the ramp is visible in the result: freezing the weight at its pre-ramp value (what a by-value capture replayed) differs
     kw0 = dict(kw, color_base_weight=0.0)
     _, l0, _ = _loop(False, kw0, 9994, 10006)
-    assert torch.equal(l0[5], la[5]) and not torch.equal(l0[-1], la[-1])
+    # (the ramp is 5e-5 per iteration on a loss of 0.25: a few ulp, not necessarily in every single iteration)
+    assert all(torch.equal(x, y) for x, y in zip(l0[:7], la[:7])) and any(not torch.equal(x, y) for x, y in zip(l0[7:], la[7:]))
 
 
 def test_regulariser_schedule_boundaries_replay_live_weights():
