@@ -8,6 +8,7 @@ last $F/bench.json > $P/r06_bench_final_run1.json
 last $F/bench_again.json > $P/r06_bench_final_run2.json
 last $F/bench_fwd_bf16x3.json > $P/r06_bench_ab_bf16x3_everywhere.json
 last $F/bench_exstored.json > $P/r06_bench_ab_ex_stored.json
+last $F/bench_tn_bf16x3.json > $P/r06_bench_ab_tn_bf16x3.json
 last $F/bench_eager.json > $P/r06_bench_final_eager.json
 last $F/bench_256.json > $P/r06_bench_256rays.json
 last $F/bench_256_eager.json > $P/r06_bench_256rays_eager.json
@@ -24,7 +25,7 @@ cp $F/pmc_mfma_busy.txt $P/r06_pmc_mlp_chain.txt
 cp $F/traffic_mlp_chain.json $P/r06_traffic_mlp_chain_bf16x3.json
 cp $F/traffic_mlp_chain_cfg5_mixed16.json $P/r06_traffic_mlp_chain_cfg5_mixed16.json
 cp $F/traffic_mlp_chain_garment.json $P/r06_traffic_mlp_chain_garment_bf16x3.json
-cp $F/traffic_gemm_tn.json $P/r06_traffic_gemm_tn3_bf16x3.json
+cp $F/traffic_gemm_tn.json $P/r06_traffic_gemm_tn2_f16x2.json
 cp $F/step_sequence_graph.txt $P/r06_step_sequence_graph.txt
 cp $F/step_sequence_garment_blend.txt $P/r06_step_sequence_garment_blend.txt
 cp $F/provenance.txt $P/r06_provenance.txt
