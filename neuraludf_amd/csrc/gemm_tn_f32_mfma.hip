@@ -1437,8 +1437,10 @@ __global__ __launch_bounds__(256, NUDF_TN3_WGS) void gemm_tn3_group_kernel(TnPla
 // =======================================================================================================
 // f16x2 mode (NudfGemmTNGroup.prec == 4, round 6): fp32 emulated with THREE fp16 MFMA products per fragment pair instead of
 // bf16x3's six (NudfChainStep.prec 4 has the arithmetic: x = hi + 2^-11 lo in fp16, acc0 += hi hi', acc1 += lo hi' + hi lo',
-// result acc0 + 2^-11 acc1).  The kernel above runs against the 1 400 W package limit; a timing probe that forms three of its
-// six products (wrong results) ran the whole train step 14 % faster (3.74 -> 3.21 ms, 1 068 W at 2 386 MHz).
+// result acc0 + 2^-11 acc1).  The kernel above runs against the 1 400 W package limit, so the gain is the products not formed:
+// measured on the step's three launches 412 / 365 / 216 -> 323 / 275 / 202 us, step 3.57 -> 3.44 ms as a pair on one box.
+// (A timing probe that formed three of the bf16x3 kernel's six products had promised 3.74 -> 3.21 ms: its wrong gradients had
+// degraded the weights it was then timed on -- 1 068 W -- so that number was not a bound of anything.)
 // fp16's exponent range is the price: one operand of every weight-gradient problem holds adjoints of the LOSS (1e-6 ... 1e-9).
 // Each side of a group therefore carries a power-of-two scale taken from a device scalar, max |x| over that side's operands
 // (written by the chain sweeps that produce them, NudfChain.absmax_out): sigma = 2^(10 - floor(log2 max)), so the largest
@@ -1470,9 +1472,18 @@ __device__ __forceinline__ void tn_scale_of(const float* amax, float& sc, float&
   inv = __builtin_bit_cast(float, (unsigned)(254 - se) << 23);
 }
 
+#ifndef NUDF_TN2_DB
+#define NUDF_TN2_DB 0      // A/B build switch, see the kernel's shared-memory comment (measured: no gain for the step)
+#endif
 __global__ __launch_bounds__(256, 2) void gemm_tn2_group_kernel(TnPlan g) {
   // image: [operand 2][plane 2][k-pair group 4][column 128][4 dwords], as gemm_tn3_group_kernel's with two planes
-  __shared__ __attribute__((aligned(16))) unsigned smem[4 * T3Q];
+  // NUDF_TN2_DB=1 (A/B build, not the default): TWO images (64 KB, still two workgroups per CU) -- step kt's MFMAs read image
+  // kt & 1 while step kt + 1 is split into the other one, so a k-step has ONE barrier and a wave's split / LDS stores run beside
+  // the other waves' MFMAs; same arithmetic, bit-identical results, 250 VGPRs.  MEASURED (profiles/r06_tn2_double_buffer_ab.txt):
+  // the kernel alone 5-10 % faster (331 / 319 / 200 vs 346-355 / 316 / 201 us), the train step SLOWER (3.56-3.57 vs 3.52 ms): the
+  // card answers the denser kernel with a lower clock for the whole replayed step (2 008 vs 2 110 MHz at 1 276 vs 1 310 W).
+  __shared__ __attribute__((aligned(16))) unsigned smem[(NUDF_TN2_DB ? 8 : 4) * T3Q];
+  constexpr int IMG = NUDF_TN2_DB ? 4 * T3Q : 0;      // dwords from one image to the other
   unsigned* As = smem;
   unsigned* Bs = smem + 2 * T3Q;
 
@@ -1534,9 +1545,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_group_kernel(TnPlan g) {
     *reinterpret_cast<u32x4*>(dst + T3Q + 512) = lq[1];
   };
   // one k-step: 2 groups of 16 rows; per group 2 + 2 operand sub-tiles x 2 planes (one ds_read_b128 each) and 12 MFMAs
-  auto mma = [&]() {
-    const unsigned* as = As + ((lane >> 5) * 128 + (wave >> 1) * 64 + (lane & 31)) * 4;
-    const unsigned* bs = Bs + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
+  auto mma = [&](int img) {
+    const unsigned* as = As + img + ((lane >> 5) * 128 + (wave >> 1) * 64 + (lane & 31)) * 4;
+    const unsigned* bs = Bs + img + ((lane >> 5) * 128 + (wave & 1) * 64 + (lane & 31)) * 4;
 #pragma unroll
     for (int kk = 0; kk < BK3 / 16; ++kk) {
       u32x4 a[2][2], b[2][2];
@@ -1584,14 +1595,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_group_kernel(TnPlan g) {
       load(pb, ldb, lb, kt + 2);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the global loads above the MFMA block
-    mma();
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                     // every wave is done reading the image
-    if (kt + 1 < nk) {
-      store(Ragged{}, ua, kt + 1, As, sca, do_bias);
-      store(Ragged{}, ub, kt + 1, Bs, scb, false);
+    if (NUDF_TN2_DB) {
+      const int nxt = ((kt + 1) & 1) * IMG;
+      if (kt + 1 < nk) {                 // (the other image: every wave left it at the previous step's barrier)
+        store(Ragged{}, ua, kt + 1, As + nxt, sca, do_bias);
+        store(Ragged{}, ub, kt + 1, Bs + nxt, scb, false);
+      }
+      mma((kt & 1) * IMG);
+      __syncthreads();
+    } else {
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                     // every wave is done reading the image
+      if (kt + 1 < nk) {
+        store(Ragged{}, ua, kt + 1, As, sca, do_bias);
+        store(Ragged{}, ub, kt + 1, Bs, scb, false);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   };
   // steady state: FULL k-steps, buffer loads with a scalar row offset (gemm_tn3_group_kernel's loop-invariant addressing)
   int kt0 = 0;
@@ -1613,22 +1634,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_group_kernel(TnPlan g) {
         for (int r = 0; r < 16; ++r)
           st[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(col * 4), so + r * ld4, 0));
       };
-      auto fstep = [&](float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+      auto fstep = [&](auto CURc, float (&la)[16], float (&lb)[16], float (&ua)[16], float (&ub)[16]) {
+        constexpr int cur = decltype(CURc)::value * IMG, nxt = IMG - cur;       // the loop runs an even number of steps from kt0 = 0
         load_f(rsa, ba, lda4, ca, la);
         load_f(rsb, bb, ldb4, cbb, lb);
         ba += sa_step;
         bb += sb_step;
         __builtin_amdgcn_sched_barrier(0);
-        mma();
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        store(Full{}, ua, 0, As, sca, do_bias);
-        store(Full{}, ub, 0, Bs, scb, false);
-        __syncthreads();
+        if (NUDF_TN2_DB) {
+          store(Full{}, ua, 0, As + nxt, sca, do_bias);
+          store(Full{}, ub, 0, Bs + nxt, scb, false);
+          mma(cur);
+          __syncthreads();
+        } else {
+          mma(0);
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+          store(Full{}, ua, 0, As, sca, do_bias);
+          store(Full{}, ub, 0, Bs, scb, false);
+          __syncthreads();
+        }
       };
       do {
-        fstep(sa, sb, sa2, sb2);
-        fstep(sa2, sb2, sa, sb);
+        fstep(std::integral_constant<int, 0>{}, sa, sb, sa2, sb2);
+        fstep(std::integral_constant<int, 1>{}, sa2, sb2, sa, sb);
         kt0 += 2;
       } while (kt0 + 1 < n_fast);
     }
