@@ -641,6 +641,24 @@ typedef struct NudfChain {
                                       bound 2^(L-1) |v| in_scale), every C1 / pe-free output of its MULSP / BWD / MULMASK / ADDMASK /
                                       NONE steps, and the rank-1 operand r1_row.  It is what scales that side of an f16x2 GEMM
                                       (NudfGemmTNGroup.amax_a / amax_b).                                                      */
+  /* Per-tile scaling of a LINEAR sweep (split modes of the workgroup-shared kernel; what lets the backward sweeps -- whose
+     operands are adjoints of the LOSS, 1e-5 ... 1e-12 -- contract as f16x2, prec 4).  The tangent, adjoint and ReLU-backward
+     sweeps map each point's seeds linearly to that point's outputs, so a tile of points may run multiplied by any power of two:
+     tile_scale = 1 makes the kernel take m = the largest |seed| of its tile -- the initial tile (INIT_LOAD values; for the JVP
+     encoding the bound 2^(L-1) |v| in_scale), the rank-1 operands of its steps, tile_amax_in -- and sigma = 2^(-6 - floor(log2 m));
+     the activation tile then holds sigma times the sweep's values (largest seed in [2^-6, 2^-5): 2^21 of growth below fp16's
+     largest number; elements down to 2^-8 of the seed keep all 22 bits of the split, smaller ones 2^-30 of the seed absolutely),
+     operands that enter from memory (r1_row, X2 of BWD / ADDMASK) are multiplied by sigma and everything that goes to memory (G0,
+     C1, C2, pe_dst) by 1 / sigma -- powers of two, exact: memory holds what it held without the option.  Requires a
+     linear chain: INIT_LOAD or the JVP encoding, steps NONE / MULSP / TANGENT / BWD / MULMASK / ADDMASK without bias.
+     A tile of zero seeds runs with sigma = 1.
+     tile_amax_in: NULL or [rows padded to 64 / 32] floats, per 32 points a bound of what ENTERS later in the sweep (X2), merged
+     into m; tile_amax_out: NULL or the same shape, receives per 32 points the largest |value| this launch stored for them (what
+     absmax_out reduces over the whole launch) -- the tangent sweep's is the adjoint sweep's tile_amax_in. */
+  const float* tile_amax_in;
+  float* tile_amax_out;
+  int32_t tile_scale;
+  int32_t reserved0;
   NudfChainStep step[NUDF_CH_MAX_STEPS];
 } NudfChain;
 int nudf_mlp_chain(const NudfChain* args, void* stream);

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be loaded before libnudf, see module docstring
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NUDF_LIB") or os.path.join(_HERE, "libnudf.so")      # NUDF_LIB: A/B builds of the library
-ABI_VERSION = 104         # nudf_version() of the include/nudf.h these ctypes structures mirror
+ABI_VERSION = 105         # nudf_version() of the include/nudf.h these ctypes structures mirror
 
 c_fp = C.c_void_p
 i32 = C.c_int32
@@ -160,7 +160,8 @@ class Chain(C.Structure):
     _fields_ = [("P", i32), ("n_steps", i32), ("init", i32), ("k0", i32), ("x_div", i32), ("tile_rows", i32), ("lda0", i32),
                 ("ldg0", i32), ("pe_L", i32), ("pe_jvp", i32), ("init_state16", i32), ("pe_in_scale", f32), ("seed_scale", f32),
                 ("seed_xscale", f32), ("A0", c_fp), ("G0", c_fp), ("x", c_fp), ("v", c_fp), ("seed_sign", c_fp),
-                ("seed_wrow", c_fp), ("dbg", c_fp), ("absmax_out", c_fp), ("step", ChainStep * CH_MAX_STEPS)]
+                ("seed_wrow", c_fp), ("dbg", c_fp), ("absmax_out", c_fp), ("tile_amax_in", c_fp),
+                ("tile_amax_out", c_fp), ("tile_scale", C.c_int32), ("reserved0", C.c_int32), ("step", ChainStep * CH_MAX_STEPS)]
 
 
 PACK_MAX_LAYERS = 16

@@ -29,6 +29,7 @@ struct ChainSmem {
   float act[TM * CH_LD];
   float xs[TM * 3];
   float vs[TM * 3];
+  float red[8];          // workgroup reductions (NudfChain.tile_scale / tile_amax_out): one value per wave
 };
 
 // MODE 3 (16-bit-tile kernel, BASELINE config 5): the activation tile holds the MFMA operand type of the chain's steps (fp16 in
@@ -38,13 +39,15 @@ struct ChainSmem16 {
   unsigned short act[TM * CH_LD16];
   float xs[TM * 3];
   float vs[TM * 3];
+  float red[8];
 };
 
 template <int TM, class SM>
 __device__ __forceinline__ void ch_write_pe(SM& sm, const NudfChain& p, int m0, int col0, float scale,
-                                            float* gdst, int ldg, int gcol0, int zero_to, bool dst16 = false, int tfmt = 0) {
+                                            float* gdst, int ldg, int gcol0, int zero_to, bool dst16 = false, int tfmt = 0,
+                                            float gscale = 1.0f) {
   ch_write_pe_rows<CH_THREADS>(reinterpret_cast<float*>(sm.act), sm.xs, sm.vs, TM, threadIdx.x, p, m0, col0, scale, gdst, ldg,
-                               gcol0, zero_to, dst16, false, tfmt);
+                               gcol0, zero_to, dst16, false, tfmt, gscale);
 }
 
 // K loop of one step for an NRT x NCT block of 32x32 tiles: two register sets, no copies and no branches in
@@ -682,7 +685,11 @@ template <int EPI, bool X2IN = false, bool S16 = false, bool RT16 = false, bool 
 __device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float* act, int m0, int rtile, int ctile,
                                                  int h, int ln, f32x16 a, float (&x1)[16], bool load_x1,
                                                  const float* x2in = nullptr, const float* bias_pre = nullptr,
-                                                 bool tile_bf = false, const X3V& x3in = X3V()) {
+                                                 bool tile_bf = false, const X3V& x3in = X3V(), float tsig = 1.0f,
+                                                 float tinv = 1.0f) {
+  // tsig / tinv (NudfChain.tile_scale): the activation tile of a LINEAR sweep holds sigma times the values -- operands that
+  // enter from memory (the rank-1 term, X2 of BWD / ADDMASK) are multiplied by sigma, what goes to memory by 1 / sigma.  Powers
+  // of two: exact.
   float tmax = 0.0f;
   const int col = ctile * 32 + ln;
   const bool col_ok = col < st.N;
@@ -703,7 +710,7 @@ __device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float
     for (int r = 0; r < 16; ++r) {
       const float rv = (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[vo];
       tmax = fmaxf(tmax, fabsf(rv));        // (NudfChain.absmax_out: the rank-1 operand is a GEMM operand too)
-      v[r] += rv * r1c;
+      v[r] += (rv * tsig) * r1c;
     }
   }
   float x2[16];   // x1 (the stored activation) was prefetched under the fp32 K loop; the short 16-bit loops load it here
@@ -738,6 +745,10 @@ __device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float
 #pragma unroll
       for (int r = 0; r < 16; ++r) x2[r] = 0.0f;
     }
+  }
+  if (EPI == NUDF_CH_BWD || EPI == NUDF_CH_ADDMASK) {      // X2 joins the (scaled) adjoint
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x2[r] *= tsig;
   }
   // NUDF_CH_BWD with a third stored operand (NudfChainStep.X3): x2 = R[l], x3 = DA[l-1] -- the second-order term is formed
   // below instead of read.  Fetched by the caller one tile ahead (x3in) or here.
@@ -866,14 +877,16 @@ __device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float
     }
   } else if (col_ok) {
     if (st.C1) {      // NudfChain.absmax_out: the largest value this launch stores for a weight-gradient GEMM to read
+      float omax = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(fabsf(out[r]), fabsf(out[r + 1])));
+      for (int r = 0; r < 16; r += 2) omax = __builtin_fmaxf(omax, __builtin_fmaxf(fabsf(out[r]), fabsf(out[r + 1])));
+      tmax = __builtin_fmaxf(tmax, omax * tinv);
     }
     if (EPI == NUDF_CH_MULSP && st.iparam > 0 && col >= st.iparam) {
       if (st.C2) {
         const unsigned vo = grow0 * (unsigned)st.ldc2 + (col - st.iparam);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r] * tinv;
       }
     } else if (st.C1) {
       const unsigned vo = grow0 * (unsigned)st.ldc1 + col;
@@ -881,7 +894,7 @@ __device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float
         ch_p4_store(st.C1, st.ldc1, (grow0 >> 2), (unsigned)col, out);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+        for (int r = 0; r < 16; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r] * tinv;
       }
     }
     if (EPI == NUDF_CH_TANGENT || (EPI == NUDF_CH_RELU && st.C2)) {
@@ -890,7 +903,7 @@ __device__ __forceinline__ float ch_epilogue_tile(const NudfChainStep& st, float
         ch_p4_store(st.C2, st.ldc2, (grow0 >> 2), (unsigned)col, out2);
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r];
+        for (int r = 0; r < 16; ++r) (st.C2 + (size_t)CH_KOFF(r) * st.ldc2)[vo] = out2[r] * tinv;
       }
     }
   }
@@ -1013,7 +1026,8 @@ __device__ __forceinline__ void ch_epilogue_seq16(const NudfChainStep& st, float
 // operands of tile t + 1 are requested before tile t is computed and stored, as in ch_epilogue_seq16.
 template <int EPI, int NRT, int NCT, bool X3 = false>
 __device__ __forceinline__ float ch_epilogue_seq32(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h,
-                                                  int ln, f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+                                                  int ln, f32x16 (&acc)[2][2], const float (&bpre)[2], float tsig = 1.0f,
+                                                  float tinv = 1.0f) {
   float smax = 0.0f;
   constexpr bool U1 = CH_USES_X1(EPI), U2 = CH_USES_X2(EPI), U3 = (EPI == NUDF_CH_BWD) && X3;
   // (three stored operands: one tile ahead -- the same 96 registers as two operands two tiles ahead)
@@ -1070,10 +1084,11 @@ __device__ __forceinline__ float ch_epilogue_seq32(const NudfChainStep& st, floa
     if constexpr (U3)
       smax = fmaxf(smax, ch_epilogue_tile<EPI, true, false, false, false, true, float[16]>(
                              st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT], xa[t % (AH + 1)], false,
-                             xb[t % (AH + 1)], &bpre[t % NCT], false, xc[t % (AH + 1)]));
+                             xb[t % (AH + 1)], &bpre[t % NCT], false, xc[t % (AH + 1)], tsig, tinv));
     else
       smax = fmaxf(smax, ch_epilogue_tile<EPI, true>(st, act, m0, rt0 + t / NCT, ct0 + t % NCT, h, ln, acc[t / NCT][t % NCT],
-                                                     xa[t % (AH + 1)], false, xb[t % (AH + 1)], &bpre[t % NCT]));
+                                                     xa[t % (AH + 1)], false, xb[t % (AH + 1)], &bpre[t % NCT], false, ChNoX3(),
+                                                     tsig, tinv));
   }
   return smax;
 }
@@ -1084,7 +1099,8 @@ __device__ __forceinline__ float ch_epilogue_seq32(const NudfChainStep& st, floa
 // whose every scratch access waits vmcnt(0)).  out = (acc + bias [+ rank-1 term]) scale s + X2 X3 100 (1 - s) / (s scale).
 template <int NRT, int NCT>
 __device__ __forceinline__ float ch_epilogue_bwd3(const NudfChainStep& st, float* act, int m0, int rt0, int ct0, int h, int ln,
-                                                  f32x16 (&acc)[2][2], const float (&bpre)[2]) {
+                                                  f32x16 (&acc)[2][2], const float (&bpre)[2], float tsig = 1.0f,
+                                                  float tinv = 1.0f) {
   float bmax = 0.0f;
   constexpr int NU = NRT * NCT * 2;
   float xa[2][8], xb[2][8], xc[2][8];
@@ -1125,20 +1141,22 @@ __device__ __forceinline__ float ch_epilogue_bwd3(const NudfChainStep& st, float
       if (st.r1_row) {
         const float rv = (st.r1_row + (size_t)CH_KOFF(r) * st.ldr1)[row0 * (unsigned)st.ldr1];
         bmax = fmaxf(bmax, fabsf(rv));
-        v += rv * r1c;
+        v += (rv * tsig) * r1c;
       }
       const float x = 100.0f * st.xscale * xa[u & 1][r];
       const float om = __builtin_amdgcn_exp2f(x * -1.44269504f);
       const float sg = 1.0f - om;
       const float f = 100.0f * om * __builtin_amdgcn_rcpf(fmaxf(sg * st.scale, 1e-30f));
-      out[r] = v * st.scale * sg + xb[u & 1][r] * xc[u & 1][r] * f;
+      out[r] = v * st.scale * sg + (xb[u & 1][r] * tsig) * xc[u & 1][r] * f;
     }
     if (col_ok && st.C1) {
       const unsigned vo = row0 * (unsigned)st.ldc1 + (unsigned)col;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r];
+      for (int r = 0; r < 8; ++r) (st.C1 + (size_t)CH_KOFF(r) * st.ldc1)[vo] = out[r] * tinv;
+      float omax = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 8; r += 2) bmax = __builtin_fmaxf(bmax, __builtin_fmaxf(fabsf(out[r]), fabsf(out[r + 1])));
+      for (int r = 0; r < 8; r += 2) omax = __builtin_fmaxf(omax, __builtin_fmaxf(fabsf(out[r]), fabsf(out[r + 1])));
+      bmax = __builtin_fmaxf(bmax, omax * tinv);
     }
     if (st.act_write) {
       float* ap = act + ((rt0 + i) * 32 + 4 * h + 16 * hf) * CH_LD + st.act_col0 + col;
@@ -1153,7 +1171,8 @@ __device__ __forceinline__ float ch_epilogue_bwd3(const NudfChainStep& st, float
 template <int EPI, int MODE>
 __device__ __forceinline__ float ch_epilogue(const NudfChain& p, const NudfChainStep& st, float* act, int m0, int rt0,
                                             int ct0, int nrt, int nct, int h, int ln, f32x16 (&acc)[2][2],
-                                            const float (&px1)[2][2][16], const float (&bpre)[2], bool tile_bf = false) {
+                                            const float (&px1)[2][2][16], const float (&bpre)[2], bool tile_bf = false,
+                                            float tsig = 1.0f, float tinv = 1.0f) {
   float emax = 0.0f;
   constexpr bool ANY16 = MODE == 1 || MODE == 3 || MODE == 4, X3 = MODE == 2, T16 = MODE == 3 || MODE == 4;
   constexpr bool PF = CH_USES_X1(EPI);
@@ -1167,17 +1186,17 @@ __device__ __forceinline__ float ch_epilogue(const NudfChain& p, const NudfChain
   }
   if constexpr (X3 && EPI == NUDF_CH_BWD) {
     if (st.X3) {      // second-order term formed from R and DA (NudfChainStep.X3): three stored operands, fp32 state
-      if (nrt == 2 && nct == 2) return ch_epilogue_bwd3<2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else if (nrt == 2) return ch_epilogue_bwd3<2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else if (nct == 2) return ch_epilogue_bwd3<1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else return ch_epilogue_bwd3<1, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      if (nrt == 2 && nct == 2) return ch_epilogue_bwd3<2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
+      else if (nrt == 2) return ch_epilogue_bwd3<2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
+      else if (nct == 2) return ch_epilogue_bwd3<1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
+      else return ch_epilogue_bwd3<1, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
     }
   }
   if constexpr (X3 && CH_USES_X1(EPI)) {
     if (st.prec >= 3 && nrt * nct >= 2) {
-      if (nrt == 2 && nct == 2) return ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else if (nrt == 2) return ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
-      else return ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre);
+      if (nrt == 2 && nct == 2) return ch_epilogue_seq32<EPI, 2, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
+      else if (nrt == 2) return ch_epilogue_seq32<EPI, 2, 1>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
+      else return ch_epilogue_seq32<EPI, 1, 2>(st, act, m0, rt0, ct0, h, ln, acc, bpre, tsig, tinv);
     }
   }
   if constexpr (ANY16 && (EPI == NUDF_CH_MULSP || EPI == NUDF_CH_TANGENT || EPI == NUDF_CH_BWD)) {
@@ -1254,7 +1273,7 @@ __device__ __forceinline__ float ch_epilogue(const NudfChain& p, const NudfChain
     }
     constexpr bool RT16 = ANY16 && (EPI == NUDF_CH_RELU || EPI == NUDF_CH_MULMASK || EPI == NUDF_CH_ADDMASK);
     emax = fmaxf(emax, ch_epilogue_tile<EPI, false, false, RT16, T16>(st, act, m0, rt0 + i, ct0 + j, h, ln, a, x1, ANY16 || X3, nullptr,
-                                                                      &bpre[j], tile_bf));
+                                                                      &bpre[j], tile_bf, ChNoX3(), tsig, tinv));
   }
   return emax;
 }
@@ -1272,6 +1291,9 @@ __device__ __forceinline__ float ch_epilogue(const NudfChain& p, const NudfChain
 // 168 of three workgroups and run 1115 instead of 872 us at config 5's shape; every other sweep is faster with three.
 #ifndef NUDF_T16_WGS
 #define NUDF_T16_WGS 3       // A/B build switch: workgroups per CU MODE 3 is register-allocated for
+#endif
+#ifndef NUDF_TS_LOG2
+#define NUDF_TS_LOG2 (-6)    // NudfChain.tile_scale: the tile's largest seed is scaled into [2^NUDF_TS_LOG2, 2 x that)
 #endif
 template <int TM, int MODE>
 __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void mlp_chain_kernel(NudfChain p_arg) {
@@ -1295,6 +1317,42 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
   const int m0 = blockIdx.x * TM;
   // NudfChain.absmax_out (split modes): the largest |value| this thread puts into arrays a weight-gradient GEMM will read
   float amax = 0.0f;
+  // NudfChain.tile_scale (split modes): sigma and 1 / sigma of this tile (wave-uniform; 1 without the option)
+  float tsig = 1.0f, tinv = 1.0f;
+  const bool tscale = X3 && p.tile_scale != 0;
+  // max over the workgroup of a per-thread value (all threads call it; two barriers)
+  auto wg_max = [&](float v) -> float {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();                       // (a previous reduction's readers are done)
+    if (lane == 0) sm.red[wave] = v;
+    __syncthreads();
+    float m = sm.red[0];
+#pragma unroll
+    for (int w = 1; w < CH_THREADS / 64; ++w) m = fmaxf(m, sm.red[w]);
+    return m;
+  };
+  // sigma = 2^(-6 - floor(log2 m)): the tile's largest seed lands in [2^-6, 2^-5) -- 2^21 of growth below fp16's largest
+  // number, and every element down to 2^-8 of that seed keeps the full 22 bits of the f16x2 split (below: 2^-36 absolute)
+  auto set_sigma = [&](float m) {
+    const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;
+    const int se = 254 + NUDF_TS_LOG2 - (int)e;
+    if (e != 0u && e != 255u && se >= 1 && se <= 254) {
+      tsig = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readfirstlane(se) << 23);
+      tinv = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readfirstlane(254 - se) << 23);
+    }
+  };
+  // what the tile's seeds other than the initial tile can be: the rank-1 operands of the steps, the caller's bound
+  auto other_seeds = [&]() -> float {
+    float m = 0.0f;
+    for (int i = 0; i < p.n_steps; ++i) {
+      const NudfChainStep& s0 = p.step[i];
+      if (s0.r1_row)
+        for (int e = tid; e < TM; e += CH_THREADS) m = fmaxf(m, fabsf(s0.r1_row[(size_t)min(m0 + e, p.P - 1) * s0.ldr1]));
+    }
+    if (p.tile_amax_in && tid < TM / 32) m = fmaxf(m, p.tile_amax_in[(m0 >> 5) + tid]);
+    return m;
+  };
 
   // ---- tile initialisation ---------------------------------------------------------------------
   if (p.x) {
@@ -1306,6 +1364,12 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
       // (JVP encoding: every element of the initial tile is (2^k or 1) v in_scale times a sine / cosine, k < pe_L)
       if (X3 && p.v && p.init == NUDF_CH_INIT_POSENC)
         amax = fmaxf(amax, fabsf(sm.vs[e] * p.pe_in_scale) * (float)(1 << (p.pe_L > 0 ? p.pe_L - 1 : 0)));
+    }
+  }
+  if constexpr (X3) {
+    if (tscale && p.init == NUDF_CH_INIT_POSENC && p.v) {   // JVP encoding: the tangents are the seeds; `amax` is their bound so far
+      set_sigma(wg_max(fmaxf(amax, other_seeds())));
+      for (int e = tid; e < TM * 3; e += CH_THREADS) sm.vs[e] *= tsig;
     }
   }
   __syncthreads();
@@ -1331,8 +1395,20 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
         *reinterpret_cast<f32x4*>(act_f + r * CH_LD + c4 * 4) = val;
       }
     }
+    if constexpr (X3) {
+      if (tscale) {          // the loaded tile is the seed: scale it in place (each thread the elements it wrote)
+        set_sigma(wg_max(fmaxf(amax, other_seeds())));
+        for (int e = tid; e < TM * k4; e += CH_THREADS) {
+          const int r = e / k4, c4 = e - r * k4;
+          f32x4* q = reinterpret_cast<f32x4*>(act_f + r * CH_LD + c4 * 4);
+          f32x4 val = *q;
+          val[0] *= tsig; val[1] *= tsig; val[2] *= tsig; val[3] *= tsig;
+          *q = val;
+        }
+      }
+    }
   } else if (p.init == NUDF_CH_INIT_POSENC) {
-    ch_write_pe<TM>(sm, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0, false, tfmt);
+    ch_write_pe<TM>(sm, p, m0, 0, 1.0f, p.G0, p.ldg0, 0, p.k0, false, tfmt, tinv);
   } else if (p.init == NUDF_CH_INIT_SEED) {
     // da[r, c] = sign[r] * w_row0[c] * inv_scale * softplus'(.)   (reverse-sweep seed, fields.py:219-231)
     const int C = p.k0;
@@ -1559,19 +1635,19 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
 
     if (nct > 0) {
       switch (st.epi) {
-        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_NONE: { const float em = ch_epilogue<NUDF_CH_NONE, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
-        case NUDF_CH_MULSP: { const float em = ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_SOFTPLUS: ch_epilogue<NUDF_CH_SOFTPLUS, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); break;
+        case NUDF_CH_NONE: { const float em = ch_epilogue<NUDF_CH_NONE, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_MULSP: { const float em = ch_epilogue<NUDF_CH_MULSP, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); if constexpr (X3) amax = fmaxf(amax, em); } break;
         case NUDF_CH_TANGENT:     // (MODE 3 never runs a TANGENT chain: the dispatcher sends those to MODE 4)
-          if constexpr (MODE != 3) ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf);
+          if constexpr (MODE != 3) ch_epilogue<NUDF_CH_TANGENT, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv);
           break;
-        case NUDF_CH_BWD: { const float em = ch_epilogue<NUDF_CH_BWD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
-        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        case NUDF_CH_MULMASK: { const float em = ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
-        case NUDF_CH_ADDMASK: { const float em = ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); if constexpr (X3) amax = fmaxf(amax, em); } break;
-        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
-        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf); break;
+        case NUDF_CH_BWD: { const float em = ch_epilogue<NUDF_CH_BWD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_RELU: ch_epilogue<NUDF_CH_RELU, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); break;
+        case NUDF_CH_SIGMOIDN: ch_epilogue<NUDF_CH_SIGMOIDN, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); break;
+        case NUDF_CH_MULMASK: { const float em = ch_epilogue<NUDF_CH_MULMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_ADDMASK: { const float em = ch_epilogue<NUDF_CH_ADDMASK, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); if constexpr (X3) amax = fmaxf(amax, em); } break;
+        case NUDF_CH_RELUADD: ch_epilogue<NUDF_CH_RELUADD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); break;
+        default: ch_epilogue<NUDF_CH_UDFHEAD, MODE>(p, st, act_f, m0, rt0, ct0, nrt, nct, h, ln, acc, px1, bpre, tile_bf, tsig, tinv); break;
       }
     }
     if (dbg && lane == 0) dbg[4 + 4 * si] = __builtin_amdgcn_s_memtime();
@@ -1581,13 +1657,17 @@ __global__ __launch_bounds__(CH_THREADS, (MODE == 3) ? NUDF_T16_WGS : 2) void ml
       // finite zeros (columns never written before hold arbitrary LDS contents)
       const int pe_end = st.pe_tail_col + 3 * (2 * p.pe_L + 1);
       ch_write_pe<TM>(sm, p, m0, st.pe_tail_col, st.pe_tail_scale, st.pe_dst, st.ld_pe, st.pe_tail_col,
-                      min((pe_end + 15) & ~15, 288), (st.layout & NUDF_CH_STATE16) != 0, tfmt);
+                      min((pe_end + 15) & ~15, 288), (st.layout & NUDF_CH_STATE16) != 0, tfmt, tinv);
     }
     __syncthreads();
     if (dbg && lane == 0) dbg[5 + 4 * si] = __builtin_amdgcn_s_memtime();
   }
   if (dbg && lane == 0) dbg[63] = wall_clock64();
   if constexpr (X3) {
+    if (p.tile_amax_out) {   // per 32 points: the largest |value| the launch stored for these rows (a later sweep's tile_amax_in)
+      const float m = wg_max(amax);
+      if (tid < TM / 32) p.tile_amax_out[(m0 >> 5) + tid] = m;
+    }
     if (p.absmax_out) {      // non-negative floats order like their bit patterns: one unsigned atomic max per wave
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
@@ -1671,6 +1751,24 @@ extern "C" int nudf_mlp_chain(const NudfChain* args, void* stream) {
   if (any3 && any16) {
     nudf_set_error("nudf_mlp_chain: split steps (prec 3 / 4) do not mix with 16-bit steps / 16-bit stored state", hipErrorInvalidValue);
     return (int)hipErrorInvalidValue;
+  }
+  if (p.tile_scale || p.tile_amax_in || p.tile_amax_out) {      // include/nudf.h: NudfChain.tile_scale
+    bool ok = true;      // (every step in a split mode: the launch runs on mlp_chain_kernel<TM, 2> whatever tile_rows asks for)
+    if (p.tile_scale)
+      ok = ok && (p.init == NUDF_CH_INIT_LOAD || (p.init == NUDF_CH_INIT_POSENC && p.v && p.pe_jvp));
+    for (int i = 0; i < p.n_steps && ok; ++i) {
+      const NudfChainStep& s = p.step[i];
+      ok = s.prec >= 3;
+      if (p.tile_scale)
+        ok = ok && !s.bias && (s.pe_tail_col < 0 || p.pe_jvp) &&
+             (s.epi == NUDF_CH_NONE || s.epi == NUDF_CH_MULSP || s.epi == NUDF_CH_TANGENT || s.epi == NUDF_CH_BWD ||
+              s.epi == NUDF_CH_MULMASK || s.epi == NUDF_CH_ADDMASK);
+    }
+    if (!ok) {
+      nudf_set_error("nudf_mlp_chain: tile_scale / tile_amax_* need a linear sweep in a split mode (INIT_LOAD or the JVP encoding; "
+                     "NONE / MULSP / TANGENT / BWD / MULMASK / ADDMASK steps of prec 3 / 4 without bias)", hipErrorInvalidValue);
+      return (int)hipErrorInvalidValue;
+    }
   }
   // Large launches: wave-private 32-point tiles (mlp_chain_rows.hip), one free-running wave per SIMD.  A "round" of
   // that kernel is 1024 waves = 32 768 points, so it is chosen when the last round is at least ~80 % full; the

@@ -82,7 +82,7 @@ template <int NTHR>
 __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, const float* vs, int rows, int tid,
                                                  const NudfChain& p, int m0, int col0, float scale, float* gdst,
                                                  int ldg, int gcol0, int zero_to, bool dst16 = false,
-                                                 bool dstblk = false, int tfmt = 0) {
+                                                 bool dstblk = false, int tfmt = 0, float gscale = 1.0f) {
   if (tfmt != 0) {   // 16-bit tile: same work items, same values, rounded once on their way into the tile
     unsigned short* a16 = reinterpret_cast<unsigned short*>(act);
     const int L = p.pe_L;
@@ -137,7 +137,7 @@ __device__ __forceinline__ void ch_write_pe_rows(float* act, const float* xs, co
       if (mirror) {
         if (dst16) reinterpret_cast<unsigned short*>(gdst)[ch_p4_off(m0 + r, gcol0 + c, ldg)] = ch_f2bf(val);
         else if (dstblk) gdst[ch_blk_off(m0 + r, gcol0 + c, ldg)] = val;
-        else gdst[goff + c] = val;
+        else gdst[goff + c] = val * gscale;        // (NudfChain.tile_scale: the tile holds sigma x, memory holds x)
       }
     };
     if (k < 0) {

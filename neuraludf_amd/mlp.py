@@ -296,17 +296,24 @@ class ChainBuilder:
         (NudfChain.absmax_out): the scale of that side of an f16x2 GEMM"""
         self.rec.append((5, a, kw))
 
+    def tile_scale(self, *a, **kw):
+        """(amax_in=None, amax_out=None): run this LINEAR sweep with every tile of points multiplied by its own power of two
+        (NudfChain.tile_scale) -- what lets a backward sweep, whose operands are adjoints of the loss, contract as f16x2.
+        amax_out [pad_rows(P) / 32] receives per 32 points the largest value the launch stored, amax_in is such an array of an
+        earlier sweep whose outputs enter this one as X2."""
+        self.rec.append((6, a, kw))
+
     # positional parameter names of the recorded calls, and the descriptor field every tensor argument lands in
     _PARAMS = (("x", "L", "in_scale", "tangent", "x_div"), ("G0",), ("A0", "lda0"),
-               ("A0", "lda0", "sign", "wrow", "scale", "xscale"), ("epi", "Bp", "K", "N"), ("t",))
+               ("A0", "lda0", "sign", "wrow", "scale", "xscale"), ("epi", "Bp", "K", "N"), ("t",), ("amax_in", "amax_out"))
     _CHAIN_FIELD = ({"x": "x", "tangent": "v"}, {"G0": "G0"}, {"A0": "A0"}, {"A0": "A0", "sign": "seed_sign", "wrow": "seed_wrow"},
-                    None, {"t": "absmax_out"})
+                    None, {"t": "absmax_out"}, {"amax_in": "tile_amax_in", "amax_out": "tile_amax_out"})
 
     def _signature(self):
         """-> (structure, pointers): the record with every tensor replaced by its element count, and the tensors' addresses
         in record order; (None, None) if a tensor is not a contiguous device tensor (the filling path raises the error)."""
         T, PT, plain = torch.Tensor, torch.nn.Parameter, _PLAIN_TYPES
-        sig = [self.P, self.init, self.k0, self.tile_rows, PRECISION, FWD_F16X2, HEAD16, STATE16, BLOCKED_STATE, TN_SPLIT]
+        sig = [self.P, self.init, self.k0, self.tile_rows, PRECISION, FWD_F16X2, BWD_F16X2, HEAD16, STATE16, BLOCKED_STATE, TN_SPLIT]
         ptrs = []
         add, addp = sig.append, ptrs.append
         for kind, a, kw in self.rec:
@@ -332,7 +339,8 @@ class ChainBuilder:
         self.c = Chain()
         self.c.P, self.c.init, self.c.k0, self.c.tile_rows = self.P, CH_INIT[self.init], self.k0, self.tile_rows
         self.c.x_div = 1
-        fns = (self._do_posenc, self._do_init_store, self._do_init_load, self._do_init_seed, self._do_step, self._do_absmax)
+        fns = (self._do_posenc, self._do_init_store, self._do_init_load, self._do_init_seed, self._do_step, self._do_absmax,
+               self._do_tile_scale)
         T = torch.Tensor
         slots = []
         for kind, a, kw in self.rec:
@@ -373,6 +381,14 @@ class ChainBuilder:
 
     def _do_absmax(self, t):
         self.c.absmax_out = self._p(t)
+
+    def _do_tile_scale(self, amax_in=None, amax_out=None):
+        need = pad_rows(self.P) // 32
+        for t in (amax_in, amax_out):
+            if t is not None and (t.dtype != torch.float32 or t.numel() < need):
+                raise _lib.NudfError("tile_scale: amax_in / amax_out hold one float per 32 points of the row-padded launch")
+        self.c.tile_scale = 1
+        self.c.tile_amax_in, self.c.tile_amax_out = self._p(amax_in), self._p(amax_out)
 
     def _do_init_load(self, A0, lda0):
         self.c.A0, self.c.lda0 = self._p(A0), lda0
@@ -728,6 +744,11 @@ _PREC = {"f32": 0, "f16": 1, "bf16": 2, "bf16x3": 3, "f16x2": 4}
 # scripts/numerics/f16x2_emulation.py).  NUDF_FWD_F16X2=0 keeps bf16x3 everywhere (A/B); "grad" additionally keeps the
 # input-gradient reverse sweep on bf16x3.
 FWD_F16X2 = os.environ.get("NUDF_FWD_F16X2", "1")
+# The backward sweeps (tangent, adjoint, ReLU backward) as f16x2 as well: their operands are adjoints of the LOSS (1e-5 ... 1e-12,
+# far below fp16's range), but each of these sweeps maps a point's seeds LINEARLY to that point's outputs, so the kernel runs
+# every tile of points multiplied by its own power of two (NudfChain.tile_scale, ChainBuilder.tile_scale) and memory holds what
+# it held before.  NUDF_BWD_F16X2=0 keeps them on bf16x3 (A/B).
+BWD_F16X2 = os.environ.get("NUDF_BWD_F16X2", "1") != "0"
 # the adjoint sweep forms the second-order term from R and DA instead of reading an EX array the tangent sweep stored
 # (NudfChainStep.X3; UDFEngine._backward_chain): 0 = the stored form (A/B)
 EX_FLY = os.environ.get("NUDF_EX_FLY", "1") != "0"
@@ -802,6 +823,8 @@ def _sweep_dtype(sweep):
     if PRECISION == "bf16x3":
         if FWD_F16X2 != "0" and (sweep == "fwd" or (sweep == "grad" and FWD_F16X2 != "grad")):
             return "f16x2"
+        if sweep == "bwd" and BWD_F16X2 and FWD_F16X2 != "0":
+            return "f16x2"
         return "bf16x3"
     return "f16" if sweep in ("fwd", "grad") else "bf16"
 
@@ -841,7 +864,7 @@ def _frag_spec32(pl, kind):
 
 def _mode_key():
     """everything that decides WHICH fragment copies a network's sweeps read"""
-    return (PRECISION, FWD_F16X2, HEAD16)
+    return (PRECISION, FWD_F16X2, BWD_F16X2, HEAD16)
 
 
 def pack_group(layers, kinds=None):
@@ -1239,6 +1262,9 @@ class UDFEngine:
         tn2 = (TN_F16X2 and PRECISION == "bf16x3" and TN_SPLIT and grouped and head4_path and not _isblk(X[L]) and not _is16(X[L])
                and CHAIN_TILE in (0, 32, 64))
         amax = torch.zeros(2, device=dev) if tn2 else None
+        # f16x2 backward sweeps: per-tile scaling; the tangent sweep's per-tile maxima bound what its R arrays add to the adjoint
+        bsc = _sweep_dtype("bwd") == "f16x2"
+        TA = torch.empty(pad_rows(P) // 32, device=dev) if (bsc and second) else None
         if second:
             sd, blk = X[L].dtype, _isblk(X[L])
             R = ([_buf(P, layers[0].inp, dev, zero=False)] +
@@ -1249,6 +1275,8 @@ class UDFEngine:
             cb.init_store(R[0])
             if tn2:
                 cb.absmax(amax[1:2])
+            if bsc:
+                cb.tile_scale(amax_out=TA)
             for l in range(L):
                 pl = layers[l]
                 nxt_skip = (l + 1) in self.skip
@@ -1298,6 +1326,8 @@ class UDFEngine:
         cb.init_load(d_feat, d_feat_ld)
         if tn2:
             cb.absmax(amax[0:1])
+        if bsc:
+            cb.tile_scale(amax_in=TA)
         for l in range(L, 0, -1):
             pl = layers[l]
             sc = self.inv_sqrt2 if l in self.skip else 1.0
@@ -1619,6 +1649,10 @@ class ColorEngine:
         cb.init_load(Dv[n - 1], Dv[n - 1].shape[1])
         if tn2:
             cb.absmax(amax)
+        bsc = _sweep_dtype("bwd") == "f16x2"          # per-tile scaling; d VIN of this sweep enters the next one as X2
+        TV = torch.empty(pad_rows(P) // 32, device=dev) if bsc else None
+        if bsc:
+            cb.tile_scale(amax_out=TV)
         for i in range(n - 1, 0, -1):
             pl = self.view[i]
             cb.step("MULMASK", pl.frag(_kind("bwd", "bwd")), k8(pl.out), pl.inp, X1=HV[i], C1=Dv[i - 1])
@@ -1635,6 +1669,8 @@ class ColorEngine:
         cb.init_load(Db[n - 1], Db[n - 1].shape[1])
         if tn2:
             cb.absmax(amax)
+        if bsc:
+            cb.tile_scale(amax_in=TV)
         for i in range(n - 1, 0, -1):
             pl = self.base[i]
             if i == n - 1:   # the hidden tap's adjoint from the view branch joins before the ReLU mask
@@ -1930,6 +1966,8 @@ class NerfEngine:
         Dp = [_buf(P, W, dev, zero=False) for _ in range(D)]
         cb = ChainBuilder(P, "LOAD", k8(3), site=("nerf_bwd", _memo_token(self)))
         cb.init_load(Drgb, Drgb.shape[1])
+        if _sweep_dtype("bwd") == "f16x2":
+            cb.tile_scale()
         cb.step("MULMASK", self.rgb.frag(bw), k8(3), self.views.out, X1=hv, C1=Dv)
         cb.step("NONE", self.views.frag(_kind("bwd_hid:%d" % W, "bwd")), k8(self.views.out), W, C1=dF)
         cb.step("MULMASK", self.feature.frag(bw), k8(W), W, X1=h_last, r1_row=Dsig, ldr1=Dsig.shape[1],

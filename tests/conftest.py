@@ -24,6 +24,6 @@ def _restore_mlp_precision():
     except Exception:          # pragma: no cover - the package always imports (no GPU needed for that)
         yield
         return
-    old, old_fwd = mlp.PRECISION, mlp.FWD_F16X2
+    old, old_fwd, old_bwd = mlp.PRECISION, mlp.FWD_F16X2, mlp.BWD_F16X2
     yield
-    mlp.PRECISION, mlp.FWD_F16X2 = old, old_fwd
+    mlp.PRECISION, mlp.FWD_F16X2, mlp.BWD_F16X2 = old, old_fwd, old_bwd

@@ -14,7 +14,7 @@ def test_library_builds_and_exports_header_symbols():
     path = build.build()
     assert os.path.exists(path)
     lib = _lib.lib()
-    assert lib.nudf_version() >= 104
+    assert lib.nudf_version() >= 105
     hdr = open(os.path.join(ROOT, "include", "nudf.h")).read()
     declared = sorted(set(re.findall(r"\b(nudf_[a-z0-9_]+)\s*\(", hdr)))
     assert declared, "no declarations found"

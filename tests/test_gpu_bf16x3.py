@@ -196,6 +196,7 @@ def test_packed_weight_planes_sum_to_the_weight_bit_for_bit(dev):
     mods = build_modules(fields, seed=0)
     udf = mods["udf"].to(dev)
     mlp.set_precision("bf16x3")
+    mlp.BWD_F16X2 = False      # (with the f16x2 backward sweeps no sweep of the default mode reads a three-plane copy of W^T)
     eng = udf.engine()
     x = torch.rand(64, 3, device=dev)
     eng.forward(x, need_grad_state=False, udf_only=True)            # packs the weights

@@ -21,7 +21,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _udf_backward(dev, P, seed=3):
+def _udf_backward(dev, P, seed=3, seed_scale=None):
+    """every parameter gradient of the UDF network's double backward for random loss adjoints; seed_scale: a number or a [P]
+    tensor the three adjoints (d udf, d feat, d grad) of every point are multiplied by"""
     from neuraludf_amd import mlp
     from neuraludf_amd.models import fields
     mods = perturb_(build_modules(fields, seed=0))
@@ -32,6 +34,9 @@ def _udf_backward(dev, P, seed=3):
     d_udf = (torch.randn(P, generator=g) * 1e-4).to(dev)
     d_g = (torch.randn(P, 3, generator=g) * 1e-5).to(dev)
     d_feat = (torch.randn(P, 288, generator=g) * 1e-5).to(dev)
+    if seed_scale is not None:
+        sc = seed_scale.to(dev) if torch.is_tensor(seed_scale) else torch.full((P,), float(seed_scale), device=dev)
+        d_udf, d_g, d_feat = d_udf * sc, d_g * sc[:, None], d_feat * sc[:, None]
     st = eng.forward(x, need_grad_state=True, feat_ld=288)
     gr, DA = eng.gradient(x, st)
     grads = eng.backward(x, st, DA, d_udf, d_feat, 288, d_g)
@@ -142,3 +147,68 @@ def test_f16x2_weight_gradient_gemm_against_float64(dev, M):
 def _err(a, ref):
     a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
     return float((a - ref).abs().max() / ref.abs().max().clamp(min=1e-300))
+
+
+# ---- f16x2 backward sweeps (NudfChain.tile_scale, mlp.BWD_F16X2) -----------------------------------------------------------
+def test_backward_sweeps_scale_exactly_with_a_power_of_two_of_the_loss(dev):
+    """The tangent / adjoint sweeps run every tile of points multiplied by its own power of two (so that adjoints of the loss fit
+    fp16's exponent range) and the f16x2 weight-gradient GEMMs scale their operands the same way: multiplying every loss adjoint
+    by 2^k must multiply every parameter gradient by exactly 2^k -- bit for bit -- far below and above fp16's range."""
+    from neuraludf_amd import mlp
+    mlp.set_precision("bf16x3")
+    assert mlp.BWD_F16X2 and mlp._sweep_dtype("bwd") == "f16x2"
+    base = _udf_backward(dev, 8192)
+    assert all(bool(torch.isfinite(t).all()) for t in base) and max(float(t.abs().max()) for t in base) > 0.0
+    for k in (-60, -20, 14):
+        got = _udf_backward(dev, 8192, seed_scale=2.0 ** k)
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert torch.equal(a * 2.0 ** k, b), (k, i, float((a * 2.0 ** k - b).abs().max()), float(b.abs().max()))
+
+
+def test_f16x2_backward_sweeps_against_the_range_free_bf16x3_sweeps(dev):
+    """Same gradients as the six-product sweeps, to the rounding of two fp32 emulations -- with the loss adjoints of the points
+    spread over 40 binades (every tile of 64 points its own scale, many of them far outside fp16's range) and a block of
+    points whose adjoints are all zero."""
+    from neuraludf_amd import mlp
+    mlp.set_precision("bf16x3")
+    P = 19200
+    g = torch.Generator().manual_seed(11)
+    sc = torch.exp2(-torch.randint(0, 40, (P // 64,), generator=g).float()).repeat_interleave(64)
+    sc[640:1280] = 0.0
+    sc[5000:5003] = 2.0 ** -70          # single points 30 binades below their tile's largest: they keep 2^-30 of it
+    old = mlp.BWD_F16X2
+    try:
+        mlp.BWD_F16X2 = False
+        ref = _udf_backward(dev, P, seed_scale=sc)
+        mlp.BWD_F16X2 = True
+        got = _udf_backward(dev, P, seed_scale=sc)
+    finally:
+        mlp.BWD_F16X2 = old
+    worst = 0.0
+    for a, b in zip(ref, got):
+        assert bool(torch.isfinite(b).all())
+        den = float(a.abs().max())
+        if den == 0.0:
+            assert float(b.abs().max()) == 0.0
+            continue
+        worst = max(worst, float((a - b).abs().max()) / den)
+    assert worst < 2e-5, worst
+    print(f"largest relative difference of a parameter gradient, f16x2 vs bf16x3 backward sweeps: {worst:.2e}")
+
+
+def test_tile_scale_is_refused_on_a_sweep_that_is_not_linear(dev):
+    from neuraludf_amd import _lib, mlp
+    from neuraludf_amd.models import fields
+    mlp.set_precision("bf16x3")
+    udf = perturb_(build_modules(fields, seed=0))["udf"].to(dev)
+    eng = udf.engine()
+    eng.forward(torch.zeros(64, 3, device=dev), need_grad_state=False, feat_ld=288)      # (packs the operand fragments)
+    pl = eng.layers[1]
+    x = torch.zeros(64, mlp.k8(pl.inp), device=dev)
+    out = torch.empty(64, pl.out, device=dev)
+    cb = mlp.ChainBuilder(64, "LOAD", mlp.k8(pl.inp))
+    cb.init_load(x, x.shape[1])
+    cb.tile_scale()
+    cb.step("SOFTPLUS", pl.frag(mlp._kind("fwd", "fwd")), mlp.k8(pl.inp), pl.out, bias=pl.bias, C1=out)
+    with pytest.raises(_lib.NudfError):
+        cb.launch()
