@@ -18,8 +18,9 @@ reduced with MAX over ranks; `ms_per_step` is the MEDIAN window, `window_ms` lis
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel class of the step (the fused layer-chain kernel `mlp_chain_kernel`): flops its
                   launches execute / their summed duration, measured with HIP events on the launch stream during one extra
-                  instrumented step.  Default mode bf16x3 (fp32 emulated on the bf16 matrix pipe, six bf16 MFMA products per
-                  fp32 product): executed flops = 6 x 2 M N K against the dense bf16 peak 2.5 PFLOP/s, with the
+                  instrumented step.  Default mode "bf16x3" (fp32 emulated on the 16-bit matrix pipe: three fp16 MFMA products per
+                  fp32 product, six bf16 ones where a switch asks for them -- `dtype` says which): executed flops = 3 x / 6 x
+                  2 M N K per launch against the dense 16-bit peak 2.5 PFLOP/s, with the
                   fp32-equivalent rate beside the 157.3 TFLOP/s of the fp32 MFMA pipe (`--precision fp32`: the exact
                   v_mfma_f32_32x32x2_f32 kernels against 157.3); traffic = HBM bytes per launch from the committed rocprofv3
                   PMC passes over this command (profiles/r06_traffic_mlp_chain_<mode>.json, see `traffic_stale`).
@@ -58,11 +59,13 @@ def dtype_string(precision):
     b3 = "bf16x3 (operands split exactly into 3 bf16 parts, 6 bf16 MFMA products per f32 product)"
     f2 = "f16x2 (x = hi + 2^-11 lo in fp16, 3 fp16 MFMA products, correction terms in their own accumulator)"
     fwd = f2 if mlp.FWD_F16X2 != "0" else b3
+    bwd = (f2 + ", every tile of 64 points multiplied by its own power of two so that the loss adjoints lie in fp16's range "
+           "(NudfChain.tile_scale: exact, memory holds the unscaled values)") if mlp._sweep_dtype("bwd") == "f16x2" else b3
     tn = ("f16x2 for the UDF and colour networks (each operand scaled by a power of two from its maximum, tracked on the device "
           "by the sweep that wrote it), bf16x3 for the background NeRF") if mlp.TN_F16X2 else "bf16x3"
-    return ("f32 emulated on the 16-bit matrix pipe, f32 accumulate, f32 state / epilogues / optimizer.  Backward sweeps (tangent, "
-            f"adjoint, ReLU backward): {b3}.  Forward-order sweeps (UDF value, input gradient, colour / NeRF forward): "
-            f"{fwd if fwd is f2 else 'bf16x3 (NUDF_FWD_F16X2=0)'}.  Weight-gradient GEMMs: {tn}.  fp32-level accuracy against float64 "
+    return ("f32 emulated on the 16-bit matrix pipe, f32 accumulate, f32 state / epilogues / optimizer.  Forward-order sweeps (UDF "
+            f"value, input gradient, colour / NeRF forward): {fwd if fwd is f2 else 'bf16x3 (NUDF_FWD_F16X2=0)'}.  Backward sweeps "
+            f"(tangent, adjoint, ReLU backward): {bwd}.  Weight-gradient GEMMs: {tn}.  fp32-level accuracy against float64 "
             "in each (tests/test_gpu_bf16x3.py, tests/test_gpu_round6.py)")
 
 
@@ -641,9 +644,9 @@ def main():
         if rank != 0:
             return None
         # flops the launches EXECUTE on the pipe they run on: algorithmic (2 M N K) for the fp32 and 16-bit modes; in the
-        # bf16x3 mode six bf16 MFMA products per fp32 product on the backward sweeps and the weight-gradient GEMMs (when they
-        # take split operands), THREE fp16 products on the forward-order sweeps that run the f16x2 split (mlp.FWD_F16X2) --
-        # every chain launch reports its own executed flops (mlp.MFMA_PRODUCTS by step), the GEMM class the factor below
+        # bf16x3 mode six bf16 MFMA products per fp32 product where a launch contracts with the 3-way bf16 split, THREE fp16
+        # products where it runs the f16x2 split (mlp.FWD_F16X2 / BWD_F16X2 / TN_F16X2: by default every sweep and the UDF /
+        # colour weight-gradient GEMMs) -- every launch reports its own executed flops (mlp.MFMA_PRODUCTS by step / group)
         x3 = precision == "bf16x3"
         cls_factor = lambda k: (X3_PRODUCTS if x3 and (k != "gemm_tn" or mlp.TN_SPLIT) else 1)
         agg, per = {}, {}
@@ -671,8 +674,8 @@ def main():
                 "traffic": None, "launches_per_step": n, "avg_launch_us": sec / n * 1e6,
                 "algorithmic_gflop_per_step": fl / 1e9, "executed_flops_per_algorithmic_flop": factor[dom],
                 # the convention of `achieved` / `frac`, in one key
-                "flops": ("executed on the 16-bit matrix pipe: 6 bf16 products per fp32 product on the backward sweeps (bf16x3), "
-                          "3 fp16 products on the forward-order sweeps (f16x2) -- %.2f x the algorithmic 2 M N K of SURVEY 8(d) "
+                "flops": ("executed on the 16-bit matrix pipe: every launch reports its own products per fp32 product -- 3 (f16x2) or "
+                          "6 (bf16x3), see `dtype` for which sweeps run which -- %.2f x the algorithmic 2 M N K of SURVEY 8(d) "
                           "over the class" % factor[dom] if x3 else "algorithmic 2 M N K"),
                 "frac_algorithmic_vs_fp32_pipe": fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS}
         if x3:

@@ -559,7 +559,8 @@ typedef struct NudfChainStep {
                                       acc0 + 2^-11 acc1 (the correction terms in their own fp32 accumulator); dropped:
                                       lo lo' <= 2^-22 |x| |y|.  For operands inside fp16's range (|x| < 65504; below
                                       6e-5 the split keeps an ABSOLUTE resolution of ~3e-11): the forward-order sweeps
-                                      (encodings, activations, weight-normed weights), not the adjoints of the backward
+                                      (encodings, activations, weight-normed weights) as they are; the backward sweeps,
+                                      whose operands are adjoints of the loss, with NudfChain.tile_scale
                                       (Bp: the two-plane layout of NudfPackFrag.dtype 4)                                */
   int32_t act_write;               /* 1: the outputs become the next step's activation tile          */
   int32_t act_col0;                /* ... at tile columns [act_col0, act_col0 + N)                   */

@@ -9,6 +9,7 @@ last $F/bench_again.json > $P/r06_bench_final_run2.json
 last $F/bench_fwd_bf16x3.json > $P/r06_bench_ab_bf16x3_everywhere.json
 last $F/bench_exstored.json > $P/r06_bench_ab_ex_stored.json
 last $F/bench_tn_bf16x3.json > $P/r06_bench_ab_tn_bf16x3.json
+last $F/bench_bwd_bf16x3.json > $P/r06_bench_ab_bwd_bf16x3.json
 last $F/bench_eager.json > $P/r06_bench_final_eager.json
 last $F/bench_256.json > $P/r06_bench_256rays.json
 last $F/bench_256_eager.json > $P/r06_bench_256rays_eager.json

@@ -20,10 +20,11 @@ timeout 300 python bench.py --workload dtu_scan24_1024x256 --steps 10 --warmup 3
 timeout 300 python bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg5_mixed16.json 2>> $O/bench.err
 NUDF_EX_FLY=0 timeout 300 python bench.py --workload dtu_scan24_1024x256 --precision mixed16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg5_mixed16_exstored.json 2>> $O/bench.err
 # round-6 A/B legs at the headline: six bf16 products on the forward-order sweeps (round 5's arithmetic), the stored second-order
-# term, and bf16x3 weight-gradient GEMMs
+# term, bf16x3 weight-gradient GEMMs, bf16x3 backward sweeps
 NUDF_FWD_F16X2=0 timeout 300 python bench.py --no-cpu-baseline --no-fp32-leg > $O/bench_fwd_bf16x3.json 2>> $O/bench.err
 NUDF_EX_FLY=0 timeout 300 python bench.py --no-cpu-baseline --no-fp32-leg > $O/bench_exstored.json 2>> $O/bench.err
 NUDF_TN_F16X2=0 timeout 300 python bench.py --no-cpu-baseline --no-fp32-leg > $O/bench_tn_bf16x3.json 2>> $O/bench.err
+NUDF_BWD_F16X2=0 timeout 300 python bench.py --no-cpu-baseline --no-fp32-leg > $O/bench_bwd_bf16x3.json 2>> $O/bench.err
 timeout 300 python bench.py --no-cpu-baseline --no-fp32-leg > $O/bench_again.json 2>> $O/bench.err
 timeout 300 python bench.py --workload dtu_scan118_4096x128 --steps 5 --warmup 2 --windows 3 --no-cpu-baseline --no-fp32-leg > $O/bench_strong4096.json 2>> $O/bench.err
 # rocprofv3 kernel trace + stats of the default command (same build, same flags)
@@ -63,7 +64,7 @@ BENCH_ARGS="--workload garment_blend_1024x128" bash scripts/trace_step_seq.sh > 
 BENCH_ARGS="" bash scripts/trace_step_seq.sh > $O/step_sequence_graph.txt 2>&1
 (nproc; grep -m1 "model name" /proc/cpuinfo; rocm-smi --showproductname 2>/dev/null | head -12; git -C $R rev-parse HEAD 2>/dev/null; sha256sum $R/neuraludf_amd/libnudf.so) > $O/provenance.txt 2>&1
 tail -n 3 $O/pytest_gpu.log; tail -n 1 $O/smoke.log
-for f in bench bench_again bench_fwd_bf16x3 bench_exstored bench_tn_bf16x3 bench_eager bench_256 bench_256_eager bench_fp32_exact bench_mixed16 bench_shipped bench_blend bench_cfg5_bf16x3 bench_cfg5_mixed16 bench_cfg5_mixed16_exstored bench_strong4096; do python -c "
+for f in bench bench_again bench_fwd_bf16x3 bench_exstored bench_tn_bf16x3 bench_bwd_bf16x3 bench_eager bench_256 bench_256_eager bench_fp32_exact bench_mixed16 bench_shipped bench_blend bench_cfg5_bf16x3 bench_cfg5_mixed16 bench_cfg5_mixed16_exstored bench_strong4096; do python -c "
 import json,sys
 try:
     d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1])

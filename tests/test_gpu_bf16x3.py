@@ -50,8 +50,8 @@ def test_chain_outputs_against_float64(dev):
         ref = O.udf_forward(n64.udf, x.double())
     gref = O.udf_gradient(n64.udf, x.double(), create_graph=False)
     res = {}
-    # "bf16x3": six bf16 products on every sweep (mlp.FWD_F16X2 = "0"); "f16x2": the library default -- the forward sweep
-    # and the input-gradient sweep on THREE fp16 products (NudfChainStep.prec 4)
+    # "bf16x3": six bf16 products on every sweep (mlp.FWD_F16X2 = "0"); "f16x2": the library default -- THREE fp16 products
+    # (NudfChainStep.prec 4) on every sweep, the backward ones with per-tile scaling (NudfChain.tile_scale)
     for mode, prec, fwd in (("fp32", "fp32", "1"), ("bf16x3", "bf16x3", "0"), ("f16x2", "bf16x3", "1")):
         mlp.set_precision(prec)
         mlp.set_fwd_split(fwd)
@@ -81,7 +81,7 @@ def test_full_backward_parameter_gradients_match_exact_fp32(dev):
         outs[mode] = {k: v.detach().float().clone() for k, v in CS.sweeps(dev, 8192, 0, seed=3).items()}
         torch.cuda.synchronize()
     _compare_with_exact_fp32(outs["fp32"], outs["bf16x3"], "bf16x3 everywhere")
-    _compare_with_exact_fp32(outs["fp32"], outs["f16x2"], "f16x2 forward-order sweeps + bf16x3 backward sweeps (the default)")
+    _compare_with_exact_fp32(outs["fp32"], outs["f16x2"], "f16x2 on every sweep, the backward ones tile-scaled (the default)")
 
 
 def _compare_with_exact_fp32(a, b, what):
