@@ -18,8 +18,9 @@ def engines(dev):
     return _state
 
 
-def sweeps(dev, P, tile, seed=0, S=64):
-    """tile: 0 = automatic, 32 / 64 = workgroup-shared tiles, 128 = wave-private tiles."""
+def sweeps(dev, P, tile, seed=0, S=64, seed_scale=1.0):
+    """tile: 0 = automatic, 32 / 64 = workgroup-shared tiles, 128 = wave-private tiles.  seed_scale multiplies every loss adjoint
+    the backward sweeps start from (d udf, d grad, d colour, d logits, the NeRF's d sigma / d rgb)."""
     st_ = engines(dev)
     eng, ceng, nerf = st_["eng"], st_["ceng"], st_["nerf"]
     old_tile = mlp.CHAIN_TILE
@@ -27,8 +28,8 @@ def sweeps(dev, P, tile, seed=0, S=64):
     try:
         g = torch.Generator().manual_seed(seed)
         x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
-        d_udf = torch.randn(P, generator=g).to(dev)
-        d_g = torch.randn(P, 3, generator=g).to(dev)
+        d_udf = torch.randn(P, generator=g).to(dev) * seed_scale
+        d_g = torch.randn(P, 3, generator=g).to(dev) * seed_scale
         rays_d = torch.nn.functional.normalize(torch.randn((P + S - 1) // S, 3, generator=g), dim=-1).to(dev)
         out = {}
         st = eng.forward(x, need_grad_state=True, feat_ld=ceng.cin_ld)
@@ -45,9 +46,9 @@ def sweeps(dev, P, tile, seed=0, S=64):
             out.update(cb=cb, cc=cc)
             if logits is not None:
                 out["logits"] = logits
-            d_cb = torch.randn(Pc, 3, generator=g).to(dev)
-            d_cc = torch.randn(Pc, 3, generator=g).to(dev)
-            d_lg = torch.randn(Pc, logits.shape[1], generator=g).to(dev) if logits is not None else None
+            d_cb = torch.randn(Pc, 3, generator=g).to(dev) * seed_scale
+            d_cc = torch.randn(Pc, 3, generator=g).to(dev) * seed_scale
+            d_lg = torch.randn(Pc, logits.shape[1], generator=g).to(dev) * seed_scale if logits is not None else None
             cgr, dCIN = ceng.backward(cst, cb, cc, d_cb, d_cc, d_lg)
             out["dCIN"] = dCIN[:Pc, :256]
             for i, t in enumerate(cgr):
@@ -62,7 +63,8 @@ def sweeps(dev, P, tile, seed=0, S=64):
             pts4 = torch.randn(Pn, 4, generator=g).to(dev) * 0.5
             sig, rgb = nerf.evaluate(pts4, rays_d[:Pn // S].contiguous(), S)
             out.update(nsig=sig.detach(), nrgb=rgb.detach())
-            (sig.sum() + (rgb * torch.randn(rgb.shape, generator=g).to(dev)).sum()).backward()
+            (sig.sum() + (rgb * torch.randn(rgb.shape, generator=g).to(dev)).sum()).backward(
+                gradient=torch.tensor(float(seed_scale), device=dev))
             for i, prm in enumerate(nerf.parameters()):
                 if prm.grad is not None:
                     out[f"n{i}"] = prm.grad.detach().clone()

@@ -165,6 +165,29 @@ def test_backward_sweeps_scale_exactly_with_a_power_of_two_of_the_loss(dev):
             assert torch.equal(a * 2.0 ** k, b), (k, i, float((a * 2.0 ** k - b).abs().max()), float(b.abs().max()))
 
 
+def test_every_backward_sweep_scales_exactly_with_a_power_of_two_of_its_seeds(dev):
+    """The same property over ALL reverse chains of a step (tests/chain_sweeps.py): UDF tangent + adjoint, the colour network's
+    view- and base-branch ReLU backward (the second one joins the first one's d VIN through X2: ADDMASK), the NeRF's (rank-1
+    operand on a later step) -- every parameter gradient and d CIN times exactly 2^-30, every forward value unchanged."""
+    import re
+    import chain_sweeps as CS
+    from neuraludf_amd import mlp
+    mlp.set_precision("bf16x3")
+    assert mlp._sweep_dtype("bwd") == "f16x2"
+    base = {k: v.detach().clone() for k, v in CS.sweeps(dev, 8192, 0, seed=3).items()}
+    got = CS.sweeps(dev, 8192, 0, seed=3, seed_scale=2.0 ** -30)
+    torch.cuda.synchronize()
+    n_grad = 0
+    for k, a in base.items():
+        if re.fullmatch(r"(p|cg|n)\d+|dCIN", k):
+            assert float(a.abs().max()) > 0.0, k
+            assert torch.equal(a * 2.0 ** -30, got[k]), (k, float((a * 2.0 ** -30 - got[k]).abs().max()), float(got[k].abs().max()))
+            n_grad += 1
+        else:
+            assert torch.equal(a, got[k]), k
+    assert n_grad >= 60, n_grad
+
+
 def test_f16x2_backward_sweeps_against_the_range_free_bf16x3_sweeps(dev):
     """Same gradients as the six-product sweeps, to the rounding of two fp32 emulations -- with the loss adjoints of the points
     spread over 40 binades (every tile of 64 points its own scale, many of them far outside fp16's range) and a block of
