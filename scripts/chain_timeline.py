@@ -36,7 +36,7 @@ def launch(self):
         mlp.CHAIN_DEBUG = dbg
         orig_launch(self)            # (fills the descriptor: the builder only records until launch)
         steps = [(int(self.c.step[i].epi), int(self.c.step[i].K), int(self.c.step[i].N)) for i in range(self.n)]
-        launches.append((dbg, steps, self.flops))
+        launches.append((dbg, steps, self.flops, [int(self.c.step[i].prec) for i in range(self.n)]))
         return
     orig_launch(self)
 
@@ -72,7 +72,7 @@ mlp.CHAIN_DEBUG = None
 from neuraludf_amd._lib import CH as _CH
 EPI = {v: k for k, v in _CH.items()}
 
-for li, (dbg, steps, flops) in enumerate(launches):
+for li, (dbg, steps, flops, precs) in enumerate(launches):
     d = dbg.cpu().numpy()
     d = d[d[:, 1] > 0]
     n = len(steps)
@@ -89,7 +89,13 @@ for li, (dbg, steps, flops) in enumerate(launches):
         per_step.append(((a - prev).mean(), (b - a).mean(), (c - b).mean(), (e - c).mean()))
         prev = e
     tot = k + w1 + ep + w2
-    mfma_cycles = flops / P * 64 / 4 / (2 * 32 * 32 * 2) * 64     # per wave of a 64-point tile: flops/point * 64 / 4 waves / flops per MFMA * 64
+    # matrix-pipe cycles per wave of a 64-point tile: algorithmic flops per point x 64 / 4 waves, per step on the pipe it runs on --
+    # fp32: v_mfma_f32_32x32x2_f32 = 4 096 flops in 64 cycles; 16-bit: v_mfma_f32_32x32x16 = 32 768 flops in 32 cycles, times the
+    # products of the step's operand mode (1: plain 16-bit, 6: bf16x3, 3: f16x2)
+    mfma_cycles = 0.0
+    for (epi_, K_, N_), pr in zip(steps, precs):
+        fl = 2.0 * K_ * N_ * 64 / 4            # (padded K, N: what the tile loop executes)
+        mfma_cycles += fl / 4096 * 64 if pr == 0 else fl * mlp.MFMA_PRODUCTS[pr] / 32768 * 32
     wall = (d[:, 63] - d[:, 62]).astype(np.float64)            # 100 MHz ticks
     mem = (d[:, 5 + 4 * (n - 1)] - d[:, 1]).astype(np.float64)
     ok = wall > 0
