@@ -235,3 +235,4 @@ def test_tile_scale_is_refused_on_a_sweep_that_is_not_linear(dev):
     cb.step("SOFTPLUS", pl.frag(mlp._kind("fwd", "fwd")), mlp.k8(pl.inp), pl.out, bias=pl.bias, C1=out)
     with pytest.raises(_lib.NudfError):
         cb.launch()
+
