@@ -8,7 +8,7 @@ path (render + colour/eikonal loss + backward + Adam) on synthetic DTU-scan24-sh
     python bench.py --gpus N ...      (no launcher: bench.py starts the N ranks itself through torch.distributed.run)
 
 Workload (BASELINE.json configs[1]): 512 rays x 128 samples per GPU (64 coarse + 64 hierarchical in
-4 rounds, no outside samples); arithmetic: fp32 EMULATED on the bf16 matrix pipe (`--precision bf16x3`, the default; `fp32`
+4 rounds, no outside samples); arithmetic: fp32 EMULATED on the 16-bit matrix pipe (`--precision bf16x3`, the default; `fp32`
 = the exact v_mfma_f32_32x32x2_f32 kernels, also timed here as the secondary `fp32_exact` leg).  With N GPUs the global
 batch is 512*N rays, ray-sharded, one packed loss all-reduce + one gradient all-reduce per step (weak scaling);
 `--scaling strong --global-rays 4096` (BASELINE configs[3]) fixes the global batch and gives every rank 4096 / N rays.
@@ -590,6 +590,12 @@ def main():
                    "samples_per_ray": s_core, "n_outside": rconf["n_outside"],
                    "step": "render + L1/eikonal loss + backward + Adam", "parallelism": f"ray-sharded dp{world}",
                    "optimizer": "fused HIP Adam" if fused else "torch.optim.Adam",
+                   # (the mode name is historical: which split each sweep class / the GEMMs actually ran -- see `dtype`)
+                   "operand_mode": {"precision": args.precision, "forward_order_sweeps": mlp._sweep_dtype("fwd"),
+                                    "input_gradient_sweep": mlp._sweep_dtype("grad"), "backward_sweeps": mlp._sweep_dtype("bwd"),
+                                    "weight_gradient_gemms": ("f16x2 (UDF, colour) / bf16x3 (NeRF)" if (mlp.TN_F16X2 and
+                                                              args.precision == "bf16x3") else mlp._sweep_dtype("bwd")
+                                                              if args.precision != "bf16x3" else "bf16x3")},
                    "launch": ("HIP graph replay: one graph launch + one 0.8 KB H2D copy of the step's scalars per step "
                               "(train.GraphedStep; replays are bit-identical to eager steps, tests/test_gpu_graph.py)"
                               + ("; the two RCCL all-reduces of the ray-sharded step are nodes of the graph" if world > 1 else ""))
